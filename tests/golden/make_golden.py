@@ -1,0 +1,90 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (build container only).
+
+    python tests/golden/make_golden.py
+
+Imports /root/reference under the stand-ins of refimport.py, loads the build's deterministic synthetic
+weights (umgen_amd.weights.synthetic_state_dict) into the reference ``UMGen`` at the tiny config, runs
+``UMGen.inference`` in full-greedy mode on synthetic scenes and stores the emitted token sequences plus a
+few intermediate activations (conditioning rows, ego logits, selected OAR logit rows).  Fixtures hold data
+only (inputs are regenerated from seeds; outputs are stored); no reference source is copied.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import refimport  # noqa: E402
+from umgen_amd.config import tiny_config  # noqa: E402
+from umgen_amd.synth import synthetic_control, synthetic_scene  # noqa: E402
+from umgen_amd.weights import synthetic_state_dict  # noqa: E402
+
+LOGIT_POS = {"map": [0, 1, 511, 1023], "bbox3d": [0, 9, 10, 11, 330, 659], "image": [0, 255, 511]}
+COND_ROWS = [0, 1, 4, 5, 6, 500, 1030, 1031, 1032, 1042, 1692, 1693, 1694, 2000, 2206]
+
+
+def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, new_frames, control):
+    sd = synthetic_state_dict(cfg, seed=weight_seed)
+    model = refimport.build_reference_model(cfg, sd, greedy=True)
+    scene = synthetic_scene(scene_id, n_frames=input_cond_frames)
+    tokens = {k: torch.from_numpy(v) for k, v in scene.items()}
+    init = None
+    if control:
+        init = {k: torch.from_numpy(v) for k, v in synthetic_control(scene_id, n_frames=new_frames).items()}
+
+    rec = {"cond": [], "ego_logits": [], "logits": {m: [] for m in LOGIT_POS}, "count": {m: 0 for m in LOGIT_POS}}
+    orig_oar = model.infer_oar_net
+
+    def oar_spy(tar_emb, *a, **k):
+        cat = torch.cat([tar_emb[m] for m in ("pose", "map", "bbox3d", "image")], dim=-2)
+        rec["cond"].append(cat[0, -1, COND_ROWS].detach().numpy().copy())
+        for m in rec["count"]:
+            rec["count"][m] = 0
+        return orig_oar(tar_emb, *a, **k)
+
+    model.infer_oar_net = oar_spy
+    model.transformer.head_ego.register_forward_hook(
+        lambda mod, i, o: rec["ego_logits"].append(o[0, -1].detach().numpy().copy()))
+
+    def mk(modname):
+        def hook(mod, i, o):
+            if len(rec["cond"]) == 1 and rec["count"][modname] in LOGIT_POS[modname]:
+                rec["logits"][modname].append(o.reshape(-1, o.shape[-1])[-1].detach().numpy().copy())
+            rec["count"][modname] += 1
+        return hook
+
+    model.transformer.head_ar_map.register_forward_hook(mk("map"))
+    model.transformer.head_ar_bbox3d.register_forward_hook(mk("bbox3d"))
+    model.transformer.head_ar_img.register_forward_hook(mk("image"))
+
+    out = model.inference(new_frames=new_frames, cond_frames=cond_frames, pred_task="pose_map_bbox3d_image",
+                          input_cond_tokens=tokens, init_tokens=init, input_cond_frames=input_cond_frames,
+                          control_test=control, cond_on_par=True, infer_from_gt=False)
+    blob = {f"out_{m}": out[m].astype(np.int16) for m in out}
+    blob["cond_rows"] = np.stack(rec["cond"]).astype(np.float32)
+    if rec["ego_logits"]:
+        blob["ego_logits"] = np.stack(rec["ego_logits"]).astype(np.float32)
+    for m in LOGIT_POS:
+        blob[f"logits_{m}"] = np.stack(rec["logits"][m]).astype(np.float32)
+    blob["meta"] = np.array([weight_seed, scene_id, cond_frames, input_cond_frames, new_frames, int(control)], dtype=np.int64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **blob)
+    print("wrote", path, {k: v.shape for k, v in blob.items()})
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cfg = tiny_config()
+    run_case("tiny_video_greedy", cfg, weight_seed=1, scene_id=0, cond_frames=3, input_cond_frames=3, new_frames=2, control=False)
+    run_case("tiny_control_greedy", cfg, weight_seed=2, scene_id=1, cond_frames=3, input_cond_frames=2, new_frames=3, control=True)
+
+
+if __name__ == "__main__":
+    if not refimport.reference_available():
+        sys.exit("reference not present; goldens can only be (re)generated in the build container")
+    main()
