@@ -1,0 +1,138 @@
+/*
+ * umgen.h -- C ABI of libumgen_hip.so, the MI355X (gfx950) next-scene rollout engine for UMGen.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference (YanhaoWu/UMGen):
+ *     UMGen.inference(...)                       projects/models/UMGen.py:1542-1671
+ * reached through the model registry             projects/registry.py:1-3, UMGen.py:51-52
+ * from                                           projects/tools/model_pl.py:173-175, 237-239.
+ * The reference has no FFI of its own (it is pure PyTorch); a maintainer binds these entry points
+ * with ctypes from a `UMGen(nn.Module)` shim -- see INTEGRATION.md and umgen_amd/model.py.
+ *
+ * Conventions: plain C, no exceptions across the boundary.  Every function returns 0 on success
+ * or a negative UMGEN_E_* code; umgen_last_error() gives the message.  All pointer arguments are
+ * HOST pointers to contiguous arrays owned by the caller (the library copies); a handle owns one
+ * HIP stream and is not thread-safe.  Token arrays are int64 like the reference's LongTensors.
+ */
+#ifndef UMGEN_H_
+#define UMGEN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMGEN_ABI_VERSION 1
+
+enum {
+    UMGEN_OK = 0,
+    UMGEN_E_INVALID = -1,   /* bad argument / shape / key          */
+    UMGEN_E_STATE = -2,     /* call order (e.g. rollout before finalize) */
+    UMGEN_E_HIP = -3,       /* HIP runtime error                   */
+    UMGEN_E_NOMEM = -4,
+    UMGEN_E_UNSUPPORTED = -5
+};
+
+enum { UMGEN_PREC_FP32 = 0, UMGEN_PREC_BF16 = 1 };
+enum { UMGEN_DT_F32 = 0, UMGEN_DT_BF16 = 1, UMGEN_DT_F16 = 2, UMGEN_DT_F64 = 3 };
+enum { UMGEN_SAMPLE_TOPK = 0, UMGEN_SAMPLE_TOPP = 1 };
+
+/* scene-sequence constants (infer_fun.py:112-118): content tokens per frame */
+#define UMGEN_S_POSE 3
+#define UMGEN_S_MAP 1024
+#define UMGEN_S_BBOX3D 660
+#define UMGEN_S_IMAGE 512
+#define UMGEN_SEQ_LEN 2207
+
+typedef struct umgen_engine umgen_engine; /* opaque */
+
+/* Mirrors the resolved `config` Namespace read in UMGen.__init__ (UMGen.py:53-172). */
+typedef struct umgen_config {
+    int32_t abi_version; /* = UMGEN_ABI_VERSION */
+    int32_t n_embd, n_head;
+    int32_t n_ego_tar_layer, n_ego_ca_layer, n_map_tar_layer, n_box_tar_layer, n_tar_layer, n_oar_layer;
+    int32_t pose_vocab, map_vocab, bbox3d_vocab, img_vocab, aux_vocab;
+    int32_t n_map_embd, n_img_embd;
+    int32_t max_frame_len; /* rows of tpe */
+    int32_t task_num, task_id;
+    int32_t precision;       /* UMGEN_PREC_* */
+    int32_t max_batch;       /* scenes rolled out together on this GPU */
+    int32_t max_cond_frames; /* history window T (reference: 20) */
+    int32_t device;          /* HIP device ordinal */
+    int32_t use_graphs;      /* 1 = replay the decode step from a hipGraph */
+} umgen_config;
+
+/* Sampler parameters (UMGen.py:99-126; infer_task_config, config.py:442-463). */
+typedef struct umgen_sampling {
+    int32_t method;                     /* UMGEN_SAMPLE_* */
+    int32_t top_k, top_k_map, topk_image;
+    float p, p_map, temperature;
+    int32_t rule_constrain;             /* evaluate.py:59-63, UMGen.py:1116-1123 */
+    int32_t merge_ar_tar, only_ar;      /* UMGen.py:1092-1104 */
+    const uint64_t *seeds;              /* [B] per-scene RNG seed (counter-based) */
+} umgen_sampling;
+
+/* Optional per-frame trace of one scene (teacher-forced logit parity; replaces SURVEY's umgen_step_logits).
+ * Any pointer may be NULL.  Sizes use the engine's n_embd / vocab sizes. */
+typedef struct umgen_trace {
+    float *cond;            /* [2207][n_embd]  conditioning rows fed to the OAR (UMGen.py:1227-1231) */
+    float *ego_logits;      /* [3][pose_vocab]                                  (UMGen.py:1001-1002) */
+    float *logits_map;      /* [1024][map_vocab]                                 (UMGen.py:1062)      */
+    float *logits_bbox3d;   /* [660][bbox3d_vocab]                               (UMGen.py:1072)      */
+    float *logits_image;    /* [512][img_vocab]                                  (UMGen.py:1132)      */
+    const int64_t *forced_pose, *forced_map, *forced_bbox3d, *forced_image; /* teacher forcing, [S_mod] */
+} umgen_trace;
+
+/* Event-timed phases of the last umgen_rollout call (milliseconds, HIP events on the engine stream). */
+typedef struct umgen_timings {
+    double total_ms, ego_ms, tar_ms, oar_ms;
+    int64_t frames, oar_steps, oar_kernels;
+    double gemm_ms;         /* sum over launches of the TAR/ego GEMM kernel (when profiling enabled) */
+    int64_t gemm_launches;
+    double gemm_flops;      /* algorithmic FLOPs of those launches */
+    double oar_bytes;       /* algorithmic HBM bytes of the decode steps */
+} umgen_timings;
+
+/* UMGen(config)  -- UMGen.py:53 */
+int umgen_create(const umgen_config *cfg, umgen_engine **out);
+
+/* model.load_state_dict(ckpt["module"], strict=False) -- infer_fun.py:43-50.  One call per state-dict entry;
+ * unknown keys are ignored (returns 1), known keys are shape-checked and repacked to the kernel layouts. */
+int umgen_load_tensor(umgen_engine *e, const char *key, const void *data, int32_t dtype,
+                      const int64_t *shape, int32_t ndim);
+
+/* Builds derived tables (GMLP(codebook) rows, sinusoid tables if not loaded) and checks that every
+ * tensor the rollout reads has been loaded.  Corresponds to model.eval() readiness. */
+int umgen_finalize_weights(umgen_engine *e);
+
+/* UMGen.inference(new_frames, cond_frames, input_cond_frames=T_in, input_cond_tokens, init_tokens, control_test)
+ * for B independent scenes (the reference is B = 1; scenes never interact).
+ *   pose/map/bbox3d/image : [B][T_in][S_mod] int64 history tokens (first T_in frames are used)
+ *   ctrl_pose/ctrl_bbox3d : NULL, or [B][T_ctl][3] / [B][T_ctl][660] control tokens (init_tokens; -1 = free)
+ *   out_*                 : [B][T_in + new_frames][S_mod], caller-allocated
+ */
+int umgen_rollout(umgen_engine *e, int32_t B, int32_t T_in, int32_t new_frames, int32_t cond_frames,
+                  const int64_t *pose, const int64_t *map, const int64_t *bbox3d, const int64_t *image,
+                  int32_t T_ctl, const int64_t *ctrl_pose, const int64_t *ctrl_bbox3d, int32_t control_test,
+                  const umgen_sampling *sampling,
+                  int64_t *out_pose, int64_t *out_map, int64_t *out_bbox3d, int64_t *out_image);
+
+/* One frame of one scene (UMGen._inference, UMGen.py:1406-1540) with optional trace / teacher forcing.
+ * Window tokens are [T][S_mod]; ctrl_* are NULL or the [S_mod] control tokens of this frame.
+ * out_* receive the new frame's tokens [S_mod]. */
+int umgen_frame(umgen_engine *e, int32_t T, const int64_t *pose, const int64_t *map, const int64_t *bbox3d,
+                const int64_t *image, const int64_t *ctrl_pose, const int64_t *ctrl_bbox3d, int32_t control_test,
+                const umgen_sampling *sampling, int32_t frame_idx, const umgen_trace *trace,
+                int64_t *out_pose, int64_t *out_map, int64_t *out_bbox3d, int64_t *out_image);
+
+int umgen_set_profiling(umgen_engine *e, int32_t enable); /* per-launch HIP-event timing of the GEMM kernel */
+int umgen_get_timings(umgen_engine *e, umgen_timings *out);
+
+const char *umgen_last_error(const umgen_engine *e); /* never NULL */
+const char *umgen_version(void);
+int umgen_destroy(umgen_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMGEN_H_ */

@@ -1,0 +1,128 @@
+"""-m gpu: each hand-written HIP kernel against an fp64/fp32 CPU restatement of the reference op, at the
+production width (E=768, H=16, head_dim 48) and with ragged sizes (S=2207 is not a multiple of any tile)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import bf16_bits, bf16_round, check, fp, from_bits, lib, vp
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_linear(act, W, bias, gelu, resid):
+    o = act.astype(np.float64) @ W.astype(np.float64).T
+    if bias is not None:
+        o = o + bias.astype(np.float64)
+    if gelu:
+        o = torch.nn.functional.gelu(torch.from_numpy(o)).numpy()
+    if resid is not None:
+        o = o + resid.astype(np.float64)
+    return o
+
+
+@pytest.mark.parametrize("R,N,K,gelu,resid", [(300, 2304, 768, 0, 0), (2207, 768, 3072, 0, 1), (513, 3072, 768, 1, 0),
+                                               (97, 288, 96, 0, 0), (130, 96, 384, 0, 1)])
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_linear(bf16, R, N, K, gelu, resid):
+    rng = np.random.default_rng(R + N + K)
+    act = rng.standard_normal((R, K), dtype=np.float32)
+    W = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal((N,), dtype=np.float32) * 0.1
+    x0 = rng.standard_normal((R, N), dtype=np.float32) if resid else None
+    if bf16:
+        a_in, w_in = bf16_bits(act), bf16_bits(W)
+        act, W = bf16_round(act), bf16_round(W)
+    else:
+        a_in, w_in = act, W
+    out = x0.copy() if resid else np.zeros((R, N), dtype=np.uint16 if bf16 else np.float32)
+    check(lib().umgen_dbg_linear(bf16, vp(a_in), vp(w_in), fp(bias), R, N, K, gelu, resid, vp(out)))
+    got = out if (resid or not bf16) else from_bits(out)
+    ref = ref_linear(act, W, bias, gelu, x0)
+    # fp32 path: summation-order noise only; bf16 path: exact products, fp32 accumulate, (bf16 output rounding when stored)
+    tol = 2e-5 if not bf16 else (2e-5 if resid else 1.2e-2)
+    np.testing.assert_allclose(got, ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)
+
+
+def ref_attention(q, k, v, H, causal):
+    B, Tq, E = q.shape
+    D = E // H
+    qh = torch.from_numpy(q).double().view(B, Tq, H, D).permute(0, 2, 1, 3)
+    kh = torch.from_numpy(k).double().view(B, -1, H, D).permute(0, 2, 1, 3)
+    vh = torch.from_numpy(v).double().view(B, -1, H, D).permute(0, 2, 1, 3)
+    att = (qh @ kh.transpose(-1, -2)) * float(np.float32(1.0 / np.sqrt(D)))
+    if causal:
+        Tk = k.shape[1]
+        i = torch.arange(Tq).view(-1, 1)
+        j = torch.arange(Tk).view(1, -1)
+        att = att.masked_fill(j > i + (Tk - Tq), float("-inf"))
+    return (torch.softmax(att, -1) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, E).numpy()
+
+
+@pytest.mark.parametrize("F,S,H", [(2, 2207, 16), (3, 1031, 2), (1, 70, 2), (2, 1693, 4)])
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_attn_spatial(bf16, F, S, H):
+    E = H * 48
+    rng = np.random.default_rng(S + H)
+    q = rng.standard_normal((F, S, E), dtype=np.float32) * 1.5
+    k = rng.standard_normal((F, S, E), dtype=np.float32) * 1.5
+    v = rng.standard_normal((F, S, E), dtype=np.float32)
+    if bf16:
+        q, k, v = bf16_round(q), bf16_round(k), bf16_round(v)
+    qk = np.ascontiguousarray(np.concatenate([q, k], axis=-1))
+    y = np.zeros((F, S, E), dtype=np.uint16 if bf16 else np.float32)
+    check(lib().umgen_dbg_attn_spatial(bf16, vp(bf16_bits(qk) if bf16 else qk), vp(bf16_bits(v) if bf16 else v), F, S, H, vp(y)))
+    got = from_bits(y) if bf16 else y
+    ref = ref_attention(q, k, v, H, False)
+    np.testing.assert_allclose(got, ref, atol=(2e-2 if bf16 else 2e-5), rtol=0)
+
+
+@pytest.mark.parametrize("B,T,S,H", [(1, 20, 333, 16), (2, 3, 100, 2)])
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_attn_temporal(bf16, B, T, S, H):
+    E = H * 48
+    rng = np.random.default_rng(T + S)
+    qkv = rng.standard_normal((B, T, S, 3 * E), dtype=np.float32)
+    if bf16:
+        qkv = bf16_round(qkv)
+    y = np.zeros((B, T, S, E), dtype=np.uint16 if bf16 else np.float32)
+    check(lib().umgen_dbg_attn_temporal(bf16, vp(bf16_bits(qkv) if bf16 else qkv), B, T, S, H, vp(y)))
+    got = from_bits(y) if bf16 else y
+    x = qkv.transpose(0, 2, 1, 3).reshape(B * S, T, 3 * E)        # (b s) t c
+    ref = ref_attention(np.ascontiguousarray(x[..., :E]), np.ascontiguousarray(x[..., E:2 * E]),
+                        np.ascontiguousarray(x[..., 2 * E:]), H, True)
+    ref = ref.reshape(B, S, T, E).transpose(0, 2, 1, 3)
+    np.testing.assert_allclose(got, ref, atol=(1.6e-2 if bf16 else 2e-5), rtol=0)
+
+
+@pytest.mark.parametrize("NQ,L,H", [(1, 1, 16), (1, 7, 16), (3, 2207, 16), (2, 1100, 2)])
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_attn_decode(bf16, NQ, L, H):
+    E = H * 48
+    rng = np.random.default_rng(L)
+    q = rng.standard_normal((NQ, E), dtype=np.float32)
+    kv = rng.standard_normal((L, 2 * E), dtype=np.float32)
+    if bf16:
+        kv = bf16_round(kv)
+    y = np.zeros((NQ, E), dtype=np.float32)
+    check(lib().umgen_dbg_attn_decode(bf16, fp(q), vp(bf16_bits(kv) if bf16 else kv), NQ, L, H, fp(y)))
+    ref = ref_attention(q[None], np.ascontiguousarray(kv[None, :, :E]), np.ascontiguousarray(kv[None, :, E:]), H, False)[0]
+    np.testing.assert_allclose(y, ref, atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("M,N,K,gelu,ln", [(1, 2304, 768, 0, 1), (3, 3072, 768, 1, 1), (8, 1028, 768, 0, 0), (11, 96, 96, 0, 1)])
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_gemv(bf16, M, N, K, gelu, ln):
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((M, K), dtype=np.float32) * 2 + 0.3
+    W = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    lw = (1 + 0.1 * rng.standard_normal((K,), dtype=np.float32)).astype(np.float32)
+    bias = rng.standard_normal((N,), dtype=np.float32) * 0.1
+    if bf16:
+        W = bf16_round(W)
+    out = np.zeros((M, N), dtype=np.float32)
+    check(lib().umgen_dbg_gemv(bf16, fp(x), fp(lw) if ln else None, vp(bf16_bits(W) if bf16 else W), fp(bias), M, N, K, gelu, fp(out)))
+    xin = torch.from_numpy(x).double()
+    if ln:
+        xin = torch.nn.functional.layer_norm(xin, (K,), torch.from_numpy(lw).double(), None, 1e-5)
+    ref = ref_linear(xin.numpy(), W, bias, gelu, None)
+    np.testing.assert_allclose(out, ref, atol=2e-5 * max(1.0, np.abs(ref).max()), rtol=0)

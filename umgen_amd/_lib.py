@@ -1,0 +1,112 @@
+"""ctypes binding of libumgen_hip.so (C ABI: include/umgen.h).  No torch types cross this boundary.
+
+The library is built in-tree by ``build_library()`` (hipcc --offload-arch=gfx950); loading fails loudly
+when it is missing -- there is no CPU fallback for the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libumgen_hip.so")
+SOURCES = ["engine.hip", "gemm.hip", "attn.hip", "gemv.hip", "rowops.hip", "frame.hip", "debug_api.hip"]
+EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen_rollout", "umgen_frame",
+           "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",
+           "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv"]
+
+PREC_FP32, PREC_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F16, DT_F64 = 0, 1, 2, 3
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "n_embd", "n_head", "n_ego_tar_layer", "n_ego_ca_layer", "n_map_tar_layer", "n_box_tar_layer",
+        "n_tar_layer", "n_oar_layer", "pose_vocab", "map_vocab", "bbox3d_vocab", "img_vocab", "aux_vocab",
+        "n_map_embd", "n_img_embd", "max_frame_len", "task_num", "task_id", "precision", "max_batch",
+        "max_cond_frames", "device", "use_graphs")]
+
+
+class Sampling(C.Structure):
+    _fields_ = [("method", C.c_int32), ("top_k", C.c_int32), ("top_k_map", C.c_int32), ("topk_image", C.c_int32),
+                ("p", C.c_float), ("p_map", C.c_float), ("temperature", C.c_float),
+                ("rule_constrain", C.c_int32), ("merge_ar_tar", C.c_int32), ("only_ar", C.c_int32),
+                ("seeds", C.POINTER(C.c_uint64))]
+
+
+class Trace(C.Structure):
+    _fields_ = [("cond", C.POINTER(C.c_float)), ("ego_logits", C.POINTER(C.c_float)),
+                ("logits_map", C.POINTER(C.c_float)), ("logits_bbox3d", C.POINTER(C.c_float)),
+                ("logits_image", C.POINTER(C.c_float)),
+                ("forced_pose", C.POINTER(C.c_int64)), ("forced_map", C.POINTER(C.c_int64)),
+                ("forced_bbox3d", C.POINTER(C.c_int64)), ("forced_image", C.POINTER(C.c_int64))]
+
+
+class Timings(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("ego_ms", C.c_double), ("tar_ms", C.c_double), ("oar_ms", C.c_double),
+                ("frames", C.c_int64), ("oar_steps", C.c_int64), ("oar_kernels", C.c_int64),
+                ("gemm_ms", C.c_double), ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("oar_bytes", C.c_double)]
+
+
+def hipcc_path() -> str:
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found: cannot build libumgen_hip.so")
+    return p
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950: compiles every HIP source into umgen_amd/libumgen_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "frame.h")] + \
+        [os.path.join(os.path.dirname(HERE), "include", "umgen.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads the in-tree library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(umgen_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
+    lib.umgen_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.umgen_load_tensor.argtypes = [vp, C.c_char_p, vp, i32, i64p, i32]
+    lib.umgen_finalize_weights.argtypes = [vp]
+    lib.umgen_rollout.argtypes = [vp, i32, i32, i32, i32, i64p, i64p, i64p, i64p, i32, i64p, i64p, i32,
+                                  C.POINTER(Sampling), i64p, i64p, i64p, i64p]
+    lib.umgen_frame.argtypes = [vp, i32, i64p, i64p, i64p, i64p, i64p, i64p, i32, C.POINTER(Sampling), i32,
+                                C.POINTER(Trace), i64p, i64p, i64p, i64p]
+    lib.umgen_set_profiling.argtypes = [vp, i32]
+    lib.umgen_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    lib.umgen_last_error.argtypes = [vp]
+    lib.umgen_last_error.restype = C.c_char_p
+    lib.umgen_version.restype = C.c_char_p
+    lib.umgen_destroy.argtypes = [vp]
+    fp = C.POINTER(C.c_float)
+    lib.umgen_dbg_linear.argtypes = [i32, vp, vp, fp, i32, i32, i32, i32, i32, vp]
+    lib.umgen_dbg_attn_spatial.argtypes = [i32, vp, vp, i32, i32, i32, vp]
+    lib.umgen_dbg_attn_temporal.argtypes = [i32, vp, i32, i32, i32, i32, vp]
+    lib.umgen_dbg_attn_decode.argtypes = [i32, fp, vp, i32, i32, i32, fp]
+    lib.umgen_dbg_gemv.argtypes = [i32, fp, fp, vp, fp, i32, i32, i32, i32, fp]
+    for name in EXPORTS:
+        if name not in ("umgen_last_error", "umgen_version"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib

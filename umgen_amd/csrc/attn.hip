@@ -1,0 +1,359 @@
+// Attention kernels (replace flash_attn_func at module.py:218-225 / 497-504; semantics: exact softmax attention,
+// scale 1/sqrt(48) applied to q.k in fp32, bottom-right aligned causal mask where causal).  head_dim is 48 everywhere.
+#include "kernels.h"
+
+namespace umgen {
+
+constexpr float kScale = 0.14433756729740643f;          // float32(1/sqrt(48)), module.py:196-198
+constexpr float kLog2e = 1.4426950408889634f;
+
+// ---------------------------------------------------------------------------------------------------------
+// spatial (non-causal, S x S per frame and head) -- bf16 MFMA, "swapped" products so softmax rows are lane-local:
+//   S^T[key][query] = K[key][d] . Q^T[d][query]      (v_mfma_f32_16x16x32_bf16 for d 0..31 + 16x16x16 for d 32..47)
+//   O^T[d][query]  += Vt[d][key] . P^T[key][query]   (16x16x32; the k-slot -> key map is chosen so that each lane's own
+//                                                     P registers are exactly its B-operand elements: no cross-lane traffic)
+// Q, K are row-major [token][2E]; V is stored transposed per (frame, head) by the QKV GEMM epilogue (GEMM_VT).
+// One wave owns QT*16 queries; a workgroup = 4 waves.  K / Vt fragments are read straight from L2 (a (frame, head)
+// K+V set is 2 x 212 KB and is shared by every workgroup of that frame/head).
+// ---------------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                                                bf16_t* __restrict__ y, int S, int S_pad, int H) {
+    const int E = H * kHeadDim;
+    const int f = blockIdx.z, h = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int q0 = (blockIdx.x * 4 + wave) * (QT * 16);
+    if (q0 >= S) return;
+    const long ld = 2L * E;
+    const bf16_t* qbase = qk + (long)f * S * ld + h * kHeadDim;
+    const bf16_t* kbase = qbase + E;
+    const bf16_t* vbase = vt + ((long)f * H + h) * kHeadDim * S_pad;
+
+    bf16x8_t qlo[QT];
+    s16x4_t qhi[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qr = min(q0 + t * 16 + c16, S - 1);
+        qlo[t] = *reinterpret_cast<const bf16x8_t*>(qbase + qr * ld + 8 * g);
+        qhi[t] = *reinterpret_cast<const s16x4_t*>(qbase + qr * ld + 32 + 4 * g);
+    }
+    f32x4_t o[QT][3];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -INFINITY;
+        l[t] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[t][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c = kScale * kLog2e;
+    for (int k0 = 0; k0 < S; k0 += 64) {
+        f32x4_t st[QT][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int kr = min(k0 + kt * 16 + c16, S - 1);
+            const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kbase + kr * ld + 8 * g);
+            const s16x4_t khi = *reinterpret_cast<const s16x4_t*>(kbase + kr * ld + 32 + 4 * g);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(klo, qlo[t], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                st[t][kt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(khi, qhi[t], a, 0, 0, 0);
+            }
+        }
+        if (k0 + 64 > S) {   // key tail: rows past S are masked out
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + kt * 16 + 4 * g + r >= S) {
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) st[t][kt][r] = -INFINITY;
+                    }
+        }
+        bf16x8_t pb[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = st[t][0][0];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m[t], mx);
+            const float alpha = exp2f((m[t] - mn) * c);
+            m[t] = mn;
+            const float mc = mn * c;
+            float ps = 0.f;
+            float p[4][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[kt][r] = exp2f(st[t][kt][r] * c - mc);
+                    ps += p[kt][r];
+                }
+            l[t] = l[t] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[t][d][r] *= alpha;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[t][hh][j] = (__bf16)p[2 * hh + (j >> 2)][j & 3];
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const bf16_t* vr = vbase + (long)(d * 16 + c16) * S_pad + k0 + 4 * g;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                union { bf16x8_t v; uint2 u[2]; } a;
+                a.u[0] = *reinterpret_cast<const uint2*>(vr + hh * 32);        // keys k0 + 32hh + 4g .. +3
+                a.u[1] = *reinterpret_cast<const uint2*>(vr + hh * 32 + 16);   // keys k0 + 32hh + 16 + 4g .. +3
+#pragma unroll
+                for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, pb[t][hh], o[t][d], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float lt = l[t];
+        lt += __shfl_xor(lt, 16);
+        lt += __shfl_xor(lt, 32);
+        const float inv = 1.0f / lt;
+        const int qr = q0 + t * 16 + c16;
+        if (qr < S) {
+            bf16_t* yr = y + ((long)f * S + qr) * E + h * kHeadDim + 4 * g;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float v[4] = {o[t][d][0] * inv, o[t][d][1] * inv, o[t][d][2] * inv, o[t][d][3] * inv};
+                store4(yr + d * 16, v);
+            }
+        }
+    }
+}
+
+void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int S_pad, int H) {
+    constexpr int QT = 4;
+    dim3 grid((S + 4 * QT * 16 - 1) / (4 * QT * 16), H, F);
+    hipLaunchKernelGGL(attn_spatial_mfma_kernel<QT>, grid, dim3(256), 0, s, qk, vt, y, S, S_pad, H);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// spatial, generic VALU (parity mode): one thread per query, keys streamed through LDS in tiles of 32
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(128) void attn_spatial_valu_kernel(const T* __restrict__ qk, const T* __restrict__ vt, T* __restrict__ y,
+                                                                int S, int S_pad, int H) {
+    __shared__ float sk[32][kHeadDim + 1];
+    __shared__ float sv[32][kHeadDim + 1];
+    const int E = H * kHeadDim;
+    const int f = blockIdx.z, h = blockIdx.y;
+    const int qi = blockIdx.x * 128 + threadIdx.x;
+    const long ld = 2L * E;
+    const T* qbase = qk + (long)f * S * ld + h * kHeadDim;
+    const T* kbase = qbase + E;
+    const T* vbase = vt + ((long)f * H + h) * kHeadDim * S_pad;
+    float q[kHeadDim], o[kHeadDim];
+    const int qr = min(qi, S - 1);
+#pragma unroll
+    for (int d = 0; d < kHeadDim; ++d) {
+        q[d] = Cvt<T>::to_f(qbase[qr * ld + d]);
+        o[d] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * kHeadDim; e += 128) {
+            const int kk = e / kHeadDim, d = e % kHeadDim;
+            const int kr = min(k0 + kk, S - 1);
+            sk[kk][d] = Cvt<T>::to_f(kbase[kr * ld + d]);
+            const int kk2 = e % 32, d2 = e / 32;
+            sv[kk2][d2] = (k0 + kk2 < S) ? Cvt<T>::to_f(vbase[(long)d2 * S_pad + k0 + kk2]) : 0.f;
+        }
+        __syncthreads();
+        float sc[32];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < kHeadDim; ++d) a = fmaf(q[d], sk[kk][d], a);
+            a = (k0 + kk < S) ? a * kScale : -INFINITY;
+            sc[kk] = a;
+            mx = fmaxf(mx, a);
+        }
+        const float mn = fmaxf(m, mx);
+        const float alpha = expf(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int d = 0; d < kHeadDim; ++d) o[d] *= alpha;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float p = expf(sc[kk] - mn);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < kHeadDim; ++d) o[d] = fmaf(p, sv[kk][d], o[d]);
+        }
+    }
+    if (qi < S) {
+        const float inv = 1.0f / l;
+        T* yr = y + ((long)f * S + qi) * E + h * kHeadDim;
+#pragma unroll
+        for (int d = 0; d < kHeadDim; ++d) yr[d] = Cvt<T>::from_f(o[d] * inv);
+    }
+}
+
+template <typename T>
+void launch_attn_spatial_valu(hipStream_t s, const T* qk, const T* vt, T* y, int F, int S, int S_pad, int H) {
+    dim3 grid((S + 127) / 128, H, F);
+    hipLaunchKernelGGL(attn_spatial_valu_kernel<T>, grid, dim3(128), 0, s, qk, vt, y, S, S_pad, H);
+}
+template void launch_attn_spatial_valu<float>(hipStream_t, const float*, const float*, float*, int, int, int, int);
+template void launch_attn_spatial_valu<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int);
+
+// ---------------------------------------------------------------------------------------------------------
+// temporal: causal over the T (<= 32) history frames of one spatial position; one thread per (b, tq, s, h)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const T* __restrict__ qkv, T* __restrict__ y, int B, int T_, int S, int H) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * T_ * S * H;
+    if (idx >= total) return;
+    const int h = (int)(idx % H);
+    const long row = idx / H;            // (b*T + tq)*S + s
+    const int s = (int)(row % S);
+    const int tq = (int)((row / S) % T_);
+    const int b = (int)(row / ((long)S * T_));
+    const int E = H * kHeadDim;
+    const long ld = 3L * E;
+    float q[kHeadDim], o[kHeadDim];
+    const T* qp = qkv + row * ld + h * kHeadDim;
+#pragma unroll
+    for (int d = 0; d < kHeadDim; d += 4) {
+        float t4[4];
+        load4(qp + d, t4);
+        q[d] = t4[0]; q[d + 1] = t4[1]; q[d + 2] = t4[2]; q[d + 3] = t4[3];
+        o[d] = 0.f; o[d + 1] = 0.f; o[d + 2] = 0.f; o[d + 3] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+#pragma unroll 1
+    for (int tk = 0; tk <= tq; ++tk) {   // online softmax (no per-thread score array -> no scratch)
+        const T* kp = qkv + (((long)b * T_ + tk) * S + s) * ld + E + h * kHeadDim;
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < kHeadDim; d += 4) {
+            float t4[4];
+            load4(kp + d, t4);
+            a = fmaf(q[d], t4[0], a); a = fmaf(q[d + 1], t4[1], a); a = fmaf(q[d + 2], t4[2], a); a = fmaf(q[d + 3], t4[3], a);
+        }
+        a *= kScale;
+        const float mn = fmaxf(m, a);
+        const float alpha = expf(m - mn);
+        const float p = expf(a - mn);
+        m = mn;
+        l = l * alpha + p;
+        const T* vp = kp + E;
+#pragma unroll
+        for (int d = 0; d < kHeadDim; d += 4) {
+            float t4[4];
+            load4(vp + d, t4);
+            o[d] = fmaf(p, t4[0], o[d] * alpha); o[d + 1] = fmaf(p, t4[1], o[d + 1] * alpha);
+            o[d + 2] = fmaf(p, t4[2], o[d + 2] * alpha); o[d + 3] = fmaf(p, t4[3], o[d + 3] * alpha);
+        }
+    }
+    const float inv = 1.0f / l;
+    T* yp = y + row * (long)E + h * kHeadDim;
+#pragma unroll
+    for (int d = 0; d < kHeadDim; d += 4) {
+        float t4[4] = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+        store4(yp + d, t4);
+    }
+}
+
+template <typename T>
+void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int T_, int S, int H) {
+    const long total = (long)B * T_ * S * H;
+    hipLaunchKernelGGL(attn_temporal_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, y, B, T_, S, H);
+}
+template void launch_attn_temporal<float>(hipStream_t, const float*, float*, int, int, int, int);
+template void launch_attn_temporal<bf16_t>(hipStream_t, const bf16_t*, bf16_t*, int, int, int, int);
+
+// ---------------------------------------------------------------------------------------------------------
+// few-query attention, partial pass over a slice of the keys (OAR decode step; ego-decoder self/cross attention)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxChunk = 640;   // keys per split: supports L <= 8*640
+template <typename T>
+__global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ kv_base, long scene_stride,
+                                                           long key_stride, long v_off, int q_per_scene, int H,
+                                                           const int* __restrict__ d_len, int len_add, float* __restrict__ part) {
+    __shared__ float sq[kHeadDim];
+    __shared__ float sp[kMaxChunk];
+    __shared__ float red[8];
+    __shared__ float so[5][kHeadDim];
+    const int h = blockIdx.x, split = blockIdx.y, qi = blockIdx.z;
+    const int E = H * kHeadDim;
+    const int L = (d_len ? *d_len : 0) + len_add;
+    const int chunk = (L + kAttnSplit - 1) / kAttnSplit;
+    const int k0 = split * chunk, k1 = min(L, k0 + chunk);
+    float* out = part + (((long)qi * H + h) * kAttnSplit + split) * kAttnPart;
+    const int tid = threadIdx.x;
+    if (k0 >= k1) {
+        if (tid < kAttnPart) out[tid] = (tid == 0) ? -INFINITY : 0.f;
+        return;
+    }
+    if (tid < kHeadDim) sq[tid] = q[(long)qi * E + h * kHeadDim + tid];
+    __syncthreads();
+    const T* base = kv_base + (long)(qi / q_per_scene) * scene_stride + h * kHeadDim;
+    float mx = -INFINITY;
+    for (int k = k0 + tid; k < k1; k += 256) {
+        const T* kp = base + (long)k * key_stride;
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < kHeadDim; d += 4) {
+            float t4[4];
+            load4(kp + d, t4);
+            a = fmaf(sq[d], t4[0], a); a = fmaf(sq[d + 1], t4[1], a); a = fmaf(sq[d + 2], t4[2], a); a = fmaf(sq[d + 3], t4[3], a);
+        }
+        a *= kScale;
+        sp[k - k0] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float ls = 0.f;
+    for (int k = k0 + tid; k < k1; k += 256) {
+        const float p = expf(sp[k - k0] - mx);
+        sp[k - k0] = p;
+        ls += p;
+    }
+    ls = wave_sum(ls);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = ls;
+    __syncthreads();
+    const float lsum = (red[4] + red[5]) + (red[6] + red[7]);
+    const int d = tid % kHeadDim, grp = tid / kHeadDim;
+    if (grp < 5) {
+        float a = 0.f;
+        for (int k = k0 + grp; k < k1; k += 5) a = fmaf(sp[k - k0], Cvt<T>::to_f(base[(long)k * key_stride + v_off + d]), a);
+        so[grp][d] = a;
+    }
+    __syncthreads();
+    if (tid < kHeadDim) out[2 + tid] = (((so[0][tid] + so[1][tid]) + so[2][tid]) + so[3][tid]) + so[4][tid];
+    if (tid == 0) { out[0] = mx; out[1] = lsum; }
+}
+
+template <typename T>
+void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long key_stride, long v_off, int NQ,
+                         int q_per_scene, int H, const int* d_len, int len_add, float* part) {
+    hipLaunchKernelGGL(attn_partial_kernel<T>, dim3(H, kAttnSplit, NQ), dim3(256), 0, s, q, kv_base, scene_stride, key_stride, v_off,
+                       q_per_scene, H, d_len, len_add, part);
+}
+template void launch_attn_partial<float>(hipStream_t, const float*, const float*, long, long, long, int, int, int, const int*, int, float*);
+template void launch_attn_partial<bf16_t>(hipStream_t, const float*, const bf16_t*, long, long, long, int, int, int, const int*, int, float*);
+
+}  // namespace umgen

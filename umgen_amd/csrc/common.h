@@ -1,0 +1,102 @@
+// Shared device/host helpers for libumgen_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace umgen {
+
+constexpr int kHeadDim = 48;      // n_embd / n_head for UMGen_Large (768/16), the 2x-width config (1536/32) and tests
+constexpr int kSeq = 2207;        // scene positions per frame (infer_fun.py:118)
+constexpr int kWave = 64;
+
+typedef unsigned short bf16_t;    // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)v) << 16;
+    return c.f;
+}
+// round-to-nearest-even, NaN preserved (same as torch's float -> bfloat16)
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+    __host__ __device__ static inline float to_f(float v) { return v; }
+    __host__ __device__ static inline float from_f(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+    __host__ __device__ static inline float to_f(bf16_t v) { return bf16_to_f32(v); }
+    __host__ __device__ static inline bf16_t from_f(float v) { return f32_to_bf16(v); }
+};
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// exact GELU (nn.GELU default, module.py:239): 0.5 x (1 + erf(x / sqrt(2)))
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// loads 8 consecutive elements as fp32
+__device__ inline void load8(const float* p, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ inline void load8(const bf16_t* p, float (&o)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
+    o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
+    o[4] = __uint_as_float(a.z << 16); o[5] = __uint_as_float(a.z & 0xffff0000u);
+    o[6] = __uint_as_float(a.w << 16); o[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ inline void load4(const float* p, float (&o)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+}
+__device__ inline void load4(const bf16_t* p, float (&o)[4]) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
+    o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
+}
+__device__ inline void store4(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ inline void store4(bf16_t* p, const float (&v)[4]) {
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+}
+
+// ---- build-owned counter-based RNG: bit-for-bit the oracle's rng_u24 (oracle/umgen_oracle.py) ----
+__host__ __device__ inline uint32_t rng_u24(uint64_t seed, int frame, int pos, int draw) {
+    uint64_t x = seed ^ ((uint64_t)(frame + 1) * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(pos + 1) * 0xBF58476D1CE4E5B9ull) ^
+                 ((uint64_t)(draw + 1) * 0x94D049BB133111EBull);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 40);
+}
+__host__ __device__ inline float rng_uniform(uint64_t seed, int frame, int pos, int draw) {
+    return (float)rng_u24(seed, frame, pos, draw) * 5.9604644775390625e-08f;  // 2^-24
+}
+enum { DRAW_MAIN = 0, DRAW_PAD_AVOID = 1, DRAW_CONTROL = 2 };
+
+}  // namespace umgen

@@ -1,0 +1,939 @@
+// Host side of libumgen_hip.so: the C ABI of include/umgen.h and the per-frame orchestration of
+// UMGen._inference (UMGen.py:1406-1540): ego net -> pose shift -> three TAR stacks -> conditioning rows -> OAR decode loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/umgen.h"
+#include "frame.h"
+#include "kernels.h"
+
+using namespace umgen;
+
+#define HIPCHK(e, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _err = (call);                                                                    \
+        if (_err != hipSuccess) return (e)->fail(UMGEN_E_HIP, "%s -> %s", #call, hipGetErrorString(_err)); \
+    } while (0)
+
+namespace {
+
+struct AttnW { void* Wqkv; float* bqkv; void* Wo; float* bo; };
+struct MlpW { void* Wfc; void* Wproj; };
+struct SubW { float* ln_a; AttnW attn; float* ln_b; MlpW mlp; };
+struct TarW { SubW sub[3]; };
+struct DecW { float* ln1; AttnW self; float *ln2, *ln3; void* Wq; float* bq; void* Wkv; float* bkv; void* Wco; float* bco; float* ln4; MlpW mlp; };
+
+struct Slot {            // destination of one state-dict entry
+    void* dst;
+    std::vector<int64_t> shape;
+    int kind;            // 0: fp32 param, 1: T (precision dtype) weight, 2: bf16 table
+    bool loaded;
+    bool optional;
+};
+
+}  // namespace
+
+struct umgen_engine {
+    umgen_config cfg{};
+    int E = 0, H = 0;
+    size_t tsz = 4;                      // sizeof(T)
+    hipStream_t stream = nullptr;
+    std::string err = "";
+    std::map<std::string, Slot> slots;
+    std::vector<void*> allocs;
+    bool finalized = false;
+    // weights
+    std::vector<TarW> stk[4];            // STACK_EGO, STACK_MAP, STACK_BOX, STACK_TAR
+    std::vector<SubW> oar;
+    std::vector<DecW> dec;
+    float *ln_ego_tar = nullptr, *ln_ego = nullptr, *ln_tar = nullptr, *ln_oar = nullptr, *ln_map_tar = nullptr, *ln_box_tar = nullptr;
+    void *head_ego = nullptr, *head_ar_map = nullptr, *head_ar_box = nullptr, *head_tar_box = nullptr, *head_ar_img = nullptr;
+    void *map_fc = nullptr, *map_proj = nullptr, *img_fc = nullptr, *img_proj = nullptr;
+    float *map_cb = nullptr, *img_cb = nullptr;
+    EmbedTables tb{};
+    // workspace
+    float *X = nullptr, *mapfeat = nullptr, *warped_last = nullptr, *cond = nullptr, *pose_diff = nullptr, *pego = nullptr;
+    void *A = nullptr, *QKV = nullptr, *VT = nullptr, *Hb = nullptr;
+    float *xdec = nullptr, *qdec = nullptr, *part = nullptr, *hdec = nullptr, *logits = nullptr, *logits_tar = nullptr, *qkv3 = nullptr;
+    void* kvcache = nullptr;
+    long kv_layer_stride = 0, kv_scene_stride = 0;
+    int Lmax = 2208, S_pad = 2240;
+    int *d_pose = nullptr, *d_pose_shift = nullptr, *d_map = nullptr, *d_box = nullptr, *d_img = nullptr;
+    int *d_tokens = nullptr, *d_prev_box = nullptr, *d_forced = nullptr, *d_counters = nullptr, *d_nboxes = nullptr, *d_ego_tok = nullptr;
+    unsigned char* d_control = nullptr;
+    double* d_boxes = nullptr;
+    unsigned long long* d_seeds = nullptr;
+    OarState* d_state = nullptr;
+    // timing
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    umgen_timings tm{};
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev;
+    size_t gemm_ev_used = 0;
+    double gemm_flops_pending = 0;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+namespace {
+
+int dev_alloc(umgen_engine* e, void** p, size_t bytes) {
+    HIPCHK(e, hipMalloc(p, bytes ? bytes : 16));
+    e->allocs.push_back(*p);
+    return 0;
+}
+template <typename P>
+int dalloc(umgen_engine* e, P** p, size_t n) { return dev_alloc(e, reinterpret_cast<void**>(p), n * sizeof(P)); }
+
+void reg(umgen_engine* e, const std::string& key, void* dst, std::vector<int64_t> shape, int kind, bool optional = false) {
+    e->slots[key] = Slot{dst, std::move(shape), kind, false, optional};
+}
+
+int alloc_f32(umgen_engine* e, const std::string& key, float** p, std::vector<int64_t> shape) {
+    size_t n = 1;
+    for (auto d : shape) n *= (size_t)d;
+    if (int rc = dalloc(e, p, n)) return rc;
+    reg(e, key, *p, shape, 0);
+    return 0;
+}
+int alloc_w(umgen_engine* e, const std::string& key, void** p, std::vector<int64_t> shape) {
+    size_t n = 1;
+    for (auto d : shape) n *= (size_t)d;
+    if (int rc = dev_alloc(e, p, n * e->tsz)) return rc;
+    reg(e, key, *p, shape, 1);
+    return 0;
+}
+
+int alloc_attn(umgen_engine* e, const std::string& pre, AttnW& a) {
+    const int64_t E = e->E;
+    if (int rc = alloc_w(e, pre + ".c_attn.weight", &a.Wqkv, {3 * E, E})) return rc;
+    if (int rc = alloc_f32(e, pre + ".c_attn.bias", &a.bqkv, {3 * E})) return rc;
+    if (int rc = alloc_w(e, pre + ".c_proj.weight", &a.Wo, {E, E})) return rc;
+    return alloc_f32(e, pre + ".c_proj.bias", &a.bo, {E});
+}
+int alloc_mlp(umgen_engine* e, const std::string& pre, MlpW& m) {
+    const int64_t E = e->E;
+    if (int rc = alloc_w(e, pre + ".c_fc.weight", &m.Wfc, {4 * E, E})) return rc;
+    return alloc_w(e, pre + ".c_proj.weight", &m.Wproj, {E, 4 * E});
+}
+int alloc_sub(umgen_engine* e, const std::string& pre, const char* ln_a, const char* attn, const char* ln_b, const char* mlp, SubW& s) {
+    const int64_t E = e->E;
+    if (int rc = alloc_f32(e, pre + "." + ln_a + ".weight", &s.ln_a, {E})) return rc;
+    if (int rc = alloc_attn(e, pre + "." + attn, s.attn)) return rc;
+    if (int rc = alloc_f32(e, pre + "." + ln_b + ".weight", &s.ln_b, {E})) return rc;
+    return alloc_mlp(e, pre + "." + mlp, s.mlp);
+}
+
+// ---- numpy-faithful host helpers (unfused double arithmetic) ----------------------------------------------
+#pragma clang fp contract(off)
+double lin_bin(int i, double start, double stop, int n) {   // np.linspace(start, stop, n)[i]
+    if (i >= n - 1) return stop;
+    const double step = (stop - start) / (double)(n - 1);
+    volatile double t = (double)i * step;
+    return t + start;
+}
+// UMGen.decode_pose (UMGen.py:1008-1024): DigitalBinsTokenizer.decode + Normalize_Standard.unnormalize_ego
+float decode_pose_value(int tok, int axis) {
+    const float stdv[3] = {10.0f, 4.0f, 1.0f};
+    const float inv_std = 1.0f / stdv[axis];                 // np.float32 division (normalize.py:26)
+    const int right = std::min(std::max(tok, 0), 1023), left = std::min(std::max(tok - 1, 0), 1023);
+    volatile double s = lin_bin(left, -1.0, 1.0, 1024) + lin_bin(right, -1.0, 1.0, 1024);
+    volatile double v = s / 2.0;
+    volatile double u = v / (double)inv_std;
+    return (float)(u + 0.0);
+}
+// module.py:746-768 position_encoding_init -> bf16
+void sinusoid_table(int n_position, int E, int start_index, std::vector<bf16_t>& out) {
+    out.assign((size_t)n_position * E, 0);
+    for (int pos = 1; pos < n_position; ++pos)
+        for (int j = 0; j < E; ++j) {
+            const double denom = std::pow(10000.0, 2.0 * (double)(j / 2) / (double)E);
+            const double a = (double)(pos + start_index) / denom;
+            const double v = (j % 2 == 0) ? std::sin(a) : std::cos(a);
+            // double -> bf16 round-to-nearest-even (via the exactly-representable float when possible)
+            float f = (float)v;
+            // correct double rounding: if the float rounding moved across a bf16 tie, fix it up
+            bf16_t b = f32_to_bf16(f);
+            const double lo = (double)bf16_to_f32((bf16_t)(b - 1)), hi = (double)bf16_to_f32((bf16_t)(b + 1)), mid = (double)bf16_to_f32(b);
+            // choose nearest of the three candidates to v (ties to even mantissa)
+            double best = mid;
+            bf16_t bb = b;
+            const double cands[2] = {lo, hi};
+            const bf16_t cb[2] = {(bf16_t)(b - 1), (bf16_t)(b + 1)};
+            for (int c = 0; c < 2; ++c) {
+                const double d1 = std::fabs(cands[c] - v), d0 = std::fabs(best - v);
+                if (d1 < d0 || (d1 == d0 && (cb[c] & 1) == 0 && (bb & 1) == 1)) { best = cands[c]; bb = cb[c]; }
+            }
+            out[(size_t)pos * E + j] = bb;
+        }
+}
+
+template <typename T> void convert_to(const void* src, int dtype, size_t n, T* dst);
+float load_as_f32(const void* src, int dtype, size_t i) {
+    switch (dtype) {
+        case UMGEN_DT_F32: return reinterpret_cast<const float*>(src)[i];
+        case UMGEN_DT_BF16: return bf16_to_f32(reinterpret_cast<const bf16_t*>(src)[i]);
+        case UMGEN_DT_F64: return (float)reinterpret_cast<const double*>(src)[i];
+        case UMGEN_DT_F16: {
+            const uint16_t h = reinterpret_cast<const uint16_t*>(src)[i];
+            const uint32_t sign = (h >> 15) & 1, ex = (h >> 10) & 31, man = h & 1023;
+            float v;
+            if (ex == 0) v = std::ldexp((float)man, -24);
+            else if (ex == 31) v = man ? NAN : INFINITY;
+            else v = std::ldexp((float)(man | 1024), (int)ex - 25);
+            return sign ? -v : v;
+        }
+    }
+    return 0.f;
+}
+
+// ---- templated compute path ---------------------------------------------------------------------------------
+template <typename T> struct Path;
+template <> struct Path<float> {
+    static void gemm(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<float, float>(s, a); }
+    static void attn_spatial(hipStream_t s, const float* qk, const float* vt, float* y, int F, int S, int Sp, int H) {
+        launch_attn_spatial_valu<float>(s, qk, vt, y, F, S, Sp, H);
+    }
+    static void gemm_w_f32act(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<float, float>(s, a); }
+};
+template <> struct Path<bf16_t> {
+    static void gemm(hipStream_t s, const GemmArgs& a) { launch_gemm_bf16_mfma(s, a); }
+    static void attn_spatial(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int Sp, int H) {
+        launch_attn_spatial_bf16_mfma(s, qk, vt, y, F, S, Sp, H);
+    }
+    static void gemm_w_f32act(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<bf16_t, float>(s, a); }
+};
+
+template <typename T>
+void gemm_timed(umgen_engine* e, const GemmArgs& a) {
+    if (e->profiling) {
+        if (e->gemm_ev_used == e->gemm_ev.size()) {
+            hipEvent_t a0, a1;
+            hipEventCreate(&a0);
+            hipEventCreate(&a1);
+            e->gemm_ev.emplace_back(a0, a1);
+        }
+        auto& pr = e->gemm_ev[e->gemm_ev_used++];
+        hipEventRecord(pr.first, e->stream);
+        Path<T>::gemm(e->stream, a);
+        hipEventRecord(pr.second, e->stream);
+        e->gemm_flops_pending += 2.0 * (double)a.Mi * (double)a.Nj * (double)a.K * (double)a.batch;
+    } else {
+        Path<T>::gemm(e->stream, a);
+    }
+}
+
+// out[tokens R][N] (T) = A[R][K] . W[N][K]^T + bias  (optionally GELU)
+template <typename T>
+void linear_store(umgen_engine* e, const void* W, const float* bias, int N, int K, const void* A, long R, void* out, long ldo, int gelu) {
+    GemmArgs g{};
+    g.P = W; g.Q = A; g.Mi = N; g.Nj = (int)R; g.K = K; g.ldp = K; g.ldq = K; g.batch = 1;
+    g.mode = GEMM_STORE; g.bias = bias; g.gelu = gelu; g.out = out; g.ldo = ldo;
+    gemm_timed<T>(e, g);
+}
+// X[R][N] (fp32) += A[R][K] . W[N][K]^T + bias
+template <typename T>
+void linear_resid(umgen_engine* e, const void* W, const float* bias, int N, int K, const void* A, long R, float* X) {
+    GemmArgs g{};
+    g.P = W; g.Q = A; g.Mi = N; g.Nj = (int)R; g.K = K; g.ldp = K; g.ldq = K; g.batch = 1;
+    g.mode = GEMM_RESID; g.bias = bias; g.out = X; g.ldo = N;
+    gemm_timed<T>(e, g);
+}
+
+// one (LayerNorm -> attention -> residual -> LayerNorm -> MLP -> residual) sub-block of BlockTAR (module.py:332-359)
+template <typename T>
+void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal) {
+    const int E = e->E, H = e->H;
+    const long R = (long)B * Tn * S;
+    T* A = reinterpret_cast<T*>(e->A);
+    T* QKV = reinterpret_cast<T*>(e->QKV);
+    launch_layernorm<T>(e->stream, e->X, E, R, E, w.ln_a, A);
+    if (temporal) {
+        linear_store<T>(e, w.attn.Wqkv, w.attn.bqkv, 3 * E, E, A, R, QKV, 3L * E, 0);
+        launch_attn_temporal<T>(e->stream, QKV, A, B, Tn, S, H);
+    } else {
+        // q | k row-major, V transposed per (frame, head) for the attention kernel
+        linear_store<T>(e, w.attn.Wqkv, w.attn.bqkv, 2 * E, E, A, R, QKV, 2L * E, 0);
+        GemmArgs g{};
+        g.P = A; g.Q = reinterpret_cast<const char*>(w.attn.Wqkv) + (size_t)2 * E * E * sizeof(T);
+        g.Mi = S; g.Nj = E; g.K = E; g.ldp = E; g.ldq = E; g.strideP = (long)S * E; g.strideQ = 0; g.batch = B * Tn;
+        g.mode = GEMM_VT; g.bias = w.attn.bqkv + 2 * E; g.out = e->VT; g.ldo = e->S_pad; g.H = H;
+        gemm_timed<T>(e, g);
+        Path<T>::attn_spatial(e->stream, QKV, reinterpret_cast<const T*>(e->VT), A, B * Tn, S, e->S_pad, H);
+    }
+    linear_resid<T>(e, w.attn.Wo, w.attn.bo, E, E, A, R, e->X);
+    launch_layernorm<T>(e->stream, e->X, E, R, E, w.ln_b, A);
+    linear_store<T>(e, w.mlp.Wfc, nullptr, 4 * E, E, A, R, e->Hb, 4L * E, 1);
+    linear_resid<T>(e, w.mlp.Wproj, nullptr, E, 4 * E, e->Hb, R, e->X);
+}
+
+template <typename T>
+void run_stack(umgen_engine* e, int stack, const WindowTokens& w) {
+    const int S = stack_len(stack);
+    launch_embed_stack(e->stream, stack, e->tb, w, e->X, e->mapfeat);
+    if (stack != STACK_EGO) launch_warp_map(e->stream, stack, e->tb, w.B, w.T, e->mapfeat, e->pose_diff, e->X,
+                                            stack == STACK_MAP ? e->warped_last : nullptr);
+    for (const TarW& blk : e->stk[stack]) {
+        tar_sub<T>(e, blk.sub[0], w.B, w.T, S, false);
+        tar_sub<T>(e, blk.sub[1], w.B, w.T, S, true);
+        tar_sub<T>(e, blk.sub[2], w.B, w.T, S, false);
+    }
+}
+
+// GemvArgs helpers
+template <typename T>
+void gemv(umgen_engine* e, const float* x, long ldx, const float* ln_w, const void* W, const float* bias, int N, int K, int M,
+          int mode, float* out, long ldo) {
+    GemvArgs a{};
+    a.x = x; a.ldx = ldx; a.ln_w = ln_w; a.W = W; a.bias = bias; a.N = N; a.K = K; a.M = M; a.out_mode = mode; a.out = out; a.ldo = ldo;
+    a.E = e->E;
+    launch_gemv<T>(e->stream, a);
+}
+template <typename T>
+void gemv_resid(umgen_engine* e, const float* a_in, long lda, const float* part, const void* W, const float* bias, int N, int K, int M,
+                float* x, long ldx) {
+    GemvResidArgs a{};
+    a.a = a_in; a.lda = lda; a.part = part; a.H = e->H; a.W = W; a.bias = bias; a.N = N; a.K = K; a.M = M; a.x = x; a.ldx = ldx;
+    launch_gemv_resid<T>(e->stream, a);
+}
+
+// infer_ego_net / forward_ego_net (UMGen.py:994-1005, 634-687).  The Decoder is frame-local and only t = -1 is consumed
+// (UMGen.py:1002), so the 12 decoder blocks run on the last frame only -- identical outputs, 1/T of the work.
+template <typename T>
+void run_ego(umgen_engine* e, const WindowTokens& w, const SamplerParams& sp, int frame_idx, bool forced, float* trace_logits) {
+    const int E = e->E, H = e->H, B = w.B, Tn = w.T;
+    run_stack<T>(e, STACK_EGO, w);
+    // p = ln_ego_tar(x) of the last frame, kept in fp32 (every decoder block re-normalises it with its own ln_3)
+    for (int b = 0; b < B; ++b)
+        launch_layernorm<float>(e->stream, e->X + (((long)b * Tn + (Tn - 1)) * kSeq) * E, E, kSeq, E, e->ln_ego_tar,
+                                e->pego + (long)b * kSeq * E);
+    float* x = e->xdec;   // [3B][E] ego queries
+    launch_ego_queries(e->stream, e->tb, B, Tn, x);
+    const int M = 3 * B;
+    T* PN = reinterpret_cast<T*>(e->A);         // ln_3(p)           [B*2207][E]
+    T* KV = reinterpret_cast<T*>(e->QKV);       // k | v of ln_3(p)  [B*2207][2E]
+    for (const DecW& d : e->dec) {               // Decoder.forward_func (module.py:662-683)
+        gemv<T>(e, x, E, d.ln1, d.self.Wqkv, d.self.bqkv, 3 * E, E, M, GEMV_OUT_F32, e->qkv3, 3L * E);
+        // self-attention among the 3 ego queries of a scene (non-causal); q rows gathered out of the packed q|k|v rows
+        hipMemcpy2DAsync(e->qdec, (size_t)E * 4, e->qkv3, (size_t)3 * E * 4, (size_t)E * 4, M, hipMemcpyDeviceToDevice, e->stream);
+        launch_attn_partial<float>(e->stream, e->qdec, e->qkv3 + E, 3L * 3 * E, 3L * E, E, M, 3, H, nullptr, 3, e->part);
+        gemv_resid<T>(e, nullptr, 0, e->part, d.self.Wo, d.self.bo, E, E, M, x, E);
+        // cross attention to the frame's 2207 scene tokens (FlashCrossAttention.forward, module.py:482-509)
+        gemv<T>(e, x, E, d.ln2, d.Wq, d.bq, E, E, M, GEMV_OUT_F32, e->qdec, E);
+        launch_layernorm<T>(e->stream, e->pego, E, (long)B * kSeq, E, d.ln3, PN);
+        linear_store<T>(e, d.Wkv, d.bkv, 2 * E, E, PN, (long)B * kSeq, KV, 2L * E, 0);
+        launch_attn_partial<T>(e->stream, e->qdec, KV, (long)kSeq * 2 * E, 2L * E, E, M, 3, H, nullptr, kSeq, e->part);
+        gemv_resid<T>(e, nullptr, 0, e->part, d.Wco, d.bco, E, E, M, x, E);
+        gemv<T>(e, x, E, d.ln4, d.mlp.Wfc, nullptr, 4 * E, E, M, GEMV_OUT_GELU, e->hdec, 4L * E);
+        gemv_resid<T>(e, e->hdec, 4L * E, nullptr, d.mlp.Wproj, nullptr, E, 4 * E, M, x, E);
+    }
+    gemv<T>(e, x, E, e->ln_ego, e->head_ego, nullptr, e->cfg.pose_vocab, E, M, GEMV_OUT_F32, e->logits, e->cfg.pose_vocab);
+    if (trace_logits) hipMemcpyAsync(trace_logits, e->logits, (size_t)3 * e->cfg.pose_vocab * 4, hipMemcpyDeviceToHost, e->stream);
+    launch_sample_ego(e->stream, e->logits, e->cfg.pose_vocab, sp, e->d_seeds, frame_idx, forced ? e->d_forced : nullptr, e->d_ego_tok, B);
+}
+
+// one OAR decode step through the 36 BlockOAR layers (module.py:402-416) for the B scenes
+template <typename T>
+void oar_layers(umgen_engine* e, int B) {
+    const int E = e->E, H = e->H;
+    const int* d_len = &e->d_state->step;
+    for (size_t li = 0; li < e->oar.size(); ++li) {
+        const SubW& w = e->oar[li];
+        T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
+        GemvArgs a{};
+        a.x = e->xdec; a.ldx = E; a.ln_w = w.ln_a; a.W = w.attn.Wqkv; a.bias = w.attn.bqkv; a.N = 3 * E; a.K = E; a.M = B;
+        a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len; a.E = E;
+        launch_gemv<T>(e->stream, a);
+        launch_attn_partial<T>(e->stream, e->qdec, cache, e->kv_scene_stride, 2L * E, E, B, 1, H, d_len, 1, e->part);
+        gemv_resid<T>(e, nullptr, 0, e->part, w.attn.Wo, w.attn.bo, E, E, B, e->xdec, E);
+        gemv<T>(e, e->xdec, E, w.ln_b, w.mlp.Wfc, nullptr, 4 * E, E, B, GEMV_OUT_GELU, e->hdec, 4L * E);
+        gemv_resid<T>(e, e->hdec, 4L * E, nullptr, w.mlp.Wproj, nullptr, E, 4 * E, B, e->xdec, E);
+    }
+    e->tm.oar_kernels += 5 * (int64_t)e->oar.size();
+}
+
+struct FrameIO {
+    int B, T;
+    const int *pose, *map, *box, *img;          // host window tokens [B][T][S_mod] (box already control-overwritten)
+    const int* ctrl_pose;                        // host [B][3] or nullptr: pose given (init_tokens["pose"])
+    const unsigned char* control_slot;           // host [B][60] or nullptr
+    int frame_idx;
+    const umgen_sampling* smp;
+    const umgen_trace* trace;                    // B == 1 only
+    int* out_tokens;                             // host [B][2199]
+};
+
+// UMGen._inference (UMGen.py:1406-1540) for B scenes
+template <typename T>
+int run_frame(umgen_engine* e, const FrameIO& io) {
+    const int E = e->E, B = io.B, Tn = io.T;
+    hipStream_t st = e->stream;
+    SamplerParams sp{io.smp->method, io.smp->top_k, io.smp->top_k_map, io.smp->topk_image, io.smp->p, io.smp->p_map, io.smp->temperature,
+                     io.smp->rule_constrain, io.smp->merge_ar_tar, io.smp->only_ar};
+    const umgen_trace* tr = io.trace;
+    const bool forced = tr && tr->forced_map;
+    HIPCHK(e, hipMemcpyAsync(e->d_pose, io.pose, (size_t)B * Tn * 3 * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(e->d_map, io.map, (size_t)B * Tn * kNMap * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(e->d_box, io.box, (size_t)B * Tn * kNBox * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(e->d_img, io.img, (size_t)B * Tn * kNImg * 4, hipMemcpyHostToDevice, st));
+    std::vector<unsigned long long> seeds(B);
+    for (int b = 0; b < B; ++b) seeds[b] = io.smp->seeds ? io.smp->seeds[b] : 0ull;
+    HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
+    std::vector<int> forced_host;
+    if (forced) {
+        forced_host.resize(kTokPerFrame);
+        for (int i = 0; i < kNPose; ++i) forced_host[i] = (int)tr->forced_pose[i];
+        for (int i = 0; i < kNMap; ++i) forced_host[kOffMap + i] = (int)tr->forced_map[i];
+        for (int i = 0; i < kNBox; ++i) forced_host[kOffBox + i] = (int)tr->forced_bbox3d[i];
+        for (int i = 0; i < kNImg; ++i) forced_host[kOffImg + i] = (int)tr->forced_image[i];
+        HIPCHK(e, hipMemcpyAsync(e->d_forced, forced_host.data(), (size_t)kTokPerFrame * 4, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int), st));
+    HIPCHK(e, hipMemsetAsync(e->d_nboxes, 0, (size_t)B * sizeof(int), st));
+
+    WindowTokens w{e->d_pose, e->d_map, e->d_box, e->d_img, B, Tn};
+    // Step 1: ego pose tokens (UMGen.py:1440-1455)
+    std::vector<int> ego(B * 3);
+    HIPCHK(e, hipEventRecord(e->ev[0], st));
+    if (io.ctrl_pose) {
+        for (int i = 0; i < B * 3; ++i) ego[i] = io.ctrl_pose[i];
+    } else {
+        run_ego<T>(e, w, sp, io.frame_idx, forced, tr ? tr->ego_logits : nullptr);
+        HIPCHK(e, hipMemcpyAsync(ego.data(), e->d_ego_tok, (size_t)B * 3 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipStreamSynchronize(st));
+    }
+    HIPCHK(e, hipEventRecord(e->ev[1], st));
+    // pose shifted one frame ahead (UMGen.py:1445-1452) and its decoded (dx, dy, dtheta) for the map warp
+    std::vector<int> pshift((size_t)B * Tn * 3);
+    std::vector<float> pdiff((size_t)B * Tn * 3);
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < Tn; ++t)
+            for (int a = 0; a < 3; ++a) {
+                const int v = (t + 1 < Tn) ? io.pose[((size_t)b * Tn + t + 1) * 3 + a] : ego[b * 3 + a];
+                pshift[((size_t)b * Tn + t) * 3 + a] = v;
+                pdiff[((size_t)b * Tn + t) * 3 + a] = decode_pose_value(v, a);
+            }
+    HIPCHK(e, hipMemcpyAsync(e->d_pose_shift, pshift.data(), pshift.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(e->pose_diff, pdiff.data(), pdiff.size() * 4, hipMemcpyHostToDevice, st));
+    // new-frame token buffer: pose = ego tokens; previous frame's bbox3d tokens; control mask
+    std::vector<int> tok0((size_t)B * kTokPerFrame, 0);
+    std::vector<int> prevbox((size_t)B * kNBox);
+    for (int b = 0; b < B; ++b) {
+        for (int a = 0; a < 3; ++a) tok0[(size_t)b * kTokPerFrame + a] = ego[b * 3 + a];
+        memcpy(&prevbox[(size_t)b * kNBox], io.box + ((size_t)b * Tn + (Tn - 1)) * kNBox, kNBox * sizeof(int));
+    }
+    HIPCHK(e, hipMemcpyAsync(e->d_tokens, tok0.data(), tok0.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(e->d_prev_box, prevbox.data(), prevbox.size() * 4, hipMemcpyHostToDevice, st));
+    if (io.control_slot) HIPCHK(e, hipMemcpyAsync(e->d_control, io.control_slot, (size_t)B * kSlots, hipMemcpyHostToDevice, st));
+    OarState s0{0, io.frame_idx};
+    HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+
+    // Step 2: the three TAR stacks (UMGen.py:1484-1494) and the conditioning rows (1496-1511)
+    WindowTokens ws{e->d_pose_shift, e->d_map, e->d_box, e->d_img, B, Tn};
+    run_stack<T>(e, STACK_MAP, ws);
+    launch_cond_rows(st, STACK_MAP, B, Tn, E, e->X, e->ln_map_tar, e->warped_last, e->cond);
+    run_stack<T>(e, STACK_BOX, ws);
+    launch_cond_rows(st, STACK_BOX, B, Tn, E, e->X, e->ln_box_tar, nullptr, e->cond);
+    run_stack<T>(e, STACK_TAR, ws);
+    launch_cond_rows(st, STACK_TAR, B, Tn, E, e->X, e->ln_tar, nullptr, e->cond);
+    if (tr && tr->cond) HIPCHK(e, hipMemcpyAsync(tr->cond, e->cond, (size_t)kSeq * E * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipEventRecord(e->ev[2], st));
+
+    // Step 3: OAR decode loop (infer_oar_net, UMGen.py:1151-1273).  Step j consumes scene position j (KV length j) and
+    // emits scene token j; j = 0..4 replays the given pose prefix, bos/eos are fixed, everything else is sampled.
+    launch_first_input(st, B, E, e->tb.tske + (long)e->cfg.task_id * E, e->cond, e->xdec);
+    SampleArgs sa{};
+    sa.st = e->d_state; sa.sp = sp; sa.tb = e->tb; sa.logits = e->logits; sa.logits_tar = e->logits_tar; sa.ld_logits = 8192;
+    sa.cond = e->cond; sa.x_next = e->xdec; sa.tokens = e->d_tokens; sa.prev_box = e->d_prev_box;
+    sa.control_slot = io.control_slot ? e->d_control : nullptr; sa.boxes = e->d_boxes; sa.n_boxes = e->d_nboxes; sa.seeds = e->d_seeds;
+    sa.forced = forced ? e->d_forced : nullptr; sa.counters = e->d_counters;
+    for (int j = 0; j < kImgEos; ++j) {   // the img-eos step (j = 2206) produces nothing that is consumed
+        oar_layers<T>(e, B);
+        int mod = 0;
+        if (j >= kMapC0 && j < kMapEos) mod = 1;
+        else if (j >= kBoxC0 && j < kBoxEos) mod = 2;
+        else if (j >= kImgC0 && j < kImgEos) mod = 3;
+        if (mod == 0) {
+            launch_fixed_token(st, sa, B);
+        } else {
+            const void* head = mod == 1 ? e->head_ar_map : (mod == 2 ? e->head_ar_box : e->head_ar_img);
+            const int V = mod == 1 ? e->cfg.map_vocab : (mod == 2 ? e->cfg.bbox3d_vocab : e->cfg.img_vocab);
+            gemv<T>(e, e->xdec, E, e->ln_oar, head, nullptr, V, E, B, GEMV_OUT_F32, e->logits, sa.ld_logits);
+            if (mod == 2) {   // head_tar_bbox3d on the conditioning row of this position (UMGen.py:1087,1103)
+                GemvArgs a{};
+                a.x = e->cond; a.ldx = (long)kSeq * E; a.d_xoff = &e->d_state->step; a.xoff_mul = E; a.W = e->head_tar_box;
+                a.N = V; a.K = E; a.M = B; a.out_mode = GEMV_OUT_F32; a.out = e->logits_tar; a.ldo = sa.ld_logits; a.E = E;
+                launch_gemv<T>(st, a);
+            }
+            if (tr) {
+                float* dst = mod == 1 ? tr->logits_map : (mod == 2 ? tr->logits_bbox3d : tr->logits_image);
+                const int k = mod == 1 ? j - kMapC0 : (mod == 2 ? j - kBoxC0 : j - kImgC0);
+                if (dst) HIPCHK(e, hipMemcpyAsync(dst + (size_t)k * V, e->logits, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+            }
+            sa.mod = mod;
+            sa.vocab = V;
+            launch_sample_token(st, sa, B);
+            e->tm.oar_kernels += (mod == 2) ? 3 : 2;
+        }
+        launch_advance(st, e->d_state);
+        e->tm.oar_kernels += 1;
+    }
+    e->tm.oar_steps += kImgEos;
+    HIPCHK(e, hipEventRecord(e->ev[3], st));
+    HIPCHK(e, hipMemcpyAsync(io.out_tokens, e->d_tokens, (size_t)B * kTokPerFrame * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    float ms;
+    hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->tm.ego_ms += ms;
+    hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->tm.tar_ms += ms;
+    hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->tm.oar_ms += ms;
+    hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->tm.total_ms += ms;
+    e->tm.frames += 1;
+    if (e->profiling) {
+        for (size_t i = 0; i < e->gemm_ev_used; ++i) {
+            hipEventElapsedTime(&ms, e->gemm_ev[i].first, e->gemm_ev[i].second);
+            e->tm.gemm_ms += ms;
+        }
+        e->tm.gemm_launches += (int64_t)e->gemm_ev_used;
+        e->tm.gemm_flops += e->gemm_flops_pending;
+        e->gemm_ev_used = 0;
+        e->gemm_flops_pending = 0;
+    }
+    // algorithmic HBM bytes of this frame's decode steps: weights once per step + KV read + KV write
+    {
+        const double w_layer = (double)e->tsz * (12.0 * E * E) + 4.0 * (6.0 * E);   // 3E*E + E*E + 4E*E + 4E*E weights, biases/LN
+        const double w_oar = w_layer * (double)e->oar.size();
+        double bytes = 0;
+        for (int j = 0; j < kImgEos; ++j) {
+            bytes += w_oar + (double)B * (double)e->oar.size() * (double)e->tsz * 2.0 * E * (double)(j + 1);
+            const int V = (j >= kMapC0 && j < kMapEos) ? e->cfg.map_vocab : (j >= kBoxC0 && j < kBoxEos) ? 2 * e->cfg.bbox3d_vocab
+                        : (j >= kImgC0 && j < kImgEos) ? e->cfg.img_vocab : 0;
+            bytes += (double)V * E * (double)e->tsz;
+        }
+        e->tm.oar_bytes += bytes;
+    }
+    return 0;
+}
+
+int run_frame_any(umgen_engine* e, const FrameIO& io) {
+    return e->cfg.precision == UMGEN_PREC_BF16 ? run_frame<bf16_t>(e, io) : run_frame<float>(e, io);
+}
+
+template <typename T>
+int build_tables(umgen_engine* e) {
+    // GMLP(codebook) rows (module.py:710-743 applied once to each of the 8192 codes): fp32 activations, exact FMA chain
+    const int E = e->E;
+    for (int which = 0; which < 2; ++which) {
+        const int V = which ? e->cfg.img_vocab : e->cfg.map_vocab;
+        const int C = which ? e->cfg.n_img_embd : e->cfg.n_map_embd;
+        float* table;
+        if (int rc = dalloc(e, &table, (size_t)V * E)) return rc;
+        float* hid;
+        HIPCHK(e, hipMalloc(&hid, (size_t)V * 4 * E * 4));
+        GemmArgs g{};
+        g.P = which ? e->img_fc : e->map_fc; g.Q = which ? e->img_cb : e->map_cb; g.Mi = 4 * E; g.Nj = V; g.K = C; g.ldp = C; g.ldq = C;
+        g.batch = 1; g.mode = GEMM_STORE; g.gelu = 1; g.out = hid; g.ldo = 4L * E;
+        Path<T>::gemm_w_f32act(e->stream, g);
+        GemmArgs g2{};
+        g2.P = which ? e->img_proj : e->map_proj; g2.Q = hid; g2.Mi = E; g2.Nj = V; g2.K = 4 * E; g2.ldp = 4 * E; g2.ldq = 4 * E;
+        g2.batch = 1; g2.mode = GEMM_STORE; g2.out = table; g2.ldo = E;
+        Path<T>::gemm_w_f32act(e->stream, g2);
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, hipFree(hid));
+        if (which) e->tb.gimg = table; else e->tb.gmap = table;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================================================
+// C ABI
+// =============================================================================================================
+extern "C" {
+
+const char* umgen_version(void) { return "umgen_hip 0.1 (gfx950)"; }
+const char* umgen_last_error(const umgen_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int umgen_create(const umgen_config* cfg, umgen_engine** out) {
+    if (!cfg || !out) return UMGEN_E_INVALID;
+    *out = nullptr;
+    umgen_engine* e = new umgen_engine();
+    *out = e;   // returned even on failure so the caller can read umgen_last_error()
+    e->cfg = *cfg;
+    if (cfg->abi_version != UMGEN_ABI_VERSION) return e->fail(UMGEN_E_INVALID, "abi_version %d != %d", cfg->abi_version, UMGEN_ABI_VERSION);
+    if (cfg->n_head <= 0 || cfg->n_embd != cfg->n_head * kHeadDim)
+        return e->fail(UMGEN_E_UNSUPPORTED, "head_dim must be %d (n_embd=%d, n_head=%d)", kHeadDim, cfg->n_embd, cfg->n_head);
+    if (cfg->n_embd > 1536) return e->fail(UMGEN_E_UNSUPPORTED, "n_embd <= 1536 supported");
+    if (cfg->map_vocab > 8192 || cfg->img_vocab > 8192 || cfg->bbox3d_vocab != 1028 || cfg->pose_vocab > 8192)
+        return e->fail(UMGEN_E_UNSUPPORTED, "vocab sizes out of range");
+    if (cfg->max_batch < 1 || cfg->max_cond_frames < 1 || cfg->max_cond_frames > cfg->max_frame_len)
+        return e->fail(UMGEN_E_INVALID, "max_batch / max_cond_frames invalid");
+    if (cfg->precision != UMGEN_PREC_FP32 && cfg->precision != UMGEN_PREC_BF16) return e->fail(UMGEN_E_INVALID, "precision");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return e->fail(UMGEN_E_HIP, "no HIP device visible: libumgen_hip has no CPU fallback");
+    HIPCHK(e, hipSetDevice(cfg->device));
+    HIPCHK(e, hipStreamCreate(&e->stream));
+    for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
+    e->E = cfg->n_embd;
+    e->H = cfg->n_head;
+    e->tsz = cfg->precision == UMGEN_PREC_BF16 ? 2 : 4;
+    const int64_t E = e->E;
+    const std::string t = "transformer.";
+    // ---- parameters (names = the reference state-dict keys, UMGen.py:176-261) ----
+    float* tmp;
+    if (int rc = alloc_f32(e, t + "egoe.weight", &tmp, {3, E})) return rc; e->tb.egoe = tmp;
+    if (int rc = alloc_f32(e, t + "axe.weight", &tmp, {cfg->aux_vocab, E})) return rc; e->tb.axe = tmp;
+    if (int rc = alloc_f32(e, t + "be.weight", &tmp, {cfg->bbox3d_vocab, E})) return rc; e->tb.be = tmp;
+    if (int rc = alloc_f32(e, t + "tpe.weight", &tmp, {cfg->max_frame_len, E})) return rc; e->tb.tpe = tmp;
+    if (int rc = alloc_f32(e, t + "spe.weight", &tmp, {kSeq, E})) return rc; e->tb.spe = tmp;
+    if (int rc = alloc_f32(e, t + "tske.weight", &tmp, {cfg->task_num, E})) return rc; e->tb.tske = tmp;
+    e->tb.E = e->E;
+    const char* stack_name[4] = {"ego_tar", "map_tar", "box_tar", "TAR"};
+    const int stack_n[4] = {cfg->n_ego_tar_layer, cfg->n_map_tar_layer, cfg->n_box_tar_layer, cfg->n_tar_layer};
+    for (int s = 0; s < 4; ++s) {
+        e->stk[s].resize(stack_n[s]);
+        for (int i = 0; i < stack_n[s]; ++i) {
+            const std::string pre = t + stack_name[s] + "." + std::to_string(i);
+            TarW& b = e->stk[s][i];
+            if (int rc = alloc_sub(e, pre, "ln_1", "spatial_attn_1", "ln_2", "mlp1", b.sub[0])) return rc;
+            if (int rc = alloc_sub(e, pre, "ln_3", "temporal_attn", "ln_4", "mlp2", b.sub[1])) return rc;
+            if (int rc = alloc_sub(e, pre, "ln_5", "spatial_attn_2", "ln_6", "mlp3", b.sub[2])) return rc;
+        }
+    }
+    e->oar.resize(cfg->n_oar_layer);
+    for (int i = 0; i < cfg->n_oar_layer; ++i)
+        if (int rc = alloc_sub(e, t + "OAR." + std::to_string(i), "ln_1", "temporal_attn", "ln_2", "mlp", e->oar[i])) return rc;
+    e->dec.resize(cfg->n_ego_ca_layer);
+    for (int i = 0; i < cfg->n_ego_ca_layer; ++i) {
+        const std::string pre = t + "ego_cross_attn." + std::to_string(i);
+        DecW& d = e->dec[i];
+        if (int rc = alloc_f32(e, pre + ".ln_1.weight", &d.ln1, {E})) return rc;
+        if (int rc = alloc_attn(e, pre + ".self_attn", d.self)) return rc;
+        if (int rc = alloc_f32(e, pre + ".ln_2.weight", &d.ln2, {E})) return rc;
+        if (int rc = alloc_f32(e, pre + ".ln_3.weight", &d.ln3, {E})) return rc;
+        if (int rc = alloc_w(e, pre + ".cross_attn.q_attn.weight", &d.Wq, {E, E})) return rc;
+        if (int rc = alloc_f32(e, pre + ".cross_attn.q_attn.bias", &d.bq, {E})) return rc;
+        // k_attn | v_attn packed into one [2E][E] projection
+        if (int rc = dev_alloc(e, &d.Wkv, (size_t)2 * E * E * e->tsz)) return rc;
+        if (int rc = dalloc(e, &d.bkv, (size_t)2 * E)) return rc;
+        reg(e, pre + ".cross_attn.k_attn.weight", d.Wkv, {E, E}, 1);
+        reg(e, pre + ".cross_attn.v_attn.weight", reinterpret_cast<char*>(d.Wkv) + (size_t)E * E * e->tsz, {E, E}, 1);
+        reg(e, pre + ".cross_attn.k_attn.bias", d.bkv, {E}, 0);
+        reg(e, pre + ".cross_attn.v_attn.bias", d.bkv + E, {E}, 0);
+        if (int rc = alloc_w(e, pre + ".cross_attn.c_proj.weight", &d.Wco, {E, E})) return rc;
+        if (int rc = alloc_f32(e, pre + ".cross_attn.c_proj.bias", &d.bco, {E})) return rc;
+        if (int rc = alloc_f32(e, pre + ".ln_4.weight", &d.ln4, {E})) return rc;
+        if (int rc = alloc_mlp(e, pre + ".mlp1", d.mlp)) return rc;
+    }
+    if (int rc = alloc_f32(e, t + "ln_ego_tar.weight", &e->ln_ego_tar, {E})) return rc;
+    if (int rc = alloc_f32(e, t + "ln_ego.weight", &e->ln_ego, {E})) return rc;
+    if (int rc = alloc_f32(e, t + "ln_tar.weight", &e->ln_tar, {E})) return rc;
+    if (int rc = alloc_f32(e, t + "ln_oar.weight", &e->ln_oar, {E})) return rc;
+    if (int rc = alloc_f32(e, t + "ln_map_tar.weight", &e->ln_map_tar, {E})) return rc;
+    if (int rc = alloc_f32(e, t + "ln_box_tar.weight", &e->ln_box_tar, {E})) return rc;
+    if (int rc = alloc_w(e, t + "head_ego.weight", &e->head_ego, {cfg->pose_vocab, E})) return rc;
+    if (int rc = alloc_w(e, t + "head_ar_map.weight", &e->head_ar_map, {cfg->map_vocab, E})) return rc;
+    if (int rc = alloc_w(e, t + "head_ar_bbox3d.weight", &e->head_ar_box, {cfg->bbox3d_vocab, E})) return rc;
+    if (int rc = alloc_w(e, t + "head_tar_bbox3d.weight", &e->head_tar_box, {cfg->bbox3d_vocab, E})) return rc;
+    if (int rc = alloc_w(e, t + "head_ar_img.weight", &e->head_ar_img, {cfg->img_vocab, E})) return rc;
+    if (int rc = alloc_w(e, "map_mlp_pre.c_fc.weight", &e->map_fc, {4 * E, cfg->n_map_embd})) return rc;
+    if (int rc = alloc_w(e, "map_mlp_pre.c_proj.weight", &e->map_proj, {E, 4 * E})) return rc;
+    if (int rc = alloc_w(e, "img_mlp_pre.c_fc.weight", &e->img_fc, {4 * E, cfg->n_img_embd})) return rc;
+    if (int rc = alloc_w(e, "img_mlp_pre.c_proj.weight", &e->img_proj, {E, 4 * E})) return rc;
+    if (int rc = alloc_f32(e, "map_codebook.weight", &e->map_cb, {cfg->map_vocab, cfg->n_map_embd})) return rc;
+    if (int rc = alloc_f32(e, "img_codebook.weight", &e->img_cb, {cfg->img_vocab, cfg->n_img_embd})) return rc;
+    // bf16 constant tables: computed at finalize unless a checkpoint provides them (UMGen.py:257-261)
+    bf16_t *fp, *po, *gp;
+    if (int rc = dalloc(e, &fp, (size_t)1024 * E)) return rc;
+    if (int rc = dalloc(e, &po, (size_t)1030 * E)) return rc;
+    if (int rc = dalloc(e, &gp, (size_t)1024 * E)) return rc;
+    e->tb.fouier_pe = fp; e->tb.posi = po; e->tb.grid_posi = gp;
+    reg(e, "fouier_pe", fp, {1024, E}, 2, true);
+    reg(e, "bbox3d_spatial_posi", po, {1030, E}, 2, true);
+    reg(e, "grid_center_posi_embedding", gp, {1024, E}, 2, true);
+
+    // ---- workspace ----
+    const size_t Bm = cfg->max_batch, Tm = cfg->max_cond_frames;
+    const size_t R = Bm * Tm * kSeq;
+    e->S_pad = ((kSeq + 63) / 64) * 64;
+    if (int rc = dalloc(e, &e->X, R * E)) return rc;
+    if (int rc = dev_alloc(e, &e->A, R * E * e->tsz)) return rc;
+    if (int rc = dev_alloc(e, &e->QKV, R * 3 * E * e->tsz)) return rc;
+    if (int rc = dev_alloc(e, &e->VT, Bm * Tm * E * e->S_pad * e->tsz)) return rc;
+    HIPCHK(e, hipMemset(e->VT, 0, Bm * Tm * E * e->S_pad * e->tsz));   // pad columns stay zero forever
+    if (int rc = dev_alloc(e, &e->Hb, R * 4 * E * e->tsz)) return rc;
+    if (int rc = dalloc(e, &e->mapfeat, Bm * Tm * kNMap * E)) return rc;
+    if (int rc = dalloc(e, &e->warped_last, Bm * kNMap * E)) return rc;
+    if (int rc = dalloc(e, &e->cond, Bm * kSeq * E)) return rc;
+    if (int rc = dalloc(e, &e->pego, Bm * kSeq * E)) return rc;
+    if (int rc = dalloc(e, &e->pose_diff, Bm * Tm * 3)) return rc;
+    if (int rc = dalloc(e, &e->xdec, 3 * Bm * E)) return rc;
+    if (int rc = dalloc(e, &e->qdec, 3 * Bm * E)) return rc;
+    if (int rc = dalloc(e, &e->qkv3, 3 * Bm * 3 * E)) return rc;
+    if (int rc = dalloc(e, &e->part, 3 * Bm * e->H * kAttnSplit * kAttnPart)) return rc;
+    if (int rc = dalloc(e, &e->hdec, 3 * Bm * 4 * E)) return rc;
+    if (int rc = dalloc(e, &e->logits, 3 * Bm * 8192)) return rc;
+    if (int rc = dalloc(e, &e->logits_tar, Bm * 8192)) return rc;
+    e->kv_scene_stride = (long)e->Lmax * 2 * E;
+    e->kv_layer_stride = (long)Bm * e->kv_scene_stride;
+    if (int rc = dev_alloc(e, &e->kvcache, (size_t)cfg->n_oar_layer * e->kv_layer_stride * e->tsz)) return rc;
+    if (int rc = dalloc(e, &e->d_pose, Bm * Tm * 3)) return rc;
+    if (int rc = dalloc(e, &e->d_pose_shift, Bm * Tm * 3)) return rc;
+    if (int rc = dalloc(e, &e->d_map, Bm * Tm * kNMap)) return rc;
+    if (int rc = dalloc(e, &e->d_box, Bm * Tm * kNBox)) return rc;
+    if (int rc = dalloc(e, &e->d_img, Bm * Tm * kNImg)) return rc;
+    if (int rc = dalloc(e, &e->d_tokens, Bm * kTokPerFrame)) return rc;
+    if (int rc = dalloc(e, &e->d_prev_box, Bm * kNBox)) return rc;
+    if (int rc = dalloc(e, &e->d_forced, Bm * kTokPerFrame)) return rc;
+    if (int rc = dalloc(e, &e->d_counters, (size_t)8)) return rc;
+    if (int rc = dalloc(e, &e->d_nboxes, Bm)) return rc;
+    if (int rc = dalloc(e, &e->d_ego_tok, Bm * 3)) return rc;
+    if (int rc = dalloc(e, &e->d_control, Bm * kSlots)) return rc;
+    if (int rc = dalloc(e, &e->d_boxes, Bm * 64 * 10)) return rc;
+    if (int rc = dalloc(e, &e->d_seeds, Bm)) return rc;
+    if (int rc = dalloc(e, &e->d_state, (size_t)1)) return rc;
+    return UMGEN_OK;
+}
+
+int umgen_load_tensor(umgen_engine* e, const char* key, const void* data, int32_t dtype, const int64_t* shape, int32_t ndim) {
+    if (!e || !key || !data) return UMGEN_E_INVALID;
+    auto it = e->slots.find(key);
+    if (it == e->slots.end()) return 1;   // not consumed by the rollout (e.g. head_tar_pose, *.scale buffers)
+    Slot& s = it->second;
+    if ((size_t)ndim != s.shape.size()) return e->fail(UMGEN_E_INVALID, "%s: ndim %d, expected %zu", key, ndim, s.shape.size());
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] != s.shape[i]) return e->fail(UMGEN_E_INVALID, "%s: dim %d is %lld, expected %lld", key, i, (long long)shape[i], (long long)s.shape[i]);
+        n *= (size_t)shape[i];
+    }
+    if (dtype < 0 || dtype > UMGEN_DT_F64) return e->fail(UMGEN_E_INVALID, "%s: dtype %d", key, dtype);
+    const bool to_bf16 = (s.kind == 2) || (s.kind == 1 && e->cfg.precision == UMGEN_PREC_BF16);
+    if (to_bf16) {
+        std::vector<bf16_t> h(n);
+        if (dtype == UMGEN_DT_BF16) memcpy(h.data(), data, n * 2);
+        else for (size_t i = 0; i < n; ++i) h[i] = f32_to_bf16(load_as_f32(data, dtype, i));
+        HIPCHK(e, hipMemcpy(s.dst, h.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+        if (dtype == UMGEN_DT_F32) {
+            HIPCHK(e, hipMemcpy(s.dst, data, n * 4, hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> h(n);
+            for (size_t i = 0; i < n; ++i) h[i] = load_as_f32(data, dtype, i);
+            HIPCHK(e, hipMemcpy(s.dst, h.data(), n * 4, hipMemcpyHostToDevice));
+        }
+    }
+    s.loaded = true;
+    e->finalized = false;
+    return UMGEN_OK;
+}
+
+int umgen_finalize_weights(umgen_engine* e) {
+    if (!e) return UMGEN_E_INVALID;
+    std::string missing;
+    int nmiss = 0;
+    for (auto& kv : e->slots)
+        if (!kv.second.loaded && !kv.second.optional) {
+            if (nmiss < 4) missing += (nmiss ? ", " : "") + kv.first;
+            ++nmiss;
+        }
+    if (nmiss) return e->fail(UMGEN_E_STATE, "%d state-dict entries not loaded (e.g. %s)", nmiss, missing.c_str());
+    const int E = e->E;
+    std::vector<bf16_t> posi;
+    const bool have_posi = e->slots["bbox3d_spatial_posi"].loaded;
+    if (!e->slots["fouier_pe"].loaded) {
+        std::vector<bf16_t> t;
+        sinusoid_table(1024, E, 0, t);
+        HIPCHK(e, hipMemcpy(const_cast<bf16_t*>(e->tb.fouier_pe), t.data(), t.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (!have_posi) {
+        sinusoid_table(1030, E, 1024, posi);
+        HIPCHK(e, hipMemcpy(const_cast<bf16_t*>(e->tb.posi), posi.data(), posi.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        posi.resize((size_t)1030 * E);
+        HIPCHK(e, hipMemcpy(posi.data(), e->tb.posi, posi.size() * 2, hipMemcpyDeviceToHost));
+    }
+    if (!e->slots["grid_center_posi_embedding"].loaded) {
+        // UMGen.py:140-153, 357-383: token of grid centre c = 62 - 4g is np.digitize((c + 64)/128, linspace(0,1,1024))
+        std::vector<bf16_t> gp((size_t)1024 * E);
+        int tok[32];
+        for (int g = 0; g < 32; ++g) {
+            const double x = ((double)(62 - 4 * g) + 64.0) / 128.0;
+            int c = 0;
+            for (int i = 0; i < 1024; ++i) if (lin_bin(i, 0.0, 1.0, 1024) <= x) ++c;
+            tok[g] = c;
+        }
+        for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 32; ++j)
+                for (int c = 0; c < E; ++c)
+                    gp[((size_t)i * 32 + j) * E + c] = f32_to_bf16(bf16_to_f32(posi[(size_t)tok[i] * E + c]) + bf16_to_f32(posi[(size_t)tok[j] * E + c]));
+        HIPCHK(e, hipMemcpy(const_cast<bf16_t*>(e->tb.grid_posi), gp.data(), gp.size() * 2, hipMemcpyHostToDevice));
+    }
+    const int rc = e->cfg.precision == UMGEN_PREC_BF16 ? build_tables<bf16_t>(e) : build_tables<float>(e);
+    if (rc) return rc;
+    e->finalized = true;
+    return UMGEN_OK;
+}
+
+int umgen_set_profiling(umgen_engine* e, int32_t enable) {
+    if (!e) return UMGEN_E_INVALID;
+    e->profiling = enable != 0;
+    return UMGEN_OK;
+}
+int umgen_get_timings(umgen_engine* e, umgen_timings* out) {
+    if (!e || !out) return UMGEN_E_INVALID;
+    *out = e->tm;
+    return UMGEN_OK;
+}
+
+static int check_sampling(umgen_engine* e, const umgen_sampling* s) {
+    if (!s) return e->fail(UMGEN_E_INVALID, "sampling is null");
+    if (s->method != UMGEN_SAMPLE_TOPK) return e->fail(UMGEN_E_UNSUPPORTED, "only sample_method='topk' (the evaluate.py default) is implemented");
+    if (s->top_k < 1 || s->top_k > 32 || s->top_k_map < 1 || s->top_k_map > 32 || s->topk_image < 1 || s->topk_image > 32)
+        return e->fail(UMGEN_E_INVALID, "top-k values must be in [1, 32]");
+    if (!(s->temperature > 0.f)) return e->fail(UMGEN_E_INVALID, "temperature must be > 0");
+    return 0;
+}
+
+int umgen_frame(umgen_engine* e, int32_t T, const int64_t* pose, const int64_t* map, const int64_t* bbox3d, const int64_t* image,
+                const int64_t* ctrl_pose, const int64_t* ctrl_bbox3d, int32_t control_test, const umgen_sampling* sampling,
+                int32_t frame_idx, const umgen_trace* trace, int64_t* out_pose, int64_t* out_map, int64_t* out_bbox3d, int64_t* out_image) {
+    if (!e) return UMGEN_E_INVALID;
+    if (!e->finalized) return e->fail(UMGEN_E_STATE, "umgen_finalize_weights has not been called");
+    if (T < 1 || T > e->cfg.max_cond_frames) return e->fail(UMGEN_E_INVALID, "T=%d out of range [1,%d]", T, e->cfg.max_cond_frames);
+    if (int rc = check_sampling(e, sampling)) return rc;
+    std::vector<int> p((size_t)T * 3), m((size_t)T * kNMap), bx((size_t)T * kNBox), im((size_t)T * kNImg);
+    for (size_t i = 0; i < p.size(); ++i) p[i] = (int)pose[i];
+    for (size_t i = 0; i < m.size(); ++i) m[i] = (int)map[i];
+    for (size_t i = 0; i < bx.size(); ++i) bx[i] = (int)bbox3d[i];
+    for (size_t i = 0; i < im.size(); ++i) im[i] = (int)image[i];
+    std::vector<int> cp;
+    std::vector<unsigned char> cs;
+    if (ctrl_pose) { cp.resize(3); for (int i = 0; i < 3; ++i) cp[i] = (int)ctrl_pose[i]; }
+    if (ctrl_bbox3d && control_test) {   // UMGen.py:1458-1473
+        cs.assign(kSlots, 0);
+        for (int i = 0; i < kNBox; ++i)
+            if (ctrl_bbox3d[i] != -1) { bx[(size_t)(T - 1) * kNBox + i] = (int)ctrl_bbox3d[i]; cs[i / kSlotLen] = 1; }
+    }
+    std::vector<int> out(kTokPerFrame);
+    FrameIO io{1, T, p.data(), m.data(), bx.data(), im.data(), ctrl_pose ? cp.data() : nullptr, cs.empty() ? nullptr : cs.data(),
+               frame_idx, sampling, trace, out.data()};
+    if (int rc = run_frame_any(e, io)) return rc;
+    for (int i = 0; i < kNPose; ++i) out_pose[i] = out[i];
+    for (int i = 0; i < kNMap; ++i) out_map[i] = out[kOffMap + i];
+    for (int i = 0; i < kNBox; ++i) out_bbox3d[i] = out[kOffBox + i];
+    for (int i = 0; i < kNImg; ++i) out_image[i] = out[kOffImg + i];
+    return UMGEN_OK;
+}
+
+// UMGen.inference (UMGen.py:1542-1671)
+int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, int32_t cond_frames, const int64_t* pose,
+                  const int64_t* map, const int64_t* bbox3d, const int64_t* image, int32_t T_ctl, const int64_t* ctrl_pose,
+                  const int64_t* ctrl_bbox3d, int32_t control_test, const umgen_sampling* sampling, int64_t* out_pose,
+                  int64_t* out_map, int64_t* out_bbox3d, int64_t* out_image) {
+    if (!e) return UMGEN_E_INVALID;
+    if (!e->finalized) return e->fail(UMGEN_E_STATE, "umgen_finalize_weights has not been called");
+    if (B < 1 || B > e->cfg.max_batch) return e->fail(UMGEN_E_INVALID, "B=%d out of range [1,%d]", B, e->cfg.max_batch);
+    if (T_in < 1 || new_frames < 0 || cond_frames < 1 || cond_frames > e->cfg.max_cond_frames)
+        return e->fail(UMGEN_E_INVALID, "T_in=%d new_frames=%d cond_frames=%d (max %d)", T_in, new_frames, cond_frames, e->cfg.max_cond_frames);
+    if (int rc = check_sampling(e, sampling)) return rc;
+    if (!pose || !map || !bbox3d || !image || !out_pose || !out_map || !out_bbox3d || !out_image) return e->fail(UMGEN_E_INVALID, "null token buffer");
+    e->tm = umgen_timings{};
+    const int T_out = T_in + new_frames;
+    const int S[4] = {kNPose, kNMap, kNBox, kNImg};
+    const int64_t* in[4] = {pose, map, bbox3d, image};
+    int64_t* out[4] = {out_pose, out_map, out_bbox3d, out_image};
+    // history: out_tokens and cond_tokens both start as the first T_in frames (UMGen.py:1581-1595)
+    std::vector<int> hist[4];   // [B][T_cur][S] "cond_tokens" window (control mode mutates its last bbox3d frame in place)
+    for (int m = 0; m < 4; ++m) {
+        hist[m].resize((size_t)B * T_in * S[m]);
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T_in; ++t)
+                for (int i = 0; i < S[m]; ++i) {
+                    const int64_t v = in[m][((size_t)b * T_in + t) * S[m] + i];
+                    hist[m][((size_t)b * T_in + t) * S[m] + i] = (int)v;
+                    out[m][((size_t)b * T_out + t) * S[m] + i] = v;
+                }
+    }
+    int T_cur = T_in;
+    bool have_ctl = (ctrl_pose != nullptr) && T_ctl > 0;
+    std::vector<int> frame_out((size_t)B * kTokPerFrame);
+    for (int idx = 0; idx < new_frames; ++idx) {
+        if (T_cur > cond_frames) {   // sliding window (UMGen.py:1600-1603)
+            for (int m = 0; m < 4; ++m) {
+                std::vector<int> nw((size_t)B * cond_frames * S[m]);
+                for (int b = 0; b < B; ++b)
+                    memcpy(&nw[(size_t)b * cond_frames * S[m]], &hist[m][((size_t)b * T_cur + (T_cur - cond_frames)) * S[m]],
+                           (size_t)cond_frames * S[m] * sizeof(int));
+                hist[m].swap(nw);
+            }
+            T_cur = cond_frames;
+        }
+        if (have_ctl && idx >= T_ctl) { have_ctl = false; control_test = 0; }   // control tokens exhausted (UMGen.py:1613-1619)
+        std::vector<int> cp;
+        std::vector<unsigned char> cs;
+        if (have_ctl) {
+            cp.resize((size_t)B * 3);
+            for (int b = 0; b < B; ++b)
+                for (int a = 0; a < 3; ++a) cp[b * 3 + a] = (int)ctrl_pose[((size_t)b * T_ctl + idx) * 3 + a];
+            if (ctrl_bbox3d && control_test) {
+                cs.assign((size_t)B * kSlots, 0);
+                for (int b = 0; b < B; ++b)
+                    for (int i = 0; i < kNBox; ++i) {
+                        const int64_t v = ctrl_bbox3d[((size_t)b * T_ctl + idx) * kNBox + i];
+                        if (v != -1) { hist[2][((size_t)b * T_cur + (T_cur - 1)) * kNBox + i] = (int)v; cs[(size_t)b * kSlots + i / kSlotLen] = 1; }
+                    }
+            } else if (ctrl_bbox3d) {
+                return e->fail(UMGEN_E_UNSUPPORTED, "init_tokens['bbox3d'] without control_test is not a supported reference path");
+            }
+        }
+        FrameIO io{B, T_cur, hist[0].data(), hist[1].data(), hist[2].data(), hist[3].data(), have_ctl ? cp.data() : nullptr,
+                   cs.empty() ? nullptr : cs.data(), idx, sampling, nullptr, frame_out.data()};
+        if (int rc = run_frame_any(e, io)) return rc;
+        // append (UMGen.py:1636-1666): control pose tokens are copied verbatim; everything else is what was generated
+        const int off[4] = {0, kOffMap, kOffBox, kOffImg};
+        for (int m = 0; m < 4; ++m) {
+            std::vector<int> nw((size_t)B * (T_cur + 1) * S[m]);
+            for (int b = 0; b < B; ++b) {
+                memcpy(&nw[(size_t)b * (T_cur + 1) * S[m]], &hist[m][(size_t)b * T_cur * S[m]], (size_t)T_cur * S[m] * sizeof(int));
+                for (int i = 0; i < S[m]; ++i) {
+                    const int v = frame_out[(size_t)b * kTokPerFrame + off[m] + i];
+                    nw[((size_t)b * (T_cur + 1) + T_cur) * S[m] + i] = v;
+                    out[m][((size_t)b * T_out + T_in + idx) * S[m] + i] = v;
+                }
+            }
+            hist[m].swap(nw);
+        }
+        T_cur += 1;
+    }
+    return UMGEN_OK;
+}
+
+int umgen_destroy(umgen_engine* e) {
+    if (!e) return UMGEN_OK;
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) hipFree(p);
+    for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
+    for (auto& pr : e->gemm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    if (e->tb.gmap) {}   // tables are in allocs
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return UMGEN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,461 @@
+// Frame-level kernels: token embedding of the TAR/ego stacks, action-aware map warp, conditioning rows, and the
+// per-token sampler with the bbox3d control flow (pad-avoid resample, control resample, rule-based constraint) that the
+// reference runs on the host between decode steps (UMGen.py:1029-1139, 1275-1383) -- here it stays on the device so a
+// frame's 2206 decode steps need no host round trip.
+#include "frame.h"
+
+namespace umgen {
+
+// ---------------------------------------------------------------------------------------------------------
+// embeddings (get_mod_emb_pre / add_spatial_pos_emb / add_bos_eos / add_pos_emb, UMGen.py:411-515)
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline int fixed_aux_id(int s) {   // bos/eos id of scene position s, or -1
+    switch (s) {
+        case kPoseBos: return 0; case kPoseEos: return 1; case kMapBos: return 2; case kMapEos: return 3;
+        case kBoxBos: return 4; case kBoxEos: return 5; case kImgBos: return 6; case kImgEos: return 7;
+        default: return -1;
+    }
+}
+
+__global__ __launch_bounds__(128) void embed_stack_kernel(int stack, EmbedTables tb, WindowTokens w, float* __restrict__ X,
+                                                          float* __restrict__ mapfeat) {
+    const int SS = stack_len(stack);
+    const long row = blockIdx.x;
+    const int s = (int)(row % SS);
+    const int t = (int)((row / SS) % w.T);
+    const int b = (int)(row / ((long)SS * w.T));
+    const int E = tb.E;
+    const long fr = (long)b * w.T + t;
+    float* xr = X + row * E;
+    const float* spe = tb.spe + (long)s * E;
+    const float* tpe = tb.tpe + (long)t * E;
+    const int aux = fixed_aux_id(s);
+    if (aux >= 0) {
+        const float* a = tb.axe + (long)aux * E;
+        for (int c = threadIdx.x; c < E; c += 128) xr[c] = (a[c] + spe[c]) + tpe[c];
+    } else if (s < kPoseEos) {
+        const bf16_t* p = tb.fouier_pe + (long)w.pose[fr * kNPose + (s - 1)] * E;
+        for (int c = threadIdx.x; c < E; c += 128) xr[c] = (bf16_to_f32(p[c]) + spe[c]) + tpe[c];
+    } else if (s < kMapEos) {
+        const int k = s - kMapC0;
+        const float* gm = tb.gmap + (long)w.map[fr * kNMap + k] * E;
+        if (stack == STACK_EGO) {
+            for (int c = threadIdx.x; c < E; c += 128) xr[c] = (gm[c] + spe[c]) + tpe[c];
+        } else {
+            float* mf = mapfeat + (fr * kNMap + k) * E;
+            if (stack == STACK_TAR) {   // grid-centre positional embedding only in forward_tar_net (UMGen.py:722-726)
+                const bf16_t* gp = tb.grid_posi + (long)k * E;
+                for (int c = threadIdx.x; c < E; c += 128) mf[c] = gm[c] + bf16_to_f32(gp[c]);
+            } else {
+                for (int c = threadIdx.x; c < E; c += 128) mf[c] = gm[c];
+            }
+        }
+    } else if (s < kBoxEos) {
+        const int k = s - kBoxC0;
+        const int* bt = w.box + fr * kNBox;
+        const int slot = k / kSlotLen;
+        const float* be = tb.be + (long)bt[k] * E;
+        const bf16_t* px = tb.posi + (long)bt[slot * kSlotLen] * E;
+        const bf16_t* py = tb.posi + (long)bt[slot * kSlotLen + 1] * E;
+        for (int c = threadIdx.x; c < E; c += 128) {
+            const float pe = bf16_to_f32(f32_to_bf16(bf16_to_f32(px[c]) + bf16_to_f32(py[c])));   // bf16 + bf16 -> bf16
+            xr[c] = ((be[c] + pe) + spe[c]) + tpe[c];
+        }
+    } else {
+        const float* gi = tb.gimg + (long)w.img[fr * kNImg + (s - kImgC0)] * E;
+        for (int c = threadIdx.x; c < E; c += 128) xr[c] = (gi[c] + spe[c]) + tpe[c];
+    }
+}
+
+void launch_embed_stack(hipStream_t s, int stack, const EmbedTables& tb, const WindowTokens& w, float* X, float* mapfeat) {
+    const long rows = (long)w.B * w.T * stack_len(stack);
+    hipLaunchKernelGGL(embed_stack_kernel, dim3((unsigned)rows), dim3(128), 0, s, stack, tb, w, X, mapfeat);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// affine_transform (UMGen.py:310-354): F.affine_grid + F.grid_sample(bilinear, zeros, align_corners=False) on the
+// 32x32 map-feature grid; theta = [[cos(-th), -sin(-th), -dy], [sin(-th), cos(-th), -dx]], dx = 2(dx_m/4)/32.
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline float base_coord(int i) {   // at::linspace(-1, 1, 32) * 31 / 32  (fp32, symmetric linspace)
+    const float step = 2.0f / 31.0f;
+    const float v = (i < 16) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(31 - i));
+    return (v * 31.0f) / 32.0f;
+}
+
+__global__ __launch_bounds__(128) void warp_map_kernel(int stack, EmbedTables tb, int T, const float* __restrict__ mapfeat,
+                                                       const float* __restrict__ pose_diff, float* __restrict__ X,
+                                                       float* __restrict__ warped_last) {
+    const int SS = stack_len(stack);
+    const long cell = blockIdx.x;            // (b*T + t)*1024 + k
+    const int k = (int)(cell % kNMap);
+    const long fr = cell / kNMap;
+    const int t = (int)(fr % T);
+    const int b = (int)(fr / T);
+    const int E = tb.E;
+    const int hy = k >> 5, wx = k & 31;
+    const float dxm = pose_diff[fr * 3 + 0], dym = pose_diff[fr * 3 + 1], th = pose_diff[fr * 3 + 2];
+    const float dx = 2.0f * (dxm / 4.0f) / 32.0f, dy = 2.0f * (dym / 4.0f) / 32.0f;
+    const float cs = cosf(-th), sn = sinf(-th);
+    const float bx = base_coord(wx), by = base_coord(hy);
+    const float gx = fmaf(cs, bx, fmaf(-sn, by, -dy));
+    const float gy = fmaf(sn, bx, fmaf(cs, by, -dx));
+    const float ix = ((gx + 1.0f) * 32.0f - 1.0f) / 2.0f;
+    const float iy = ((gy + 1.0f) * 32.0f - 1.0f) / 2.0f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float nw = (x0f + 1.0f - ix) * (y0f + 1.0f - iy), ne = (ix - x0f) * (y0f + 1.0f - iy);
+    const float sw = (x0f + 1.0f - ix) * (iy - y0f), se = (ix - x0f) * (iy - y0f);
+    const float* src = mapfeat + fr * kNMap * E;
+    const bool in_nw = (x0 >= 0 && x0 < 32 && y0 >= 0 && y0 < 32), in_ne = (x1 >= 0 && x1 < 32 && y0 >= 0 && y0 < 32);
+    const bool in_sw = (x0 >= 0 && x0 < 32 && y1 >= 0 && y1 < 32), in_se = (x1 >= 0 && x1 < 32 && y1 >= 0 && y1 < 32);
+    const float* pnw = src + (long)(y0 * 32 + x0) * E;
+    const float* pne = src + (long)(y0 * 32 + x1) * E;
+    const float* psw = src + (long)(y1 * 32 + x0) * E;
+    const float* pse = src + (long)(y1 * 32 + x1) * E;
+    const float* f = src + (long)k * E;
+    const int s = kMapC0 + k;
+    float* xr = X + ((fr * SS) + s) * E;
+    const float* spe = tb.spe + (long)s * E;
+    const float* tpe = tb.tpe + (long)t * E;
+    float* wl = (warped_last && t == T - 1) ? warped_last + ((long)b * kNMap + k) * E : nullptr;
+    for (int c = threadIdx.x; c < E; c += 128) {
+        float o = 0.f;
+        if (in_nw) o += pnw[c] * nw;
+        if (in_ne) o += pne[c] * ne;
+        if (in_sw) o += psw[c] * sw;
+        if (in_se) o += pse[c] * se;
+        xr[c] = ((o + f[c]) + spe[c]) + tpe[c];
+        if (wl) wl[c] = o;
+    }
+}
+
+void launch_warp_map(hipStream_t s, int stack, const EmbedTables& tb, int B, int T, const float* mapfeat, const float* pose_diff,
+                     float* X, float* warped_last) {
+    hipLaunchKernelGGL(warp_map_kernel, dim3((unsigned)((long)B * T * kNMap)), dim3(128), 0, s, stack, tb, T, mapfeat, pose_diff, X,
+                       warped_last);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conditioning rows of the OAR (UMGen.py:1496-1511, 1227-1231): last history frame of each stack after its final LN
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cond_rows_kernel(int stack, int T, int E, const float* __restrict__ X, const float* __restrict__ ln_w,
+                                                        const float* __restrict__ warped_last, float* __restrict__ cond, int n_rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (r >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    int s;
+    if (stack == STACK_MAP) s = kMapBos + r;
+    else if (stack == STACK_BOX) s = kBoxBos + r;
+    else s = (r < 5) ? r : (kImgBos + (r - 5));
+    const int SS = stack_len(stack);
+    const float* xr = X + (((long)b * T + (T - 1)) * SS + s) * E;
+    float sum = 0.f;
+    for (int c = lane; c < E; c += 64) sum += xr[c];
+    const float mean = wave_sum(sum) / (float)E;
+    float q = 0.f;
+    for (int c = lane; c < E; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+    float* o = cond + ((long)b * kSeq + s) * E;
+    const float* wl = (stack == STACK_MAP && s >= kMapC0 && s < kMapEos) ? warped_last + ((long)b * kNMap + (s - kMapC0)) * E : nullptr;
+    for (int c = lane; c < E; c += 64) {
+        float v = (xr[c] - mean) * rstd * ln_w[c];
+        if (wl) v += wl[c];
+        o[c] = v;
+    }
+}
+
+void launch_cond_rows(hipStream_t s, int stack, int B, int T, int E, const float* X, const float* ln_w, const float* warped_last,
+                      float* cond) {
+    const int n_rows = stack == STACK_MAP ? 1026 : (stack == STACK_BOX ? 662 : 5 + 514);
+    hipLaunchKernelGGL(cond_rows_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, stack, T, E, X, ln_w, warped_last, cond, n_rows);
+}
+
+__global__ void first_input_kernel(int E, const float* __restrict__ row, const float* __restrict__ cond, float* __restrict__ x) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < E; c += blockDim.x) x[(long)b * E + c] = row[c] + cond[(long)b * kSeq * E + c];
+}
+void launch_first_input(hipStream_t s, int B, int E, const float* tske_row, const float* cond, float* x) {
+    hipLaunchKernelGGL(first_input_kernel, dim3(B), dim3(256), 0, s, E, tske_row, cond, x);
+}
+
+__global__ void ego_queries_kernel(EmbedTables tb, int T, float* __restrict__ x) {
+    const int j = blockIdx.x % 3;
+    const int E = tb.E;
+    for (int c = threadIdx.x; c < E; c += blockDim.x)
+        x[(long)blockIdx.x * E + c] = (tb.egoe[(long)j * E + c] + tb.spe[(long)j * E + c]) + tb.tpe[(long)(T - 1) * E + c];
+}
+void launch_ego_queries(hipStream_t s, const EmbedTables& tb, int B, int T, float* x) {
+    hipLaunchKernelGGL(ego_queries_kernel, dim3(B * 3), dim3(256), 0, s, tb, T, x);
+}
+
+__global__ void advance_kernel(OarState* st) { st->step += 1; }
+void launch_advance(hipStream_t s, OarState* st) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, st); }
+
+// ---------------------------------------------------------------------------------------------------------
+// sampler: topk (UMGen.py:899-913) + sfmx_temp_sampling (967-974); torch.multinomial is replaced by inverse-CDF
+// sampling on the build's counter-based uniform (bit-for-bit the oracle's OracleUMGen.sample)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxKept = 64;
+struct SampleShared {
+    float red_v[4];
+    int red_i[4];
+    float win_v;
+    int win_i;
+    int n_kept;
+    int kept_i[kMaxKept];
+    float kept_v[kMaxKept];
+    int result;
+};
+
+// all 256 threads call; returns the sampled index.  mask_idx (>=0) is treated as -inf.
+__device__ int block_sample_topk(const float* __restrict__ logits, int V, int k, float temp, float u, int mask_idx, SampleShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int idx = tid + 256 * i;
+        v[i] = (idx < V && idx != mask_idx) ? logits[idx] : -INFINITY;
+    }
+    float kth = -INFINITY;
+    const int kk = min(k, V);
+    for (int it = 0; it < kk; ++it) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int idx = tid + 256 * i;
+            if (v[i] > bv) { bv = v[i]; bi = idx; }   // ascending idx within a thread => lowest index kept on ties
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { sh.red_v[wave] = bv; sh.red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float wv = sh.red_v[0];
+            int wi = sh.red_i[0];
+            for (int w2 = 1; w2 < 4; ++w2)
+                if (sh.red_v[w2] > wv || (sh.red_v[w2] == wv && sh.red_i[w2] < wi)) { wv = sh.red_v[w2]; wi = sh.red_i[w2]; }
+            sh.win_v = wv;
+            sh.win_i = wi;
+        }
+        __syncthreads();
+        kth = sh.win_v;
+        const int wi = sh.win_i;
+        if ((wi & 255) == tid) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (tid + 256 * i == wi) v[i] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) sh.n_kept = 0;
+    __syncthreads();
+    for (int idx = tid; idx < V; idx += 256) {
+        const float l = (idx != mask_idx) ? logits[idx] : -INFINITY;
+        if (l >= kth && l > -INFINITY) {
+            const int slot = atomicAdd(&sh.n_kept, 1);
+            if (slot < kMaxKept) { sh.kept_i[slot] = idx; sh.kept_v[slot] = l; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int n = min(sh.n_kept, kMaxKept);
+        for (int a = 1; a < n; ++a) {   // insertion sort by index
+            const int ki = sh.kept_i[a];
+            const float kv = sh.kept_v[a];
+            int bpos = a - 1;
+            while (bpos >= 0 && sh.kept_i[bpos] > ki) { sh.kept_i[bpos + 1] = sh.kept_i[bpos]; sh.kept_v[bpos + 1] = sh.kept_v[bpos]; --bpos; }
+            sh.kept_i[bpos + 1] = ki;
+            sh.kept_v[bpos + 1] = kv;
+        }
+        float zmax = -INFINITY;
+        for (int a = 0; a < n; ++a) { sh.kept_v[a] = sh.kept_v[a] / temp; zmax = fmaxf(zmax, sh.kept_v[a]); }
+        float total = 0.f;
+        for (int a = 0; a < n; ++a) { sh.kept_v[a] = expf(sh.kept_v[a] - zmax); total = __fadd_rn(total, sh.kept_v[a]); }
+        const float target = __fmul_rn(u, total);
+        float c = 0.f;
+        int res = sh.kept_i[n - 1];
+        for (int a = 0; a < n; ++a) {
+            c = __fadd_rn(c, sh.kept_v[a]);
+            if (c > target) { res = sh.kept_i[a]; break; }
+        }
+        sh.result = res;
+    }
+    __syncthreads();
+    const int r = sh.result;
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rule-based constraint (UMGen.py:1275-1383) and its helpers, evaluated by one thread
+//   decode: BBox3DTokenizer.decode_single_objects (tokenizer.py:679-687) + Normalize.unnormalize_bbox3d (normalize.py:136-229)
+//   collision: BoxOverlap.check_collision(fliter=True) (misc.py:591-630), bbox3d2bevcorners (143-177), box_collision_test (203-311)
+// fp64 / fp32 operations are issued unfused (__dmul_rn, __fsub_rn ...) to follow numpy's evaluation order.
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline double box_bin(int i) {   // np.linspace(0, 1, 1024)[i]
+    return (i >= 1023) ? 1.0 : __dadd_rn(__dmul_rn((double)i, 1.0 / 1023.0), 0.0);
+}
+__constant__ double kBoxLo[10] = {-64, -64, -5, 0, 0, 0, -3.14, -20, -15, -0.3};
+__constant__ double kBoxHi[10] = {64, 64, 5, 15, 4, 5, 3.14, 20, 15, 0.3};
+
+__device__ inline bool gt_cross(float a1, float a0, float b1, float b0) {   // a1*a0 > b1*b0 in fp32
+    return __fmul_rn(a1, a0) > __fmul_rn(b1, b0);
+}
+
+__device__ bool check_collision_dev(const double* boxes, int n, float (*cor)[8]) {
+    if (n == 1) return false;
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const double* bx = boxes + i * 10;
+        if (bx[0] >= 63.0) continue;   // fliter_and_map_object (misc.py:475-481)
+        const double l = bx[3], w = bx[4], ang = -bx[6];
+        const double sn = sin(ang), cs = cos(ang);
+        const double tx[4] = {-0.5, -0.5, 0.5, 0.5}, ty[4] = {-0.5, 0.5, 0.5, -0.5};
+        for (int k = 0; k < 4; ++k) {
+            const double x = __dmul_rn(tx[k], l), y = __dmul_rn(ty[k], w);
+            const double rx = __dadd_rn(__dmul_rn(x, cs), __dmul_rn(y, -sn));
+            const double ry = __dadd_rn(__dmul_rn(x, sn), __dmul_rn(y, cs));
+            cor[m][2 * k] = (float)__dadd_rn(rx, bx[0]);
+            cor[m][2 * k + 1] = (float)__dadd_rn(ry, bx[1]);
+        }
+        ++m;
+    }
+    if (m <= 1) return false;
+    const float* q = cor[m - 1];
+    float qx0 = q[0], qx1 = q[0], qy0 = q[1], qy1 = q[1];
+    for (int k = 1; k < 4; ++k) { qx0 = fminf(qx0, q[2 * k]); qx1 = fmaxf(qx1, q[2 * k]); qy0 = fminf(qy0, q[2 * k + 1]); qy1 = fmaxf(qy1, q[2 * k + 1]); }
+    for (int i = 0; i < m; ++i) {
+        const float* bq = cor[i];
+        float bx0 = bq[0], bx1 = bq[0], by0 = bq[1], by1 = bq[1];
+        for (int k = 1; k < 4; ++k) { bx0 = fminf(bx0, bq[2 * k]); bx1 = fmaxf(bx1, bq[2 * k]); by0 = fminf(by0, bq[2 * k + 1]); by1 = fmaxf(by1, bq[2 * k + 1]); }
+        const float iw = __fsub_rn(fminf(bx1, qx1), fmaxf(bx0, qx0));
+        if (!(iw > 0.f)) continue;
+        const float ih = __fsub_rn(fminf(by1, qy1), fmaxf(by0, qy0));
+        if (!(ih > 0.f)) continue;
+        for (int k = 0; k < 4; ++k) {
+            const float A0 = bq[2 * k], A1 = bq[2 * k + 1], B0 = bq[2 * ((k + 1) & 3)], B1 = bq[2 * ((k + 1) & 3) + 1];
+            for (int l2 = 0; l2 < 4; ++l2) {
+                const float C0 = q[2 * l2], C1 = q[2 * l2 + 1], D0 = q[2 * ((l2 + 1) & 3)], D1 = q[2 * ((l2 + 1) & 3) + 1];
+                const bool acd = gt_cross(__fsub_rn(D1, A1), __fsub_rn(C0, A0), __fsub_rn(C1, A1), __fsub_rn(D0, A0));
+                const bool bcd = gt_cross(__fsub_rn(D1, B1), __fsub_rn(C0, B0), __fsub_rn(C1, B1), __fsub_rn(D0, B0));
+                if (acd != bcd) {
+                    const bool abc = gt_cross(__fsub_rn(C1, A1), __fsub_rn(B0, A0), __fsub_rn(B1, A1), __fsub_rn(C0, A0));
+                    const bool abd = gt_cross(__fsub_rn(D1, A1), __fsub_rn(B0, A0), __fsub_rn(B1, A1), __fsub_rn(D0, A0));
+                    if (abc != abd) return true;
+                }
+            }
+        }
+    }
+    return false;
+}
+
+__device__ inline void write_next_input(const SampleArgs& a, int b, int j, const float* emb_f, const bf16_t* emb_b) {
+    const int E = a.tb.E;
+    const float* cr = a.cond + ((long)b * kSeq + (j + 1)) * E;
+    float* xo = a.x_next + (long)b * E;
+    for (int c = threadIdx.x; c < E; c += blockDim.x) xo[c] = (emb_f ? emb_f[c] : bf16_to_f32(emb_b[c])) + cr[c];
+}
+
+// steps whose emitted scene token is known: pose prefix (bos, 3 pose tokens, eos) and every bos/eos (d_token_pos,
+// UMGen.py:976-984, 1046-1050)
+__global__ __launch_bounds__(256) void fixed_token_kernel(SampleArgs a) {
+    const int b = blockIdx.x, j = a.st->step, E = a.tb.E;
+    const int aux = fixed_aux_id(j);
+    if (aux >= 0) write_next_input(a, b, j, a.tb.axe + (long)aux * E, nullptr);
+    else write_next_input(a, b, j, nullptr, a.tb.fouier_pe + (long)a.tokens[(long)b * kTokPerFrame + (j - 1)] * E);
+}
+void launch_fixed_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchKernelGGL(fixed_token_kernel, dim3(B), dim3(256), 0, s, a); }
+
+__global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
+    __shared__ SampleShared sh;
+    __shared__ float cor[64][8];
+    __shared__ int s_tok;
+    const int b = blockIdx.x, j = a.st->step, frame = a.st->frame_idx, E = a.tb.E;
+    const int pos1 = j + 1;   // the reference's 1-based curr_seq_len
+    const unsigned long long seed = a.seeds[b];
+    const float* lg = a.logits + (long)b * a.ld_logits;
+    const int topk = a.mod == 1 ? a.sp.top_k_map : (a.mod == 3 ? a.sp.topk_image : a.sp.top_k);
+    int tok = block_sample_topk(lg, a.vocab, topk, a.sp.temperature, rng_uniform(seed, frame, pos1, DRAW_MAIN), -1, sh);
+    int off, k;
+    if (a.mod == 1) { off = kOffMap; k = j - kMapC0; }
+    else if (a.mod == 2) { off = kOffBox; k = j - kBoxC0; }
+    else { off = kOffImg; k = j - kImgC0; }
+    int* toks = a.tokens + (long)b * kTokPerFrame;
+    if (a.mod == 2) {
+        const float* lt = a.logits_tar + (long)b * a.ld_logits;
+        const int prev = a.prev_box[(long)b * kNBox + k];
+        if (a.control_slot) {   // UMGen.py:1083-1089
+            const int object_id = (pos1 - 1032) / kSlotLen;
+            if (object_id < kSlots && a.control_slot[b * kSlots + object_id]) {
+                tok = block_sample_topk(lt, a.vocab, a.sp.top_k, a.sp.temperature, rng_uniform(seed, frame, pos1, DRAW_CONTROL), a.vocab - 1, sh);
+                if (threadIdx.x == 0) atomicAdd(a.counters + 1, 1);
+            }
+        }
+        if (tok == kBoxPad && a.sp.merge_ar_tar && prev != kBoxPad && !a.sp.only_ar) {   // UMGen.py:1092-1104
+            tok = block_sample_topk(lt, a.vocab, a.sp.top_k, a.sp.temperature, rng_uniform(seed, frame, pos1, DRAW_PAD_AVOID), -1, sh);
+            if (threadIdx.x == 0) atomicAdd(a.counters + 0, 1);
+        }
+        if (a.sp.rule_constrain && !a.forced && tok != kBoxPad && (pos1 - 1032) % kSlotLen == 0) {   // UMGen.py:1116-1123
+            if (threadIdx.x == 0) {
+                double* boxes = a.boxes + (long)b * 64 * 10;
+                int n = a.n_boxes[b];
+                if (n == 0) {
+                    const double ego[10] = {0, 0, 0, 5.176, 2.297, 1.777, 0, 0, 0, 0};
+                    for (int q = 0; q < 10; ++q) boxes[q] = ego[q];
+                    n = 1;
+                }
+                double* nb = boxes + n * 10;
+                for (int q = 0; q < 10; ++q) {
+                    const int t = toks[off + k - 10 + q];
+                    const int right = min(max(t, 0), 1023), left = min(max(t - 1, 0), 1023);
+                    const double v = __dadd_rn(box_bin(left), box_bin(right)) / 2.0;
+                    nb[q] = __dadd_rn(__dmul_rn(v, kBoxHi[q] - kBoxLo[q]), kBoxLo[q]);
+                }
+                ++n;
+                const bool collision = check_collision_dev(boxes, n, cor);
+                const bool newborn = (prev == kBoxPad);
+                atomicAdd(a.counters + 2, 1);
+                if (collision) atomicAdd(a.counters + 3, 1);
+                int t2 = tok;
+                if ((newborn && collision) || (n > 30 && newborn)) {
+                    for (int q = 1; q <= 10; ++q) toks[off + k - q] = kBoxPad;
+                    --n;
+                    t2 = kBoxPad;
+                    atomicAdd(a.counters + 4, 1);
+                }
+                a.n_boxes[b] = n;
+                s_tok = t2;
+            }
+            __syncthreads();
+            tok = s_tok;
+        }
+    }
+    if (a.forced) tok = a.forced[(long)b * kTokPerFrame + off + k];
+    if (threadIdx.x == 0) toks[off + k] = tok;
+    const float* emb = (a.mod == 1) ? a.tb.gmap + (long)tok * E : (a.mod == 3 ? a.tb.gimg + (long)tok * E : a.tb.be + (long)tok * E);
+    write_next_input(a, b, j, emb, nullptr);
+}
+void launch_sample_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchKernelGGL(sample_token_kernel, dim3(B), dim3(256), 0, s, a); }
+
+__global__ __launch_bounds__(256) void sample_ego_kernel(const float* __restrict__ logits, int vocab, SamplerParams sp,
+                                                         const unsigned long long* __restrict__ seeds, int frame_idx,
+                                                         const int* __restrict__ forced, int* __restrict__ out_tokens) {
+    __shared__ SampleShared sh;
+    const int b = blockIdx.x / 3, jq = blockIdx.x % 3;
+    int tok = block_sample_topk(logits + (long)blockIdx.x * vocab, vocab, sp.top_k, sp.temperature,
+                                rng_uniform(seeds[b], frame_idx, kSeq + jq, DRAW_MAIN), -1, sh);
+    if (forced) tok = forced[(long)b * kTokPerFrame + jq];
+    if (threadIdx.x == 0) out_tokens[b * 3 + jq] = tok;
+}
+void launch_sample_ego(hipStream_t s, const float* logits, int vocab, SamplerParams sp, const unsigned long long* seeds, int frame_idx,
+                       const int* forced, int* out_tokens, int B) {
+    hipLaunchKernelGGL(sample_ego_kernel, dim3(B * 3), dim3(256), 0, s, logits, vocab, sp, seeds, frame_idx, forced, out_tokens);
+}
+
+}  // namespace umgen

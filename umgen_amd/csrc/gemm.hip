@@ -1,0 +1,202 @@
+// GEMM kernels for the TAR / ego prefill stacks (replace F.linear at module.py:184-190, 236-242 on [B*T*S, E] rows).
+//   * gemm_bf16_mfma: bf16 operands, fp32 accumulate on the CDNA4 matrix cores (v_mfma_f32_16x16x32_bf16),
+//     128x128x64 tiles, 4 waves (2x2) per workgroup, XOR-swizzled LDS read with ds_read_b128, register-prefetched
+//     global->LDS staging.  Epilogues fuse bias, exact GELU, the fp32 residual add and the transposed V store.
+//   * gemm_valu: exact fp32 FMA chain (parity mode and the one-off GMLP(codebook) tables).
+#include "kernels.h"
+
+namespace umgen {
+
+template <int MODE, typename TO>
+__device__ inline void epilogue4(const GemmArgs& a, int z, int i0, int j, const float (&v)[4]) {
+    // v[r] = C[i0 + r][j]
+    if (j >= a.Nj || i0 >= a.Mi) return;
+    if (MODE == GEMM_VT) {
+        const float b = a.bias ? a.bias[j] : 0.f;
+        TO* dst = reinterpret_cast<TO*>(a.out) + (((long)z * a.H + j / kHeadDim) * kHeadDim + j % kHeadDim) * a.ldo + i0;
+        if (i0 + 3 < a.Mi) {
+            float o[4] = {v[0] + b, v[1] + b, v[2] + b, v[3] + b};
+            store4(dst, o);
+        } else {
+            for (int r = 0; r < 4 && i0 + r < a.Mi; ++r) dst[r] = Cvt<TO>::from_f(v[r] + b);
+        }
+        return;
+    }
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = v[r] + (a.bias ? a.bias[i0 + r] : 0.f);   // Mi (features) is a multiple of 4
+        if (MODE == GEMM_STORE && a.gelu) t = gelu_erf(t);
+        o[r] = t;
+    }
+    if (MODE == GEMM_RESID) {
+        float* x = reinterpret_cast<float*>(a.out) + (long)z * a.strideO + (long)j * a.ldo + i0;
+        float c[4];
+        load4(x, c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] += o[r];
+        store4(x, c);
+    } else if (MODE == GEMM_STORE_F32) {
+        store4(reinterpret_cast<float*>(a.out) + (long)z * a.strideO + (long)j * a.ldo + i0, o);
+    } else {
+        store4(reinterpret_cast<TO*>(a.out) + (long)z * a.strideO + (long)j * a.ldo + i0, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA bf16
+// ---------------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+
+__device__ inline int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }  // byte offset
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * BK * 2];
+    unsigned char* ldsP = lds;
+    unsigned char* ldsQ = lds + BM * BK * 2;
+    const int z = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i_base = blockIdx.x * BM, j_base = blockIdx.y * BN;
+    const bf16_t* P = reinterpret_cast<const bf16_t*>(a.P) + (long)z * a.strideP;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q) + (long)z * a.strideQ;
+
+    // staging assignment: 4 x 16-byte chunks per operand per thread
+    const int srow = tid >> 3, schunk = tid & 7;
+    const bf16_t* pp[4];
+    const bf16_t* qq[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        int r = srow + 32 * it;
+        int gi = min(i_base + r, a.Mi - 1), gj = min(j_base + r, a.Nj - 1);
+        pp[it] = P + (long)gi * a.ldp + schunk * 8;
+        qq[it] = Q + (long)gj * a.ldq + schunk * 8;
+    }
+    uint4 rp[4], rq[4];
+    auto gload = [&](int k0) {
+        const bool ok = (k0 + schunk * 8) < a.K;   // K is a multiple of 8; chunks past K contribute zeros
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            rp[it] = ok ? *reinterpret_cast<const uint4*>(pp[it] + k0) : make_uint4(0, 0, 0, 0);
+            rq[it] = ok ? *reinterpret_cast<const uint4*>(qq[it] + k0) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, g = lane >> 4;
+    const int nkt = (a.K + BK - 1) / BK;
+    gload(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int r = srow + 32 * it;
+            *reinterpret_cast<uint4*>(ldsP + swz(r, schunk)) = rp[it];
+            *reinterpret_cast<uint4*>(ldsQ + swz(r, schunk)) = rq[it];
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) gload((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[4], bfr[4];
+            const int c = kk * 4 + g;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const bf16x8_t*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bfr[n] = *reinterpret_cast<const bf16x8_t*>(ldsQ + swz(wj * 64 + n * 16 + frow, c));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of the 16x16 MFMA: col = lane&15 (j), row = 4*(lane>>4) + reg (i)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int i0 = i_base + wi * 64 + m * 16 + 4 * g;
+            const int j = j_base + wj * 64 + n * 16 + frow;
+            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+            epilogue4<MODE, bf16_t>(a, z, i0, j, v);
+        }
+}
+
+void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a) {
+    dim3 grid((a.Mi + BM - 1) / BM, (a.Nj + BN - 1) / BN, a.batch), block(256);
+    switch (a.mode) {
+        case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_STORE>, grid, block, 0, s, a); break;
+        case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_RESID>, grid, block, 0, s, a); break;
+        case GEMM_STORE_F32: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_STORE_F32>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_VT>, grid, block, 0, s, a); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// VALU fp32 (exact): 64x64 tile, 16-deep k-slab, each thread a 4(i) x 4(j) micro-tile; k ascending fmaf chain
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, typename TP, typename TQ, typename TO>
+__global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs a) {
+    __shared__ float sP[16][64 + 4];
+    __shared__ float sQ[16][64 + 4];
+    const int z = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int i_base = blockIdx.x * 64, j_base = blockIdx.y * 64;
+    const TP* P = reinterpret_cast<const TP*>(a.P) + (long)z * a.strideP;
+    const TQ* Q = reinterpret_cast<const TQ*>(a.Q) + (long)z * a.strideQ;
+    const int ti = tid & 15, tj = tid >> 4;   // thread owns i = i_base + 4*ti + r, j = j_base + 4*tj + c
+    float acc[4][4] = {};
+    const int lr = tid >> 2, lk = (tid & 3) * 4;   // staging: row lr (0..63), k offset lk (0..12)
+    for (int k0 = 0; k0 < a.K; k0 += 16) {
+        {
+            const int gi = min(i_base + lr, a.Mi - 1), gj = min(j_base + lr, a.Nj - 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + lk + e;
+                sP[lk + e][lr] = (k < a.K) ? Cvt<TP>::to_f(P[(long)gi * a.ldp + k]) : 0.f;
+                sQ[lk + e][lr] = (k < a.K) ? Cvt<TQ>::to_f(Q[(long)gj * a.ldq + k]) : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float p[4], q[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = sP[k][4 * ti + r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = sQ[k][4 * tj + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(p[r], q[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v[4] = {acc[0][c], acc[1][c], acc[2][c], acc[3][c]};
+        epilogue4<MODE, TO>(a, z, i_base + 4 * ti, j_base + 4 * tj + c, v);
+    }
+}
+
+template <typename TP, typename TQ>
+void launch_gemm_valu(hipStream_t s, const GemmArgs& a) {
+    dim3 grid((a.Mi + 63) / 64, (a.Nj + 63) / 64, a.batch), block(256);
+    // output element type of STORE / VT follows the activation operand (Q for STORE, P for VT)
+    switch (a.mode) {
+        case GEMM_STORE: hipLaunchKernelGGL((gemm_valu_kernel<GEMM_STORE, TP, TQ, TQ>), grid, block, 0, s, a); break;
+        case GEMM_RESID: hipLaunchKernelGGL((gemm_valu_kernel<GEMM_RESID, TP, TQ, float>), grid, block, 0, s, a); break;
+        case GEMM_STORE_F32: hipLaunchKernelGGL((gemm_valu_kernel<GEMM_STORE_F32, TP, TQ, float>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((gemm_valu_kernel<GEMM_VT, TP, TQ, TP>), grid, block, 0, s, a); break;
+    }
+}
+template void launch_gemm_valu<float, float>(hipStream_t, const GemmArgs&);
+template void launch_gemm_valu<bf16_t, float>(hipStream_t, const GemmArgs&);   // bf16 weights x fp32 activations (tables)
+template void launch_gemm_valu<bf16_t, bf16_t>(hipStream_t, const GemmArgs&);
+
+}  // namespace umgen

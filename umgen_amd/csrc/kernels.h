@@ -1,0 +1,89 @@
+// Launcher declarations for the HIP kernels of libumgen_hip (implemented in the *.hip files next to this header).
+#pragma once
+#include "common.h"
+
+namespace umgen {
+
+// ------------------------------------------------------------------------------------------------
+// GEMM  C[i][j] = sum_k P[i][k] * Q[j][k]   (both operands K-contiguous, like nn.Linear weights)
+// The lane that owns C holds 4 consecutive i for one j, so:
+//   P = weights, Q = activations  -> out[token j][feature i..i+3]   (row-major activations out)
+//   P = activations, Q = weights  -> Vt[feature j][token i..i+3]    (transposed V for spatial attention)
+// ------------------------------------------------------------------------------------------------
+enum GemmMode {
+    GEMM_STORE = 0,      // outT[j*ldo + i] = acc + bias[i]   (optional exact GELU)          T = operand dtype
+    GEMM_RESID = 1,      // X[j*ldo + i]  += acc + bias[i]                                   fp32 residual stream
+    GEMM_STORE_F32 = 2,  // outF[j*ldo + i] = acc + bias[i]
+    GEMM_VT = 3          // Vt[((z*H + j/48)*48 + j%48)*ldo + i] = acc + bias[j]             T, per-frame batch z
+};
+struct GemmArgs {
+    const void* P; const void* Q;
+    int Mi, Nj, K;
+    long ldp, ldq;
+    long strideP, strideQ;   // per batch z (elements)
+    int batch;
+    int mode;
+    const float* bias;       // nullable
+    int gelu;
+    void* out;
+    long ldo;
+    long strideO;            // per batch z (GEMM_STORE/RESID/F32 only)
+    int H;                   // heads (GEMM_VT)
+};
+void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a);               // P,Q bf16, MFMA 16x16x32
+template <typename TP, typename TQ> void launch_gemm_valu(hipStream_t s, const GemmArgs& a);  // exact fp32 FMA chain
+
+// ------------------------------------------------------------------------------------------------
+// row ops
+// ------------------------------------------------------------------------------------------------
+// out[r] = LayerNorm(x[row_base + r*row_stride]) * w   (weight only, eps 1e-5, module.py:26-37)
+template <typename T> void launch_layernorm(hipStream_t s, const float* x, long row_stride, long n_rows, int E, const float* w, T* out);
+
+// ------------------------------------------------------------------------------------------------
+// attention (head_dim 48)
+// ------------------------------------------------------------------------------------------------
+// spatial (non-causal) attention inside each frame: qk [F*S][2E] row-major (q | k), vt [F][H][48][S_pad], y [F*S][E]
+void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int S_pad, int H);
+template <typename T> void launch_attn_spatial_valu(hipStream_t s, const T* qk, const T* vt, T* y, int F, int S, int S_pad, int H);
+// temporal causal attention over T frames per spatial position: qkv [B*T*S][3E] row-major, y [B*T*S][E]
+template <typename T> void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int T_, int S, int H);
+
+// few-query attention over a key/value stream (OAR decode, ego decoder): partial pass, NSPLIT splits of the keys.
+//   q   [NQ][E] fp32;  K,V rows of scene sc = kv_base + sc*scene_stride + key*key_stride (+ v_off for V), head h at +h*48
+//   L   = *d_len + len_add  when d_len != nullptr, else len_add;  scene of query qi = qi / q_per_scene
+//   part [NQ][H][NSPLIT][50] = (m, l, o[48])
+constexpr int kAttnSplit = 8;
+constexpr int kAttnPart = 50;
+template <typename T> void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long key_stride,
+                                               long v_off, int NQ, int q_per_scene, int H, const int* d_len, int len_add, float* part);
+
+// ------------------------------------------------------------------------------------------------
+// few-row linear layers (decode / ego decoder): weights W [N][K] of type T, activations fp32
+// ------------------------------------------------------------------------------------------------
+enum GemvOut {
+    GEMV_OUT_F32 = 0,    // out[m*ldo + n] = v
+    GEMV_OUT_GELU = 1,   // out[m*ldo + n] = gelu(v)
+    GEMV_OUT_QKV = 2     // n < E: q[m][n] = v ; else K/V cache of scene m at position *d_len: cache[m*scene_stride + pos*2E + (n-E)]
+};
+struct GemvArgs {
+    const float* x; long ldx;      // [M][K] input rows
+    const int* d_xoff; long xoff_mul;   // optional device-side row offset: x += (*d_xoff) * xoff_mul
+    const float* ln_w;             // nullable: apply LayerNorm(weight only) to each input row first
+    const void* W; const float* bias; int N, K, M;
+    int out_mode;
+    float* out; long ldo;
+    void* cache; long scene_stride; const int* d_len;   // GEMV_OUT_QKV
+    int E;
+};
+template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
+
+// x[m][n] += sum_k a[m][k] W[n][k] + bias[n];  if part != nullptr the input a is first combined from the attention
+// partials (K must equal H*48)
+struct GemvResidArgs {
+    const float* a; long lda; const float* part; int H;
+    const void* W; const float* bias; int N, K, M;
+    float* x; long ldx;
+};
+template <typename T> void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a);
+
+}  // namespace umgen
