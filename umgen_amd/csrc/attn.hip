@@ -136,7 +136,10 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
 }
 
 void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int S_pad, int H) {
-    constexpr int QT = 4;
+#ifndef UMGEN_ATTN_QT
+#define UMGEN_ATTN_QT 2   // QT=4 (204 VGPR + 88 AGPR) miscomputes the 4th query tile on ROCm 7.2 -- see DESIGN.md
+#endif
+    constexpr int QT = UMGEN_ATTN_QT;
     dim3 grid((S + 4 * QT * 16 - 1) / (4 * QT * 16), H, F);
     hipLaunchKernelGGL(attn_spatial_mfma_kernel<QT>, grid, dim3(256), 0, s, qk, vt, y, S, S_pad, H);
 }
