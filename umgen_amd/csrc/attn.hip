@@ -285,78 +285,4 @@ void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int T_, int 
 template void launch_attn_temporal<float>(hipStream_t, const float*, float*, int, int, int, int);
 template void launch_attn_temporal<bf16_t>(hipStream_t, const bf16_t*, bf16_t*, int, int, int, int);
 
-// ---------------------------------------------------------------------------------------------------------
-// few-query attention, partial pass over a slice of the keys (OAR decode step; ego-decoder self/cross attention)
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kMaxChunk = 640;   // keys per split: supports L <= 8*640
-template <typename T>
-__global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ kv_base, long scene_stride,
-                                                           long key_stride, long v_off, int q_per_scene, int H,
-                                                           const int* __restrict__ d_len, int len_add, float* __restrict__ part) {
-    __shared__ float sq[kHeadDim];
-    __shared__ float sp[kMaxChunk];
-    __shared__ float red[8];
-    __shared__ float so[5][kHeadDim];
-    const int h = blockIdx.x, split = blockIdx.y, qi = blockIdx.z;
-    const int E = H * kHeadDim;
-    const int L = (d_len ? *d_len : 0) + len_add;
-    const int chunk = (L + kAttnSplit - 1) / kAttnSplit;
-    const int k0 = split * chunk, k1 = min(L, k0 + chunk);
-    float* out = part + (((long)qi * H + h) * kAttnSplit + split) * kAttnPart;
-    const int tid = threadIdx.x;
-    if (k0 >= k1) {
-        if (tid < kAttnPart) out[tid] = (tid == 0) ? -INFINITY : 0.f;
-        return;
-    }
-    if (tid < kHeadDim) sq[tid] = q[(long)qi * E + h * kHeadDim + tid];
-    __syncthreads();
-    const T* base = kv_base + (long)(qi / q_per_scene) * scene_stride + h * kHeadDim;
-    float mx = -INFINITY;
-    for (int k = k0 + tid; k < k1; k += 256) {
-        const T* kp = base + (long)k * key_stride;
-        float a = 0.f;
-#pragma unroll
-        for (int d = 0; d < kHeadDim; d += 4) {
-            float t4[4];
-            load4(kp + d, t4);
-            a = fmaf(sq[d], t4[0], a); a = fmaf(sq[d + 1], t4[1], a); a = fmaf(sq[d + 2], t4[2], a); a = fmaf(sq[d + 3], t4[3], a);
-        }
-        a *= kScale;
-        sp[k - k0] = a;
-        mx = fmaxf(mx, a);
-    }
-    mx = wave_max(mx);
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float ls = 0.f;
-    for (int k = k0 + tid; k < k1; k += 256) {
-        const float p = expf(sp[k - k0] - mx);
-        sp[k - k0] = p;
-        ls += p;
-    }
-    ls = wave_sum(ls);
-    if ((tid & 63) == 0) red[4 + (tid >> 6)] = ls;
-    __syncthreads();
-    const float lsum = (red[4] + red[5]) + (red[6] + red[7]);
-    const int d = tid % kHeadDim, grp = tid / kHeadDim;
-    if (grp < 5) {
-        float a = 0.f;
-        for (int k = k0 + grp; k < k1; k += 5) a = fmaf(sp[k - k0], Cvt<T>::to_f(base[(long)k * key_stride + v_off + d]), a);
-        so[grp][d] = a;
-    }
-    __syncthreads();
-    if (tid < kHeadDim) out[2 + tid] = (((so[0][tid] + so[1][tid]) + so[2][tid]) + so[3][tid]) + so[4][tid];
-    if (tid == 0) { out[0] = mx; out[1] = lsum; }
-}
-
-template <typename T>
-void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long key_stride, long v_off, int NQ,
-                         int q_per_scene, int H, const int* d_len, int len_add, float* part) {
-    hipLaunchKernelGGL(attn_partial_kernel<T>, dim3(H, kAttnSplit, NQ), dim3(256), 0, s, q, kv_base, scene_stride, key_stride, v_off,
-                       q_per_scene, H, d_len, len_add, part);
-}
-template void launch_attn_partial<float>(hipStream_t, const float*, const float*, long, long, long, int, int, int, const int*, int, float*);
-template void launch_attn_partial<bf16_t>(hipStream_t, const float*, const bf16_t*, long, long, long, int, int, int, const int*, int, float*);
-
 }  // namespace umgen

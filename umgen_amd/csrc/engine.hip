@@ -75,6 +75,8 @@ struct umgen_engine {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     umgen_timings tm{};
     bool profiling = false;
+    hipGraphExec_t step_graph[4] = {nullptr, nullptr, nullptr, nullptr};   // decode step per kind: fixed / map / bbox3d / image
+    int step_graph_B = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev;
     size_t gemm_ev_used = 0;
     double gemm_flops_pending = 0;
@@ -306,9 +308,9 @@ void gemv(umgen_engine* e, const float* x, long ldx, const float* ln_w, const vo
 }
 template <typename T>
 void gemv_resid(umgen_engine* e, const float* a_in, long lda, const float* part, const void* W, const float* bias, int N, int K, int M,
-                float* x, long ldx) {
+                float* x, long ldx, const int* d_len = nullptr, int len_add = 0) {
     GemvResidArgs a{};
-    a.a = a_in; a.lda = lda; a.part = part; a.H = e->H; a.W = W; a.bias = bias; a.N = N; a.K = K; a.M = M; a.x = x; a.ldx = ldx;
+    a.a = a_in; a.lda = lda; a.part = part; a.H = e->H; a.d_len = d_len; a.len_add = len_add; a.W = W; a.bias = bias; a.N = N; a.K = K; a.M = M; a.x = x; a.ldx = ldx;
     launch_gemv_resid<T>(e->stream, a);
 }
 
@@ -332,13 +334,13 @@ void run_ego(umgen_engine* e, const WindowTokens& w, const SamplerParams& sp, in
         // self-attention among the 3 ego queries of a scene (non-causal); q rows gathered out of the packed q|k|v rows
         hipMemcpy2DAsync(e->qdec, (size_t)E * 4, e->qkv3, (size_t)3 * E * 4, (size_t)E * 4, M, hipMemcpyDeviceToDevice, e->stream);
         launch_attn_partial<float>(e->stream, e->qdec, e->qkv3 + E, 3L * 3 * E, 3L * E, E, M, 3, H, nullptr, 3, e->part);
-        gemv_resid<T>(e, nullptr, 0, e->part, d.self.Wo, d.self.bo, E, E, M, x, E);
+        gemv_resid<T>(e, nullptr, 0, e->part, d.self.Wo, d.self.bo, E, E, M, x, E, nullptr, 3);
         // cross attention to the frame's 2207 scene tokens (FlashCrossAttention.forward, module.py:482-509)
         gemv<T>(e, x, E, d.ln2, d.Wq, d.bq, E, E, M, GEMV_OUT_F32, e->qdec, E);
         launch_layernorm<T>(e->stream, e->pego, E, (long)B * kSeq, E, d.ln3, PN);
         linear_store<T>(e, d.Wkv, d.bkv, 2 * E, E, PN, (long)B * kSeq, KV, 2L * E, 0);
         launch_attn_partial<T>(e->stream, e->qdec, KV, (long)kSeq * 2 * E, 2L * E, E, M, 3, H, nullptr, kSeq, e->part);
-        gemv_resid<T>(e, nullptr, 0, e->part, d.Wco, d.bco, E, E, M, x, E);
+        gemv_resid<T>(e, nullptr, 0, e->part, d.Wco, d.bco, E, E, M, x, E, nullptr, kSeq);
         gemv<T>(e, x, E, d.ln4, d.mlp.Wfc, nullptr, 4 * E, E, M, GEMV_OUT_GELU, e->hdec, 4L * E);
         gemv_resid<T>(e, e->hdec, 4L * E, nullptr, d.mlp.Wproj, nullptr, E, 4 * E, M, x, E);
     }
@@ -360,11 +362,10 @@ void oar_layers(umgen_engine* e, int B) {
         a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len; a.E = E;
         launch_gemv<T>(e->stream, a);
         launch_attn_partial<T>(e->stream, e->qdec, cache, e->kv_scene_stride, 2L * E, E, B, 1, H, d_len, 1, e->part);
-        gemv_resid<T>(e, nullptr, 0, e->part, w.attn.Wo, w.attn.bo, E, E, B, e->xdec, E);
+        gemv_resid<T>(e, nullptr, 0, e->part, w.attn.Wo, w.attn.bo, E, E, B, e->xdec, E, d_len, 1);
         gemv<T>(e, e->xdec, E, w.ln_b, w.mlp.Wfc, nullptr, 4 * E, E, B, GEMV_OUT_GELU, e->hdec, 4L * E);
         gemv_resid<T>(e, e->hdec, 4L * E, nullptr, w.mlp.Wproj, nullptr, E, 4 * E, B, e->xdec, E);
     }
-    e->tm.oar_kernels += 5 * (int64_t)e->oar.size();
 }
 
 struct FrameIO {
@@ -377,6 +378,40 @@ struct FrameIO {
     const umgen_trace* trace;                    // B == 1 only
     int* out_tokens;                             // host [B][2199]
 };
+
+// kernels of one decode step of kind mod (0 fixed token, 1 map, 2 bbox3d, 3 image) for B scenes
+template <typename T>
+int enqueue_step(umgen_engine* e, int B, int mod, const umgen_trace* tr, int j) {
+    const int E = e->E;
+    hipStream_t st = e->stream;
+    oar_layers<T>(e, B);
+    SampleArgs sa{};
+    sa.st = e->d_state; sa.tb = e->tb; sa.logits = e->logits; sa.logits_tar = e->logits_tar; sa.ld_logits = 8192;
+    sa.cond = e->cond; sa.x_next = e->xdec; sa.tokens = e->d_tokens; sa.prev_box = e->d_prev_box; sa.control_slot = e->d_control;
+    sa.boxes = e->d_boxes; sa.n_boxes = e->d_nboxes; sa.seeds = e->d_seeds; sa.forced = e->d_forced; sa.counters = e->d_counters;
+    if (mod == 0) {
+        launch_fixed_token(st, sa, B);
+    } else {
+        const void* head = mod == 1 ? e->head_ar_map : (mod == 2 ? e->head_ar_box : e->head_ar_img);
+        const int V = mod == 1 ? e->cfg.map_vocab : (mod == 2 ? e->cfg.bbox3d_vocab : e->cfg.img_vocab);
+        gemv<T>(e, e->xdec, E, e->ln_oar, head, nullptr, V, E, B, GEMV_OUT_F32, e->logits, sa.ld_logits);
+        if (mod == 2) {   // head_tar_bbox3d on the conditioning row of this position (UMGen.py:1087,1103)
+            GemvArgs a{};
+            a.x = e->cond; a.ldx = (long)kSeq * E; a.d_xoff = &e->d_state->step; a.xoff_mul = E; a.W = e->head_tar_box;
+            a.N = V; a.K = E; a.M = B; a.out_mode = GEMV_OUT_F32; a.out = e->logits_tar; a.ldo = sa.ld_logits; a.E = E;
+            launch_gemv<T>(st, a);
+        }
+        if (tr) {
+            float* dst = mod == 1 ? tr->logits_map : (mod == 2 ? tr->logits_bbox3d : tr->logits_image);
+            const int k = mod == 1 ? j - kMapC0 : (mod == 2 ? j - kBoxC0 : j - kImgC0);
+            if (dst) HIPCHK(e, hipMemcpyAsync(dst + (size_t)k * V, e->logits, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+        }
+        sa.mod = mod;
+        sa.vocab = V;
+        launch_sample_token(st, sa, B);
+    }
+    return 0;
+}
 
 // UMGen._inference (UMGen.py:1406-1540) for B scenes
 template <typename T>
@@ -440,7 +475,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     HIPCHK(e, hipMemcpyAsync(e->d_tokens, tok0.data(), tok0.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->d_prev_box, prevbox.data(), prevbox.size() * 4, hipMemcpyHostToDevice, st));
     if (io.control_slot) HIPCHK(e, hipMemcpyAsync(e->d_control, io.control_slot, (size_t)B * kSlots, hipMemcpyHostToDevice, st));
-    OarState s0{0, io.frame_idx};
+    OarState s0{0, io.frame_idx, forced ? 1 : 0, io.control_slot ? 1 : 0, 0, sp};
     HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
 
     // Step 2: the three TAR stacks (UMGen.py:1484-1494) and the conditioning rows (1496-1511)
@@ -456,42 +491,30 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
 
     // Step 3: OAR decode loop (infer_oar_net, UMGen.py:1151-1273).  Step j consumes scene position j (KV length j) and
     // emits scene token j; j = 0..4 replays the given pose prefix, bos/eos are fixed, everything else is sampled.
+    // A step is a fixed kernel sequence with fixed arguments (all per-step state is device resident), replayed from a
+    // hipGraph per step kind; trace mode launches directly so the logits can be copied out between kernels.
     launch_first_input(st, B, E, e->tb.tske + (long)e->cfg.task_id * E, e->cond, e->xdec);
-    SampleArgs sa{};
-    sa.st = e->d_state; sa.sp = sp; sa.tb = e->tb; sa.logits = e->logits; sa.logits_tar = e->logits_tar; sa.ld_logits = 8192;
-    sa.cond = e->cond; sa.x_next = e->xdec; sa.tokens = e->d_tokens; sa.prev_box = e->d_prev_box;
-    sa.control_slot = io.control_slot ? e->d_control : nullptr; sa.boxes = e->d_boxes; sa.n_boxes = e->d_nboxes; sa.seeds = e->d_seeds;
-    sa.forced = forced ? e->d_forced : nullptr; sa.counters = e->d_counters;
+    const bool graphs = e->cfg.use_graphs && !tr;
+    if (graphs && e->step_graph_B != B) {
+        for (int kind = 0; kind < 4; ++kind) {
+            if (e->step_graph[kind]) { hipGraphExecDestroy(e->step_graph[kind]); e->step_graph[kind] = nullptr; }
+            hipGraph_t g;
+            HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            enqueue_step<T>(e, B, kind, nullptr, 0);
+            HIPCHK(e, hipStreamEndCapture(st, &g));
+            HIPCHK(e, hipGraphInstantiate(&e->step_graph[kind], g, nullptr, nullptr, 0));
+            HIPCHK(e, hipGraphDestroy(g));
+        }
+        e->step_graph_B = B;
+    }
     for (int j = 0; j < kImgEos; ++j) {   // the img-eos step (j = 2206) produces nothing that is consumed
-        oar_layers<T>(e, B);
         int mod = 0;
         if (j >= kMapC0 && j < kMapEos) mod = 1;
         else if (j >= kBoxC0 && j < kBoxEos) mod = 2;
         else if (j >= kImgC0 && j < kImgEos) mod = 3;
-        if (mod == 0) {
-            launch_fixed_token(st, sa, B);
-        } else {
-            const void* head = mod == 1 ? e->head_ar_map : (mod == 2 ? e->head_ar_box : e->head_ar_img);
-            const int V = mod == 1 ? e->cfg.map_vocab : (mod == 2 ? e->cfg.bbox3d_vocab : e->cfg.img_vocab);
-            gemv<T>(e, e->xdec, E, e->ln_oar, head, nullptr, V, E, B, GEMV_OUT_F32, e->logits, sa.ld_logits);
-            if (mod == 2) {   // head_tar_bbox3d on the conditioning row of this position (UMGen.py:1087,1103)
-                GemvArgs a{};
-                a.x = e->cond; a.ldx = (long)kSeq * E; a.d_xoff = &e->d_state->step; a.xoff_mul = E; a.W = e->head_tar_box;
-                a.N = V; a.K = E; a.M = B; a.out_mode = GEMV_OUT_F32; a.out = e->logits_tar; a.ldo = sa.ld_logits; a.E = E;
-                launch_gemv<T>(st, a);
-            }
-            if (tr) {
-                float* dst = mod == 1 ? tr->logits_map : (mod == 2 ? tr->logits_bbox3d : tr->logits_image);
-                const int k = mod == 1 ? j - kMapC0 : (mod == 2 ? j - kBoxC0 : j - kImgC0);
-                if (dst) HIPCHK(e, hipMemcpyAsync(dst + (size_t)k * V, e->logits, (size_t)V * 4, hipMemcpyDeviceToHost, st));
-            }
-            sa.mod = mod;
-            sa.vocab = V;
-            launch_sample_token(st, sa, B);
-            e->tm.oar_kernels += (mod == 2) ? 3 : 2;
-        }
-        launch_advance(st, e->d_state);
-        e->tm.oar_kernels += 1;
+        if (graphs) HIPCHK(e, hipGraphLaunch(e->step_graph[mod], st));
+        else if (int rc = enqueue_step<T>(e, B, mod, tr, j)) return rc;
+        e->tm.oar_kernels += 5 * (int64_t)e->oar.size() + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
     }
     e->tm.oar_steps += kImgEos;
     HIPCHK(e, hipEventRecord(e->ev[3], st));
@@ -927,6 +950,7 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
 int umgen_destroy(umgen_engine* e) {
     if (!e) return UMGEN_OK;
     if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto& g : e->step_graph) if (g) hipGraphExecDestroy(g);
     for (void* p : e->allocs) hipFree(p);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : e->gemm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }

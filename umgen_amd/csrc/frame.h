@@ -32,22 +32,26 @@ struct WindowTokens {
     int B, T;
 };
 
-// state of the OAR decode loop (device resident so a step can be replayed from a hipGraph)
-struct OarState {
-    int step;        // input position j of the current step == KV length before the step
-    int frame_idx;
-};
-
 struct SamplerParams {
     int method, top_k, top_k_map, topk_image;
     float p, p_map, temperature;
     int rule_constrain, merge_ar_tar, only_ar;
 };
 
+// state of the OAR decode loop: device resident, so that one decode step is a fixed kernel sequence with fixed
+// arguments and can be replayed from a hipGraph (everything that changes between steps / frames / calls lives here)
+struct OarState {
+    int step;        // input position j of the current step == KV length before the step
+    int frame_idx;
+    int use_forced;  // teacher forcing: take tokens from SampleArgs::forced
+    int use_control; // control_test: SampleArgs::control_slot is valid
+    int done;        // blocks of the step's last kernel that have finished (the last one advances `step`)
+    SamplerParams sp;
+};
+
 // everything the per-token sampler kernel touches
 struct SampleArgs {
-    const OarState* st;
-    SamplerParams sp;
+    OarState* st;
     EmbedTables tb;
     const float* logits;       // [B][ld_logits] current AR head
     const float* logits_tar;   // [B][ld_logits] head_tar_bbox3d on the conditioning row (bbox3d steps only)
@@ -58,11 +62,11 @@ struct SampleArgs {
     float* x_next;             // [B][E] input of the next step
     int* tokens;               // [B][2199] tokens of the frame being generated
     const int* prev_box;       // [B][660] bbox3d tokens of the last history frame (after control overwrite)
-    const unsigned char* control_slot;   // [B][60] or nullptr
+    const unsigned char* control_slot;   // [B][60] (valid when st->use_control)
     double* boxes;             // [B][64][10] decoded boxes of this frame (rule constraint), boxes[b][0] = ego
     int* n_boxes;              // [B]
     const unsigned long long* seeds;   // [B]
-    const int* forced;         // [B][2199] teacher forcing or nullptr
+    const int* forced;         // [B][2199] teacher forcing (valid when st->use_forced)
     int* counters;             // [8] debug counters (pad_avoid, control, rule_checked, rule_collision, rule_blanked)
 };
 
@@ -77,7 +81,6 @@ void launch_cond_rows(hipStream_t s, int stack, int B, int T, int E, const float
 void launch_first_input(hipStream_t s, int B, int E, const float* tske_row, const float* cond, float* x);
 void launch_fixed_token(hipStream_t s, const SampleArgs& a, int B);             // bos/eos/pose prefix steps
 void launch_sample_token(hipStream_t s, const SampleArgs& a, int B);            // sampled steps
-void launch_advance(hipStream_t s, OarState* st);
 // ego head: sample 3 pose tokens per scene from logits [B*3][vocab]
 void launch_sample_ego(hipStream_t s, const float* logits, int vocab, SamplerParams sp, const unsigned long long* seeds, int frame_idx,
                        const int* forced, int* out_tokens, int B);

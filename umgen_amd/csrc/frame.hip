@@ -189,8 +189,14 @@ void launch_ego_queries(hipStream_t s, const EmbedTables& tb, int B, int T, floa
     hipLaunchKernelGGL(ego_queries_kernel, dim3(B * 3), dim3(256), 0, s, tb, T, x);
 }
 
-__global__ void advance_kernel(OarState* st) { st->step += 1; }
-void launch_advance(hipStream_t s, OarState* st) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, st); }
+// Last kernel of a decode step: every block has read st->step before it arrives here; the last block to arrive advances it.
+__device__ inline void finish_step(OarState* st) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(&st->done, 1);
+        if (t == (int)gridDim.x - 1) { st->done = 0; st->step += 1; }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // sampler: topk (UMGen.py:899-913) + sfmx_temp_sampling (967-974); torch.multinomial is replaced by inverse-CDF
@@ -369,6 +375,7 @@ __global__ __launch_bounds__(256) void fixed_token_kernel(SampleArgs a) {
     const int aux = fixed_aux_id(j);
     if (aux >= 0) write_next_input(a, b, j, a.tb.axe + (long)aux * E, nullptr);
     else write_next_input(a, b, j, nullptr, a.tb.fouier_pe + (long)a.tokens[(long)b * kTokPerFrame + (j - 1)] * E);
+    finish_step(a.st);
 }
 void launch_fixed_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchKernelGGL(fixed_token_kernel, dim3(B), dim3(256), 0, s, a); }
 
@@ -377,11 +384,13 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
     __shared__ float cor[64][8];
     __shared__ int s_tok;
     const int b = blockIdx.x, j = a.st->step, frame = a.st->frame_idx, E = a.tb.E;
+    const SamplerParams sp = a.st->sp;
+    const bool use_forced = a.st->use_forced != 0, use_control = a.st->use_control != 0;
     const int pos1 = j + 1;   // the reference's 1-based curr_seq_len
     const unsigned long long seed = a.seeds[b];
     const float* lg = a.logits + (long)b * a.ld_logits;
-    const int topk = a.mod == 1 ? a.sp.top_k_map : (a.mod == 3 ? a.sp.topk_image : a.sp.top_k);
-    int tok = block_sample_topk(lg, a.vocab, topk, a.sp.temperature, rng_uniform(seed, frame, pos1, DRAW_MAIN), -1, sh);
+    const int topk = a.mod == 1 ? sp.top_k_map : (a.mod == 3 ? sp.topk_image : sp.top_k);
+    int tok = block_sample_topk(lg, a.vocab, topk, sp.temperature, rng_uniform(seed, frame, pos1, DRAW_MAIN), -1, sh);
     int off, k;
     if (a.mod == 1) { off = kOffMap; k = j - kMapC0; }
     else if (a.mod == 2) { off = kOffBox; k = j - kBoxC0; }
@@ -390,18 +399,18 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
     if (a.mod == 2) {
         const float* lt = a.logits_tar + (long)b * a.ld_logits;
         const int prev = a.prev_box[(long)b * kNBox + k];
-        if (a.control_slot) {   // UMGen.py:1083-1089
+        if (use_control) {   // UMGen.py:1083-1089
             const int object_id = (pos1 - 1032) / kSlotLen;
             if (object_id < kSlots && a.control_slot[b * kSlots + object_id]) {
-                tok = block_sample_topk(lt, a.vocab, a.sp.top_k, a.sp.temperature, rng_uniform(seed, frame, pos1, DRAW_CONTROL), a.vocab - 1, sh);
+                tok = block_sample_topk(lt, a.vocab, sp.top_k, sp.temperature, rng_uniform(seed, frame, pos1, DRAW_CONTROL), a.vocab - 1, sh);
                 if (threadIdx.x == 0) atomicAdd(a.counters + 1, 1);
             }
         }
-        if (tok == kBoxPad && a.sp.merge_ar_tar && prev != kBoxPad && !a.sp.only_ar) {   // UMGen.py:1092-1104
-            tok = block_sample_topk(lt, a.vocab, a.sp.top_k, a.sp.temperature, rng_uniform(seed, frame, pos1, DRAW_PAD_AVOID), -1, sh);
+        if (tok == kBoxPad && sp.merge_ar_tar && prev != kBoxPad && !sp.only_ar) {   // UMGen.py:1092-1104
+            tok = block_sample_topk(lt, a.vocab, sp.top_k, sp.temperature, rng_uniform(seed, frame, pos1, DRAW_PAD_AVOID), -1, sh);
             if (threadIdx.x == 0) atomicAdd(a.counters + 0, 1);
         }
-        if (a.sp.rule_constrain && !a.forced && tok != kBoxPad && (pos1 - 1032) % kSlotLen == 0) {   // UMGen.py:1116-1123
+        if (sp.rule_constrain && !use_forced && tok != kBoxPad && (pos1 - 1032) % kSlotLen == 0) {   // UMGen.py:1116-1123
             if (threadIdx.x == 0) {
                 double* boxes = a.boxes + (long)b * 64 * 10;
                 int n = a.n_boxes[b];
@@ -436,10 +445,11 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
             tok = s_tok;
         }
     }
-    if (a.forced) tok = a.forced[(long)b * kTokPerFrame + off + k];
+    if (use_forced) tok = a.forced[(long)b * kTokPerFrame + off + k];
     if (threadIdx.x == 0) toks[off + k] = tok;
     const float* emb = (a.mod == 1) ? a.tb.gmap + (long)tok * E : (a.mod == 3 ? a.tb.gimg + (long)tok * E : a.tb.be + (long)tok * E);
     write_next_input(a, b, j, emb, nullptr);
+    finish_step(a.st);
 }
 void launch_sample_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchKernelGGL(sample_token_kernel, dim3(B), dim3(256), 0, s, a); }
 

@@ -1,177 +1,399 @@
 // Few-row linear layers for the OAR decode step and the ego decoder (M = scenes or 3*scenes rows).
-// These are HBM-bound weight streams: each weight row is read exactly once per launch, 16 B per lane, fp32 accumulate,
-// activations stay fp32 (only the stored weights / KV cache are bf16 in the bf16 precision mode).
 // Replaces F.linear at module.py:206,229 (c_attn, c_proj), 246-248 (MLP) and the heads (UMGen.py:1062,1072,1087,1132)
 // for single-token inputs, with LayerNorm (module.py:34-37), exact GELU and the residual add fused in.
+//
+// These launches are latency-bound weight streams (a decode layer is 14 MB; the whole chip drains that in ~2.5 us), so the
+// kernels are written around the dependency chain, not around bandwidth:
+//   * every weight byte of the launch is requested in the first instructions of each wave (16 B per lane, whole rows held in
+//     registers) -- no loop-carried load->use->load chain, no LDS staging, no barrier on the weight path;
+//   * the activation row(s) live in registers in exactly the k-chunks the lane needs for its dot products; LayerNorm statistics
+//     are wave reductions over those registers (each wave recomputes them: 768 floats, cheaper than a barrier);
+//   * weights stay bf16 in HBM (precision mode bf16) and are widened in-register; activations and accumulation are fp32.
 #include "kernels.h"
 
 namespace umgen {
 
-constexpr int MB = 8;    // activation rows processed per pass
-constexpr int RPW = 2;   // weight rows per wave
+template <typename T> struct WChunk;                      // 8 consecutive weights of one row
+template <> struct WChunk<bf16_t> { uint4 v; };
+template <> struct WChunk<float> { float4 a, b; };
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];   // [MB][K]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ inline void wload(WChunk<bf16_t>& w, const bf16_t* p) { w.v = *reinterpret_cast<const uint4*>(p); }
+__device__ inline void wload(WChunk<float>& w, const float* p) {
+    w.a = *reinterpret_cast<const float4*>(p);
+    w.b = *reinterpret_cast<const float4*>(p + 4);
+}
+__device__ inline void wzero(WChunk<bf16_t>& w) { w.v = make_uint4(0, 0, 0, 0); }
+__device__ inline void wzero(WChunk<float>& w) { w.a = make_float4(0, 0, 0, 0); w.b = w.a; }
+__device__ inline void wunpack(const WChunk<bf16_t>& w, float (&o)[8]) {
+    o[0] = __uint_as_float(w.v.x << 16); o[1] = __uint_as_float(w.v.x & 0xffff0000u);
+    o[2] = __uint_as_float(w.v.y << 16); o[3] = __uint_as_float(w.v.y & 0xffff0000u);
+    o[4] = __uint_as_float(w.v.z << 16); o[5] = __uint_as_float(w.v.z & 0xffff0000u);
+    o[6] = __uint_as_float(w.v.w << 16); o[7] = __uint_as_float(w.v.w & 0xffff0000u);
+}
+__device__ inline void wunpack(const WChunk<float>& w, float (&o)[8]) {
+    o[0] = w.a.x; o[1] = w.a.y; o[2] = w.a.z; o[3] = w.a.w; o[4] = w.b.x; o[5] = w.b.y; o[6] = w.b.z; o[7] = w.b.w;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// out[m][n] = LN(x[m]) . W[n] + bias[n]     K = n_embd (<= 1536): NCH = ceil(K / 512) chunks of 8 per lane
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int MB, int NCH, int RPW>
+__global__ __launch_bounds__(256) void gemv_ln_kernel(GemvArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
+    const int n0 = (blockIdx.x * 4 + wave) * RPW;
+    if (n0 >= a.N) return;
+    WChunk<T> w[RPW][NCH];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const T* wr = W + (long)min(n0 + r, a.N - 1) * K;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < K) wload(w[r][i], wr + c); else wzero(w[r][i]);
+        }
+    }
+    float bias[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) bias[r] = (a.bias && n0 + r < a.N) ? a.bias[n0 + r] : 0.f;
     const int pos = a.d_len ? *a.d_len : 0;
     const float* xbase = a.x + (a.d_xoff ? (long)(*a.d_xoff) * a.xoff_mul : 0L);
+    float lw[NCH][8];
+    if (a.ln_w) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < K) load8(a.ln_w + c, lw[i]);
+        }
+    }
     for (int m0 = 0; m0 < a.M; m0 += MB) {
-        const int mc = min(MB, a.M - m0);
-        __syncthreads();
-        // stage (and LayerNorm) the activation rows: one wave per row
-        for (int m = wave; m < mc; m += 4) {
-            const float* xr = xbase + (long)(m0 + m) * a.ldx;
-            float* dst = xs + (long)m * K;
-            if (a.ln_w) {
-                float s = 0.f;
-                for (int c = lane; c < K; c += 64) s += xr[c];
-                const float mean = wave_sum(s) / (float)K;
-                float q = 0.f;
-                for (int c = lane; c < K; c += 64) { const float d = xr[c] - mean; q += d * d; }
-                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
-                for (int c = lane; c < K; c += 64) dst[c] = (xr[c] - mean) * rstd * a.ln_w[c];
-            } else {
-                for (int c = lane; c < K; c += 64) dst[c] = xr[c];
+        float xv[MB][NCH][8];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float* xr = xbase + (long)min(m0 + m, a.M - 1) * a.ldx;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane * 8 + 512 * i;
+                if (c < K) load8(xr + c, xv[m][i]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[m][i][e] = 0.f;
+                }
             }
         }
-        __syncthreads();
-        const int n0 = (blockIdx.x * 4 + wave) * RPW;
-#pragma unroll 1
-        for (int r = 0; r < RPW; ++r) {
-            const int n = n0 + r;
-            if (n >= a.N) break;
-            float acc[MB];
+        if (a.ln_w) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[m] = 0.f;
-            const T* wr = W + (long)n * K;
-            for (int c = lane * 8; c < K; c += 512) {
-                float w8[8];
-                load8(wr + c, w8);
+            for (int m = 0; m < MB; ++m) {
+                float s = 0.f;
 #pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    if (m < mc) {
-                        float x8[8];
-                        load8(xs + (long)m * K + c, x8);
+                for (int i = 0; i < NCH; ++i)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[m] = fmaf(w8[e], x8[e], acc[m]);
+                    for (int e = 0; e < 8; ++e) s += xv[m][i][e];
+                const float mean = wave_sum(s) / (float)K;
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    if (lane * 8 + 512 * i < K) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float d = xv[m][i][e] - mean; q += d * d; }
+                    }
+                }
+                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    if (lane * 8 + 512 * i < K) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xv[m][i][e] = (xv[m][i][e] - mean) * rstd * lw[i][e];
                     }
                 }
             }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            float acc[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                float w8[8];
+                wunpack(w[r][i], w8);
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[m] = fmaf(w8[e], xv[m][i][e], acc[m]);
+            }
 #pragma unroll
             for (int m = 0; m < MB; ++m) acc[m] = wave_sum(acc[m]);
-            if (lane == 0) {
-                const float b = a.bias ? a.bias[n] : 0.f;
-                for (int m = 0; m < mc; ++m) {
-                    const float v = acc[m] + b;
+            const int n = n0 + r;
+            if (lane == 0 && n < a.N) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
                     const int mm = m0 + m;
-                    if (a.out_mode == GEMV_OUT_QKV) {
-                        if (n < a.E) a.out[(long)mm * a.ldo + n] = v;
-                        else reinterpret_cast<T*>(a.cache)[(long)mm * a.scene_stride + (long)pos * 2 * a.E + (n - a.E)] = Cvt<T>::from_f(v);
-                    } else {
-                        a.out[(long)mm * a.ldo + n] = (a.out_mode == GEMV_OUT_GELU) ? gelu_erf(v) : v;
+                    if (mm < a.M) {
+                        const float v = acc[m] + bias[r];
+                        if (a.out_mode == GEMV_OUT_QKV) {
+                            if (n < a.E) a.out[(long)mm * a.ldo + n] = v;
+                            else reinterpret_cast<T*>(a.cache)[(long)mm * a.scene_stride + (long)pos * 2 * a.E + (n - a.E)] = Cvt<T>::from_f(v);
+                        } else {
+                            a.out[(long)mm * a.ldo + n] = (a.out_mode == GEMV_OUT_GELU) ? gelu_erf(v) : v;
+                        }
                     }
                 }
             }
         }
     }
+}
+
+template <typename T, int NCH>
+static void launch_gemv_nch(hipStream_t s, const GemvArgs& a) {
+    constexpr int RPW = 2;
+    const int grid = (a.N + 4 * RPW - 1) / (4 * RPW);
+    if (a.M == 1) hipLaunchKernelGGL((gemv_ln_kernel<T, 1, NCH, RPW>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.M == 2) hipLaunchKernelGGL((gemv_ln_kernel<T, 2, NCH, RPW>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemv_ln_kernel<T, 4, NCH, RPW>), dim3(grid), dim3(256), 0, s, a);
 }
 
 template <typename T>
 void launch_gemv(hipStream_t s, const GemvArgs& a) {
-    const int grid = (a.N + 4 * RPW - 1) / (4 * RPW);
-    const size_t shm = (size_t)MB * a.K * sizeof(float);
-    hipLaunchKernelGGL(gemv_kernel<T>, dim3(grid), dim3(256), shm, s, a);
+    if (a.K <= 512) launch_gemv_nch<T, 1>(s, a);
+    else if (a.K <= 1024) launch_gemv_nch<T, 2>(s, a);
+    else launch_gemv_nch<T, 3>(s, a);
 }
 template void launch_gemv<float>(hipStream_t, const GemvArgs&);
 template void launch_gemv<bf16_t>(hipStream_t, const GemvArgs&);
 
-// x[m][n] += (sum_k a[m][k] W[n][k]) + bias[n]
-template <typename T, bool COMBINE>
+// ---------------------------------------------------------------------------------------------------------
+// x[m][n] += (sum_k a[m][k] W[n][k]) + bias[n]    one weight row per wave; K = n_embd or 4 n_embd (NCH chunks)
+// COMBINE: a[m][:] is first merged from the attention partials (K == H*48) into LDS, after the weight loads are in flight
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline int attn_nsplit(int L) { return min(kAttnSplit, (L + kAttnChunk - 1) / kAttnChunk); }
+
+template <typename T, int MB, int NCH, bool COMBINE>
 __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float as[];   // [MB][K] when COMBINE
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) float as[];   // [M][K] when COMBINE
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
+    const int n = blockIdx.x * 4 + wave;
+    const bool active = n < a.N;
+    WChunk<T> w[NCH];
+    {
+        const T* wr = W + (long)min(n, a.N - 1) * K;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < K) wload(w[i], wr + c); else wzero(w[i]);
+        }
+    }
+    const float bias = (a.bias && active) ? a.bias[n] : 0.f;
+    if (COMBINE) {
+        // merge the split-softmax partials (m, l, o[48]) of every (row, head): o = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s
+        const int L = (a.d_len ? *a.d_len : 0) + a.len_add;
+        const int ns = attn_nsplit(L);
+        for (int e = threadIdx.x; e < a.M * K; e += 256) {
+            const int m = e / K, col = e % K;
+            const int h = col / kHeadDim, d = col % kHeadDim;
+            const float* p = a.part + (((long)m * a.H + h) * kAttnSplit) * kAttnPart;
+            float mx = -INFINITY;
+            for (int sp = 0; sp < ns; ++sp) mx = fmaxf(mx, p[sp * kAttnPart]);
+            float l = 0.f, o = 0.f;
+            for (int sp = 0; sp < ns; ++sp) {
+                const float ww = expf(p[sp * kAttnPart] - mx);
+                l = fmaf(ww, p[sp * kAttnPart + 1], l);
+                o = fmaf(ww, p[sp * kAttnPart + 2 + d], o);
+            }
+            as[e] = o / l;
+        }
+        __syncthreads();
+    }
+    if (!active) return;
     for (int m0 = 0; m0 < a.M; m0 += MB) {
-        const int mc = min(MB, a.M - m0);
-        if (COMBINE) {
-            // merge the kAttnSplit partial softmax results of every (row, head):  (m, l, o[48]) -> o / l
-            __syncthreads();
-            for (int e = tid; e < mc * K; e += 256) {
-                const int m = e / K, col = e % K;
-                const int h = col / kHeadDim, d = col % kHeadDim;
-                const float* p = a.part + (((long)(m0 + m) * a.H + h) * kAttnSplit) * kAttnPart;
-                float mx = -INFINITY;
-#pragma unroll
-                for (int sp = 0; sp < kAttnSplit; ++sp) mx = fmaxf(mx, p[sp * kAttnPart]);
-                float l = 0.f, o = 0.f;
-#pragma unroll
-                for (int sp = 0; sp < kAttnSplit; ++sp) {
-                    const float w = expf(p[sp * kAttnPart] - mx);
-                    l = fmaf(w, p[sp * kAttnPart + 1], l);
-                    o = fmaf(w, p[sp * kAttnPart + 2 + d], o);
-                }
-                as[e] = o / l;
-            }
-            __syncthreads();
-        }
-        const int n0 = (blockIdx.x * 4 + wave) * RPW;
-        float acc[RPW][MB];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
-        for (int c = lane * 8; c < K; c += 512) {
-            float w8[RPW][8];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int n = min(n0 + r, a.N - 1);
-                load8(W + (long)n * K + c, w8[r]);
-            }
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                if (m < mc) {
-                    float x8[8];
-                    if (COMBINE) load8(as + (long)m * K + c, x8);
-                    else load8(a.a + (long)(m0 + m) * a.lda + c, x8);
-#pragma unroll
-                    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[r][m] = fmaf(w8[r][e], x8[e], acc[r][m]);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum(acc[r][m]);
+        float xold[MB];
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int n = n0 + r;
-                if (n < a.N) {
-                    const float b = a.bias ? a.bias[n] : 0.f;
-                    for (int m = 0; m < mc; ++m) a.x[(long)(m0 + m) * a.ldx + n] += acc[r][m] + b;
+            for (int m = 0; m < MB; ++m) xold[m] = (m0 + m < a.M) ? a.x[(long)(m0 + m) * a.ldx + n] : 0.f;
+        }
+        float acc[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+        float xv[MB][NCH][8];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int mm = min(m0 + m, a.M - 1);
+            const float* xr = COMBINE ? (as + (long)mm * K) : (a.a + (long)mm * a.lda);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane * 8 + 512 * i;
+                if (c < K) load8(xr + c, xv[m][i]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[m][i][e] = 0.f;
                 }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float w8[8];
+            wunpack(w[i], w8);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[m] = fmaf(w8[e], xv[m][i][e], acc[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[m] = wave_sum(acc[m]);
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                if (m0 + m < a.M) a.x[(long)(m0 + m) * a.ldx + n] = xold[m] + (acc[m] + bias);
         }
     }
 }
 
+template <typename T, int NCH, bool COMBINE>
+static void launch_resid_nch(hipStream_t s, const GemvResidArgs& a) {
+    const int grid = (a.N + 3) / 4;
+    const size_t shm = COMBINE ? (size_t)a.M * a.K * sizeof(float) : 0;
+    constexpr int MBmax = (NCH <= 3) ? 4 : (NCH <= 6 ? 2 : 1);
+    if (a.M == 1 || MBmax == 1) hipLaunchKernelGGL((gemv_resid_kernel<T, 1, NCH, COMBINE>), dim3(grid), dim3(256), shm, s, a);
+    else if (a.M == 2 || MBmax == 2) hipLaunchKernelGGL((gemv_resid_kernel<T, (MBmax >= 2 ? 2 : 1), NCH, COMBINE>), dim3(grid), dim3(256), shm, s, a);
+    else hipLaunchKernelGGL((gemv_resid_kernel<T, MBmax, NCH, COMBINE>), dim3(grid), dim3(256), shm, s, a);
+}
+
 template <typename T>
-void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a) {
-    const int grid = (a.N + 4 * RPW - 1) / (4 * RPW);
+void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a0) {
+    GemvResidArgs a = a0;
+    const int nch = (a.K + 511) / 512;
+    if (a.part && a.M > 8) {   // the merged attention rows are staged in LDS: at most 8 rows per launch
+        for (int m = 0; m < a0.M; m += 8) {
+            GemvResidArgs b = a0;
+            b.M = min(8, a0.M - m);
+            b.part = a0.part + (long)m * a0.H * kAttnSplit * kAttnPart;
+            b.x = a0.x + (long)m * a0.ldx;
+            launch_gemv_resid<T>(s, b);
+        }
+        return;
+    }
     if (a.part) {
-        const size_t shm = (size_t)MB * a.K * sizeof(float);
-        hipLaunchKernelGGL((gemv_resid_kernel<T, true>), dim3(grid), dim3(256), shm, s, a);
+        if (nch <= 1) launch_resid_nch<T, 1, true>(s, a);
+        else if (nch <= 2) launch_resid_nch<T, 2, true>(s, a);
+        else launch_resid_nch<T, 3, true>(s, a);
     } else {
-        hipLaunchKernelGGL((gemv_resid_kernel<T, false>), dim3(grid), dim3(256), 0, s, a);
+        if (nch <= 1) launch_resid_nch<T, 1, false>(s, a);
+        else if (nch <= 2) launch_resid_nch<T, 2, false>(s, a);
+        else if (nch <= 3) launch_resid_nch<T, 3, false>(s, a);
+        else if (nch <= 6) launch_resid_nch<T, 6, false>(s, a);
+        else launch_resid_nch<T, 12, false>(s, a);
     }
 }
 template void launch_gemv_resid<float>(hipStream_t, const GemvResidArgs&);
 template void launch_gemv_resid<bf16_t>(hipStream_t, const GemvResidArgs&);
+
+// ---------------------------------------------------------------------------------------------------------
+// few-query attention, partial pass over one slice of <= kAttnChunk keys (OAR decode step; ego-decoder self/cross attention).
+// 8 lanes own one key: lane piece p < 6 holds the 8 head-dim values [8p, 8p+8) of BOTH the K row and the V row of its keys,
+// all requested up front (16 B per lane per row); scores are 8-lane shuffle sums, the softmax statistics and the P.V
+// accumulation are wave shuffles + one LDS exchange across the 4 waves.  Only ceil(L / kAttnChunk) splits do work.
+// ---------------------------------------------------------------------------------------------------------
+constexpr float kScale = 0.14433756729740643f;   // float32(1/sqrt(48)), module.py:196-198
+constexpr int kKeyPass = kAttnChunk / 32;        // keys per thread (32 keys per pass of the 256 threads)
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ kv_base, long scene_stride,
+                                                           long key_stride, long v_off, int q_per_scene, int H,
+                                                           const int* __restrict__ d_len, int len_add, float* __restrict__ part) {
+    __shared__ float s_max[4];
+    __shared__ float s_sum[4];
+    __shared__ float s_o[4][kHeadDim];
+    const int h = blockIdx.x, split = blockIdx.y, qi = blockIdx.z;
+    const int E = H * kHeadDim;
+    const int L = (d_len ? *d_len : 0) + len_add;
+    const int ns = attn_nsplit(L);
+    if (split >= ns) return;
+    const int chunk = (L + ns - 1) / ns;             // <= kAttnChunk
+    const int k0 = split * chunk, k1 = min(L, k0 + chunk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int piece = tid & 7, kg = tid >> 3;        // 32 key groups
+    const bool pact = piece < 6;
+    const T* base = kv_base + (long)(qi / q_per_scene) * scene_stride + h * kHeadDim + piece * 8;
+    float kf[kKeyPass][8], vf[kKeyPass][8];
+#pragma unroll
+    for (int i = 0; i < kKeyPass; ++i) {
+        const int k = k0 + kg + 32 * i;
+        if (pact && k < k1) {
+            load8(base + (long)k * key_stride, kf[i]);
+            load8(base + (long)k * key_stride + v_off, vf[i]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[i][e] = 0.f; vf[i][e] = 0.f; }
+        }
+    }
+    float q8[8];
+    if (pact) load8(q + (long)qi * E + h * kHeadDim + piece * 8, q8);
+    else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q8[e] = 0.f;
+    }
+    float sc[kKeyPass];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kKeyPass; ++i) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(q8[e], kf[i][e], d);
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        d += __shfl_xor(d, 4);
+        d = (k0 + kg + 32 * i < k1) ? d * kScale : -INFINITY;
+        sc[i] = d;
+        mx = fmaxf(mx, d);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 8));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    float ls = 0.f;
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kKeyPass; ++i) {
+        const float p = expf(sc[i] - mx);   // exp(-inf) = 0 for keys past the slice
+        ls += p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = fmaf(p, vf[i][e], o8[e]);
+    }
+    // reduce over the 8 key groups of the wave (lanes with equal piece): xor 8, 16, 32
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o8[e] += __shfl_xor(o8[e], 8);
+        o8[e] += __shfl_xor(o8[e], 16);
+        o8[e] += __shfl_xor(o8[e], 32);
+    }
+    ls += __shfl_xor(ls, 8);
+    ls += __shfl_xor(ls, 16);
+    ls += __shfl_xor(ls, 32);
+    if (lane < 6) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_o[wave][lane * 8 + e] = o8[e];
+    }
+    if (lane == 0) s_sum[wave] = ls;
+    __syncthreads();
+    float* out = part + (((long)qi * H + h) * kAttnSplit + split) * kAttnPart;
+    if (tid < kHeadDim) out[2 + tid] = ((s_o[0][tid] + s_o[1][tid]) + s_o[2][tid]) + s_o[3][tid];
+    if (tid == 0) { out[0] = mx; out[1] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3]; }
+}
+
+template <typename T>
+void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long key_stride, long v_off, int NQ,
+                         int q_per_scene, int H, const int* d_len, int len_add, float* part) {
+    hipLaunchKernelGGL(attn_partial_kernel<T>, dim3(H, kAttnSplit, NQ), dim3(256), 0, s, q, kv_base, scene_stride, key_stride, v_off,
+                       q_per_scene, H, d_len, len_add, part);
+}
+template void launch_attn_partial<float>(hipStream_t, const float*, const float*, long, long, long, int, int, int, const int*, int, float*);
+template void launch_attn_partial<bf16_t>(hipStream_t, const float*, const bf16_t*, long, long, long, int, int, int, const int*, int, float*);
 
 }  // namespace umgen

@@ -53,6 +53,7 @@ template <typename T> void launch_attn_temporal(hipStream_t s, const T* qkv, T* 
 //   L   = *d_len + len_add  when d_len != nullptr, else len_add;  scene of query qi = qi / q_per_scene
 //   part [NQ][H][NSPLIT][50] = (m, l, o[48])
 constexpr int kAttnSplit = 8;
+constexpr int kAttnChunk = 288;   // keys per split; only ceil(L / kAttnChunk) splits run (L <= 2304)
 constexpr int kAttnPart = 50;
 template <typename T> void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long key_stride,
                                                long v_off, int NQ, int q_per_scene, int H, const int* d_len, int len_add, float* part);
@@ -81,6 +82,7 @@ template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
 // partials (K must equal H*48)
 struct GemvResidArgs {
     const float* a; long lda; const float* part; int H;
+    const int* d_len; int len_add;   // key count of the attention whose partials are merged: L = (d_len ? *d_len : 0) + len_add
     const void* W; const float* bias; int N, K, M;
     float* x; long ldx;
 };
