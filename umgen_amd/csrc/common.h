@@ -39,10 +39,16 @@ template <> struct Cvt<bf16_t> {
     __host__ __device__ static inline bf16_t from_f(float v) { return f32_to_bf16(v); }
 };
 
+// wave64 sum, result broadcast to all lanes.  DPP row shifts / broadcasts (7 VALU ops) instead of six dependent
+// ds_bpermute round trips: on the decode path the reduction latency is a visible fraction of a ~3 us kernel.
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));   // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xe, true));   // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xc, true));   // row_shr:8  -> lane 15 of each row
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, true));   // row_bcast:15
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, true));   // row_bcast:31 -> lane 63
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ inline float wave_max(float v) {
 #pragma unroll

@@ -87,10 +87,10 @@ int umgen_dbg_attn_decode(int bf16, const float* q, const void* kv, int NQ, int 
     for (int i = 0; i < E; ++i) eye[(size_t)i * E + i] = 1.f;
     if (up(dW.p, eye.data(), eye.size() * 4)) return UMGEN_E_HIP;
     (void)hipMemset(dX.p, 0, (size_t)NQ * E * 4);
-    if (bf16) launch_attn_partial<bf16_t>(nullptr, (const float*)dQ.p, (const bf16_t*)dKV.p, 0, 2L * E, E, NQ, NQ, H, nullptr, L, (float*)dP.p);
-    else launch_attn_partial<float>(nullptr, (const float*)dQ.p, (const float*)dKV.p, 0, 2L * E, E, NQ, NQ, H, nullptr, L, (float*)dP.p);
+    if (bf16) launch_attn_partial<bf16_t>(nullptr, (const float*)dQ.p, (const bf16_t*)dKV.p, 0, kHeadDim, 2L * E, E, NQ, NQ, H, nullptr, L, attn_nsplit(L), (float*)dP.p);
+    else launch_attn_partial<float>(nullptr, (const float*)dQ.p, (const float*)dKV.p, 0, kHeadDim, 2L * E, E, NQ, NQ, H, nullptr, L, attn_nsplit(L), (float*)dP.p);
     GemvResidArgs a{};
-    a.part = (const float*)dP.p; a.H = H; a.len_add = L; a.W = dW.p; a.N = E; a.K = E; a.M = NQ; a.x = (float*)dX.p; a.ldx = E;
+    a.part = (const float*)dP.p; a.H = H; a.ns = attn_nsplit(L); a.W = dW.p; a.N = E; a.K = E; a.M = NQ; a.x = (float*)dX.p; a.ldx = E;
     launch_gemv_resid<float>(nullptr, a);
     if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
     return down(y, dX.p, (size_t)NQ * E * 4);

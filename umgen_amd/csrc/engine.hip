@@ -64,7 +64,7 @@ struct umgen_engine {
     float *xdec = nullptr, *qdec = nullptr, *part = nullptr, *hdec = nullptr, *logits = nullptr, *logits_tar = nullptr, *qkv3 = nullptr;
     void* kvcache = nullptr;
     long kv_layer_stride = 0, kv_scene_stride = 0;
-    int Lmax = 2208, S_pad = 2240;
+    int Lmax = kAttnSplit * kAttnChunk, S_pad = 2240;   // cache rows per head: every split's fixed key range is addressable
     int *d_pose = nullptr, *d_pose_shift = nullptr, *d_map = nullptr, *d_box = nullptr, *d_img = nullptr;
     int *d_tokens = nullptr, *d_prev_box = nullptr, *d_forced = nullptr, *d_counters = nullptr, *d_nboxes = nullptr, *d_ego_tok = nullptr;
     unsigned char* d_control = nullptr;
@@ -75,7 +75,8 @@ struct umgen_engine {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     umgen_timings tm{};
     bool profiling = false;
-    hipGraphExec_t step_graph[4] = {nullptr, nullptr, nullptr, nullptr};   // decode step per kind: fixed / map / bbox3d / image
+    // decode step graphs per (kind: fixed / map / bbox3d / image, number of attention key splits 1..8)
+    hipGraphExec_t step_graph[4][kAttnSplit + 1] = {};
     int step_graph_B = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev;
     size_t gemm_ev_used = 0;
@@ -308,9 +309,9 @@ void gemv(umgen_engine* e, const float* x, long ldx, const float* ln_w, const vo
 }
 template <typename T>
 void gemv_resid(umgen_engine* e, const float* a_in, long lda, const float* part, const void* W, const float* bias, int N, int K, int M,
-                float* x, long ldx, const int* d_len = nullptr, int len_add = 0) {
+                float* x, long ldx, int ns = 1) {
     GemvResidArgs a{};
-    a.a = a_in; a.lda = lda; a.part = part; a.H = e->H; a.d_len = d_len; a.len_add = len_add; a.W = W; a.bias = bias; a.N = N; a.K = K; a.M = M; a.x = x; a.ldx = ldx;
+    a.a = a_in; a.lda = lda; a.part = part; a.H = e->H; a.ns = ns; a.W = W; a.bias = bias; a.N = N; a.K = K; a.M = M; a.x = x; a.ldx = ldx;
     launch_gemv_resid<T>(e->stream, a);
 }
 
@@ -333,14 +334,14 @@ void run_ego(umgen_engine* e, const WindowTokens& w, const SamplerParams& sp, in
         gemv<T>(e, x, E, d.ln1, d.self.Wqkv, d.self.bqkv, 3 * E, E, M, GEMV_OUT_F32, e->qkv3, 3L * E);
         // self-attention among the 3 ego queries of a scene (non-causal); q rows gathered out of the packed q|k|v rows
         hipMemcpy2DAsync(e->qdec, (size_t)E * 4, e->qkv3, (size_t)3 * E * 4, (size_t)E * 4, M, hipMemcpyDeviceToDevice, e->stream);
-        launch_attn_partial<float>(e->stream, e->qdec, e->qkv3 + E, 3L * 3 * E, 3L * E, E, M, 3, H, nullptr, 3, e->part);
-        gemv_resid<T>(e, nullptr, 0, e->part, d.self.Wo, d.self.bo, E, E, M, x, E, nullptr, 3);
+        launch_attn_partial<float>(e->stream, e->qdec, e->qkv3 + E, 3L * 3 * E, kHeadDim, 3L * E, E, M, 3, H, nullptr, 3, 1, e->part);
+        gemv_resid<T>(e, nullptr, 0, e->part, d.self.Wo, d.self.bo, E, E, M, x, E, 1);
         // cross attention to the frame's 2207 scene tokens (FlashCrossAttention.forward, module.py:482-509)
         gemv<T>(e, x, E, d.ln2, d.Wq, d.bq, E, E, M, GEMV_OUT_F32, e->qdec, E);
         launch_layernorm<T>(e->stream, e->pego, E, (long)B * kSeq, E, d.ln3, PN);
         linear_store<T>(e, d.Wkv, d.bkv, 2 * E, E, PN, (long)B * kSeq, KV, 2L * E, 0);
-        launch_attn_partial<T>(e->stream, e->qdec, KV, (long)kSeq * 2 * E, 2L * E, E, M, 3, H, nullptr, kSeq, e->part);
-        gemv_resid<T>(e, nullptr, 0, e->part, d.Wco, d.bco, E, E, M, x, E, nullptr, kSeq);
+        launch_attn_partial<T>(e->stream, e->qdec, KV, (long)kSeq * 2 * E, kHeadDim, 2L * E, E, M, 3, H, nullptr, kSeq, attn_nsplit(kSeq), e->part);
+        gemv_resid<T>(e, nullptr, 0, e->part, d.Wco, d.bco, E, E, M, x, E, attn_nsplit(kSeq));
         gemv<T>(e, x, E, d.ln4, d.mlp.Wfc, nullptr, 4 * E, E, M, GEMV_OUT_GELU, e->hdec, 4L * E);
         gemv_resid<T>(e, e->hdec, 4L * E, nullptr, d.mlp.Wproj, nullptr, E, 4 * E, M, x, E);
     }
@@ -351,7 +352,7 @@ void run_ego(umgen_engine* e, const WindowTokens& w, const SamplerParams& sp, in
 
 // one OAR decode step through the 36 BlockOAR layers (module.py:402-416) for the B scenes
 template <typename T>
-void oar_layers(umgen_engine* e, int B) {
+void oar_layers(umgen_engine* e, int B, int ns) {
     const int E = e->E, H = e->H;
     const int* d_len = &e->d_state->step;
     for (size_t li = 0; li < e->oar.size(); ++li) {
@@ -359,10 +360,10 @@ void oar_layers(umgen_engine* e, int B) {
         T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
         GemvArgs a{};
         a.x = e->xdec; a.ldx = E; a.ln_w = w.ln_a; a.W = w.attn.Wqkv; a.bias = w.attn.bqkv; a.N = 3 * E; a.K = E; a.M = B;
-        a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len; a.E = E;
+        a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len; a.Lmax = e->Lmax; a.E = E;
         launch_gemv<T>(e->stream, a);
-        launch_attn_partial<T>(e->stream, e->qdec, cache, e->kv_scene_stride, 2L * E, E, B, 1, H, d_len, 1, e->part);
-        gemv_resid<T>(e, nullptr, 0, e->part, w.attn.Wo, w.attn.bo, E, E, B, e->xdec, E, d_len, 1);
+        launch_attn_partial<T>(e->stream, e->qdec, cache, e->kv_scene_stride, (long)e->Lmax * kHeadDim, kHeadDim, (long)H * e->Lmax * kHeadDim, B, 1, H, d_len, 1, ns, e->part);
+        gemv_resid<T>(e, nullptr, 0, e->part, w.attn.Wo, w.attn.bo, E, E, B, e->xdec, E, ns);
         gemv<T>(e, e->xdec, E, w.ln_b, w.mlp.Wfc, nullptr, 4 * E, E, B, GEMV_OUT_GELU, e->hdec, 4L * E);
         gemv_resid<T>(e, e->hdec, 4L * E, nullptr, w.mlp.Wproj, nullptr, E, 4 * E, B, e->xdec, E);
     }
@@ -381,10 +382,10 @@ struct FrameIO {
 
 // kernels of one decode step of kind mod (0 fixed token, 1 map, 2 bbox3d, 3 image) for B scenes
 template <typename T>
-int enqueue_step(umgen_engine* e, int B, int mod, const umgen_trace* tr, int j) {
+int enqueue_step(umgen_engine* e, int B, int mod, int ns, const umgen_trace* tr, int j) {
     const int E = e->E;
     hipStream_t st = e->stream;
-    oar_layers<T>(e, B);
+    oar_layers<T>(e, B, ns);
     SampleArgs sa{};
     sa.st = e->d_state; sa.tb = e->tb; sa.logits = e->logits; sa.logits_tar = e->logits_tar; sa.ld_logits = 8192;
     sa.cond = e->cond; sa.x_next = e->xdec; sa.tokens = e->d_tokens; sa.prev_box = e->d_prev_box; sa.control_slot = e->d_control;
@@ -496,15 +497,9 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     launch_first_input(st, B, E, e->tb.tske + (long)e->cfg.task_id * E, e->cond, e->xdec);
     const bool graphs = e->cfg.use_graphs && !tr;
     if (graphs && e->step_graph_B != B) {
-        for (int kind = 0; kind < 4; ++kind) {
-            if (e->step_graph[kind]) { hipGraphExecDestroy(e->step_graph[kind]); e->step_graph[kind] = nullptr; }
-            hipGraph_t g;
-            HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            enqueue_step<T>(e, B, kind, nullptr, 0);
-            HIPCHK(e, hipStreamEndCapture(st, &g));
-            HIPCHK(e, hipGraphInstantiate(&e->step_graph[kind], g, nullptr, nullptr, 0));
-            HIPCHK(e, hipGraphDestroy(g));
-        }
+        for (auto& row : e->step_graph)
+            for (auto& g : row)
+                if (g) { hipGraphExecDestroy(g); g = nullptr; }
         e->step_graph_B = B;
     }
     for (int j = 0; j < kImgEos; ++j) {   // the img-eos step (j = 2206) produces nothing that is consumed
@@ -512,8 +507,21 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         if (j >= kMapC0 && j < kMapEos) mod = 1;
         else if (j >= kBoxC0 && j < kBoxEos) mod = 2;
         else if (j >= kImgC0 && j < kImgEos) mod = 3;
-        if (graphs) HIPCHK(e, hipGraphLaunch(e->step_graph[mod], st));
-        else if (int rc = enqueue_step<T>(e, B, mod, tr, j)) return rc;
+        const int ns = attn_nsplit(j + 1);
+        if (graphs) {
+            hipGraphExec_t& ge = e->step_graph[mod][ns];
+            if (!ge) {
+                hipGraph_t g;
+                HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                enqueue_step<T>(e, B, mod, ns, nullptr, 0);
+                HIPCHK(e, hipStreamEndCapture(st, &g));
+                HIPCHK(e, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                HIPCHK(e, hipGraphDestroy(g));
+            }
+            HIPCHK(e, hipGraphLaunch(ge, st));
+        } else if (int rc = enqueue_step<T>(e, B, mod, ns, tr, j)) {
+            return rc;
+        }
         e->tm.oar_kernels += 5 * (int64_t)e->oar.size() + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
     }
     e->tm.oar_steps += kImgEos;
@@ -950,7 +958,9 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
 int umgen_destroy(umgen_engine* e) {
     if (!e) return UMGEN_OK;
     if (e->stream) hipStreamSynchronize(e->stream);
-    for (auto& g : e->step_graph) if (g) hipGraphExecDestroy(g);
+    for (auto& row : e->step_graph)
+        for (auto& g : row)
+            if (g) hipGraphExecDestroy(g);
     for (void* p : e->allocs) hipFree(p);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : e->gemm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }

@@ -134,7 +134,12 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(GemvArgs a) {
                         const float v = acc[m] + bias[r];
                         if (a.out_mode == GEMV_OUT_QKV) {
                             if (n < a.E) a.out[(long)mm * a.ldo + n] = v;
-                            else reinterpret_cast<T*>(a.cache)[(long)mm * a.scene_stride + (long)pos * 2 * a.E + (n - a.E)] = Cvt<T>::from_f(v);
+                            else {
+                                const int c = n - a.E, kvsel = c / a.E, hc = c % a.E;   // kvsel 0 = K, 1 = V
+                                const long H = a.E / kHeadDim;
+                                reinterpret_cast<T*>(a.cache)[(long)mm * a.scene_stride + ((kvsel * H + hc / kHeadDim) * a.Lmax + pos) * kHeadDim +
+                                                              hc % kHeadDim] = Cvt<T>::from_f(v);
+                            }
                         } else {
                             a.out[(long)mm * a.ldo + n] = (a.out_mode == GEMV_OUT_GELU) ? gelu_erf(v) : v;
                         }
@@ -167,7 +172,6 @@ template void launch_gemv<bf16_t>(hipStream_t, const GemvArgs&);
 // x[m][n] += (sum_k a[m][k] W[n][k]) + bias[n]    one weight row per wave; K = n_embd or 4 n_embd (NCH chunks)
 // COMBINE: a[m][:] is first merged from the attention partials (K == H*48) into LDS, after the weight loads are in flight
 // ---------------------------------------------------------------------------------------------------------
-__device__ inline int attn_nsplit(int L) { return min(kAttnSplit, (L + kAttnChunk - 1) / kAttnChunk); }
 
 template <typename T, int MB, int NCH, bool COMBINE>
 __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
@@ -188,20 +192,34 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
     }
     const float bias = (a.bias && active) ? a.bias[n] : 0.f;
     if (COMBINE) {
-        // merge the split-softmax partials (m, l, o[48]) of every (row, head): o = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s
-        const int L = (a.d_len ? *a.d_len : 0) + a.len_add;
-        const int ns = attn_nsplit(L);
+        // merge the split-softmax partials (m, l, o[48]) of every (row, head): o = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s.
+        // Stage A: the (row, head, split) statistics go to LDS; stage B: every output column folds its own weights from LDS
+        // (<= 18 LDS reads) and streams the o_s values with independent loads.
+        float* s_m = as + (long)a.M * K;                      // [M][H][kAttnSplit]
+        float* s_l = s_m + (long)a.M * a.H * kAttnSplit;
+        const int ns = a.ns;
+        for (int e = threadIdx.x; e < a.M * a.H * ns; e += 256) {
+            const int sp = e % ns, mh = e / ns;
+            const float* p = a.part + ((long)mh * kAttnSplit + sp) * kAttnPart;
+            s_m[mh * kAttnSplit + sp] = p[0];
+            s_l[mh * kAttnSplit + sp] = p[1];
+        }
+        __syncthreads();
         for (int e = threadIdx.x; e < a.M * K; e += 256) {
             const int m = e / K, col = e % K;
             const int h = col / kHeadDim, d = col % kHeadDim;
-            const float* p = a.part + (((long)m * a.H + h) * kAttnSplit) * kAttnPart;
-            float mx = -INFINITY;
-            for (int sp = 0; sp < ns; ++sp) mx = fmaxf(mx, p[sp * kAttnPart]);
+            const int mh = m * a.H + h;
+            const float* p = a.part + ((long)mh * kAttnSplit) * kAttnPart + 2 + d;
+            const float* pm = s_m + mh * kAttnSplit;
+            const float* pl = s_l + mh * kAttnSplit;
+            float mx = pm[0];
+            for (int sp = 1; sp < ns; ++sp) mx = fmaxf(mx, pm[sp]);
             float l = 0.f, o = 0.f;
+#pragma unroll 6
             for (int sp = 0; sp < ns; ++sp) {
-                const float ww = expf(p[sp * kAttnPart] - mx);
-                l = fmaf(ww, p[sp * kAttnPart + 1], l);
-                o = fmaf(ww, p[sp * kAttnPart + 2 + d], o);
+                const float ww = expf(pm[sp] - mx);
+                l = fmaf(ww, pl[sp], l);
+                o = fmaf(ww, p[sp * kAttnPart], o);
             }
             as[e] = o / l;
         }
@@ -254,7 +272,7 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
 template <typename T, int NCH, bool COMBINE>
 static void launch_resid_nch(hipStream_t s, const GemvResidArgs& a) {
     const int grid = (a.N + 3) / 4;
-    const size_t shm = COMBINE ? (size_t)a.M * a.K * sizeof(float) : 0;
+    const size_t shm = COMBINE ? ((size_t)a.M * a.K + 2 * (size_t)a.M * a.H * kAttnSplit) * sizeof(float) : 0;
     constexpr int MBmax = (NCH <= 3) ? 4 : (NCH <= 6 ? 2 : 1);
     if (a.M == 1 || MBmax == 1) hipLaunchKernelGGL((gemv_resid_kernel<T, 1, NCH, COMBINE>), dim3(grid), dim3(256), shm, s, a);
     else if (a.M == 2 || MBmax == 2) hipLaunchKernelGGL((gemv_resid_kernel<T, (MBmax >= 2 ? 2 : 1), NCH, COMBINE>), dim3(grid), dim3(256), shm, s, a);
@@ -301,27 +319,25 @@ constexpr int kKeyPass = kAttnChunk / 32;        // keys per thread (32 keys per
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ kv_base, long scene_stride,
-                                                           long key_stride, long v_off, int q_per_scene, int H,
-                                                           const int* __restrict__ d_len, int len_add, float* __restrict__ part) {
+                                                           long head_stride, long key_stride, long v_off, int q_per_scene, int H,
+                                                           const int* __restrict__ d_len, int len_add, int kmax, float* __restrict__ part) {
     __shared__ float s_max[4];
     __shared__ float s_sum[4];
     __shared__ float s_o[4][kHeadDim];
     const int h = blockIdx.x, split = blockIdx.y, qi = blockIdx.z;
     const int E = H * kHeadDim;
-    const int L = (d_len ? *d_len : 0) + len_add;
-    const int ns = attn_nsplit(L);
-    if (split >= ns) return;
-    const int chunk = (L + ns - 1) / ns;             // <= kAttnChunk
-    const int k0 = split * chunk, k1 = min(L, k0 + chunk);
+    // fixed key ranges: the K/V addresses do not depend on the device-side length, so every load below is issued before
+    // *d_len has arrived (rows past L are allocated cache rows; they are masked out of the softmax)
+    const int k0 = split * kAttnChunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int piece = tid & 7, kg = tid >> 3;        // 32 key groups
     const bool pact = piece < 6;
-    const T* base = kv_base + (long)(qi / q_per_scene) * scene_stride + h * kHeadDim + piece * 8;
+    const T* base = kv_base + (long)(qi / q_per_scene) * scene_stride + h * head_stride + piece * 8;
     float kf[kKeyPass][8], vf[kKeyPass][8];
 #pragma unroll
     for (int i = 0; i < kKeyPass; ++i) {
-        const int k = k0 + kg + 32 * i;
-        if (pact && k < k1) {
+        const int k = min(k0 + kg + 32 * i, kmax - 1);
+        if (pact) {
             load8(base + (long)k * key_stride, kf[i]);
             load8(base + (long)k * key_stride + v_off, vf[i]);
         } else {
@@ -335,6 +351,8 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) q8[e] = 0.f;
     }
+    const int L = (d_len ? *d_len : 0) + len_add;
+    const int k1 = min(L, k0 + kAttnChunk);
     float sc[kKeyPass];
     float mx = -INFINITY;
 #pragma unroll
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restri
     for (int e = 0; e < 8; ++e) o8[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < kKeyPass; ++i) {
-        const float p = expf(sc[i] - mx);   // exp(-inf) = 0 for keys past the slice
+        const float p = (k0 + kg + 32 * i < k1) ? expf(sc[i] - mx) : 0.f;   // keys past the slice contribute nothing
         ls += p;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o8[e] = fmaf(p, vf[i][e], o8[e]);
@@ -388,12 +406,14 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restri
 }
 
 template <typename T>
-void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long key_stride, long v_off, int NQ,
-                         int q_per_scene, int H, const int* d_len, int len_add, float* part) {
-    hipLaunchKernelGGL(attn_partial_kernel<T>, dim3(H, kAttnSplit, NQ), dim3(256), 0, s, q, kv_base, scene_stride, key_stride, v_off,
-                       q_per_scene, H, d_len, len_add, part);
+void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long head_stride, long key_stride, long v_off,
+                         int NQ, int q_per_scene, int H, const int* d_len, int len_add, int ns, float* part) {
+    // kmax: rows that exist behind kv_base for one (scene, head): loads are clamped to it, the softmax masks by the true length
+    const int kmax = d_len ? kAttnSplit * kAttnChunk : len_add;
+    hipLaunchKernelGGL(attn_partial_kernel<T>, dim3(H, ns, NQ), dim3(256), 0, s, q, kv_base, scene_stride, head_stride, key_stride,
+                       v_off, q_per_scene, H, d_len, len_add, kmax, part);
 }
-template void launch_attn_partial<float>(hipStream_t, const float*, const float*, long, long, long, int, int, int, const int*, int, float*);
-template void launch_attn_partial<bf16_t>(hipStream_t, const float*, const bf16_t*, long, long, long, int, int, int, const int*, int, float*);
+template void launch_attn_partial<float>(hipStream_t, const float*, const float*, long, long, long, long, int, int, int, const int*, int, int, float*);
+template void launch_attn_partial<bf16_t>(hipStream_t, const float*, const bf16_t*, long, long, long, long, int, int, int, const int*, int, int, float*);
 
 }  // namespace umgen

@@ -49,14 +49,18 @@ template <typename T> void launch_attn_spatial_valu(hipStream_t s, const T* qk, 
 template <typename T> void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int T_, int S, int H);
 
 // few-query attention over a key/value stream (OAR decode, ego decoder): partial pass, NSPLIT splits of the keys.
-//   q   [NQ][E] fp32;  K,V rows of scene sc = kv_base + sc*scene_stride + key*key_stride (+ v_off for V), head h at +h*48
+//   q   [NQ][E] fp32;  K row of (scene sc, head h, key k) = kv_base + sc*scene_stride + h*head_stride + k*key_stride (48 values),
+//   V row at + v_off.  Row-major k|v rows [L][2E]: head_stride 48, key_stride 2E, v_off E.  Decode cache (head-major, so a
+//   split's keys are one contiguous 96 B x n_keys run): [2][H][Lmax][48] -> head_stride Lmax*48, key_stride 48, v_off H*Lmax*48.
 //   L   = *d_len + len_add  when d_len != nullptr, else len_add;  scene of query qi = qi / q_per_scene
 //   part [NQ][H][NSPLIT][50] = (m, l, o[48])
-constexpr int kAttnSplit = 8;
-constexpr int kAttnChunk = 288;   // keys per split; only ceil(L / kAttnChunk) splits run (L <= 2304)
+constexpr int kAttnSplit = 18;
+constexpr int kAttnChunk = 128;   // split s owns keys [128 s, 128 s + 128); the host launches ns = ceil(L / 128) splits (L <= 2304)
+inline int attn_nsplit(int L) { return L <= 0 ? 1 : (L + kAttnChunk - 1) / kAttnChunk; }
 constexpr int kAttnPart = 50;
-template <typename T> void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long key_stride,
-                                               long v_off, int NQ, int q_per_scene, int H, const int* d_len, int len_add, float* part);
+template <typename T> void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long head_stride,
+                                               long key_stride, long v_off, int NQ, int q_per_scene, int H, const int* d_len, int len_add,
+                                               int ns, float* part);
 
 // ------------------------------------------------------------------------------------------------
 // few-row linear layers (decode / ego decoder): weights W [N][K] of type T, activations fp32
@@ -64,7 +68,7 @@ template <typename T> void launch_attn_partial(hipStream_t s, const float* q, co
 enum GemvOut {
     GEMV_OUT_F32 = 0,    // out[m*ldo + n] = v
     GEMV_OUT_GELU = 1,   // out[m*ldo + n] = gelu(v)
-    GEMV_OUT_QKV = 2     // n < E: q[m][n] = v ; else K/V cache of scene m at position *d_len: cache[m*scene_stride + pos*2E + (n-E)]
+    GEMV_OUT_QKV = 2     // n < E: q[m][n] = v ; else K/V cache of scene m (head-major [2][H][Lmax][48]) at position *d_len
 };
 struct GemvArgs {
     const float* x; long ldx;      // [M][K] input rows
@@ -73,7 +77,7 @@ struct GemvArgs {
     const void* W; const float* bias; int N, K, M;
     int out_mode;
     float* out; long ldo;
-    void* cache; long scene_stride; const int* d_len;   // GEMV_OUT_QKV
+    void* cache; long scene_stride; const int* d_len; int Lmax;   // GEMV_OUT_QKV
     int E;
 };
 template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
@@ -82,7 +86,7 @@ template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
 // partials (K must equal H*48)
 struct GemvResidArgs {
     const float* a; long lda; const float* part; int H;
-    const int* d_len; int len_add;   // key count of the attention whose partials are merged: L = (d_len ? *d_len : 0) + len_add
+    int ns;                          // number of attention splits to merge (attn_nsplit of the key count)
     const void* W; const float* bias; int N, K, M;
     float* x; long ldx;
 };
