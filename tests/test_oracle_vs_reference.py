@@ -1,0 +1,47 @@
+"""Build-container only: re-runs the comparison oracle == reference LIVE (a seed that is not in the committed
+fixtures).  Skipped wherever /root/reference is absent (e.g. the GPU box) -- nothing at run time depends on it there."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import refimport  # noqa: E402
+
+from oracle.umgen_oracle import OracleUMGen, check_collision, decode_pose_values  # noqa: E402
+from umgen_amd.config import MOD_ORDER, tiny_config  # noqa: E402
+from umgen_amd.synth import synthetic_scene  # noqa: E402
+from umgen_amd.weights import synthetic_state_dict  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not refimport.reference_available(), reason="reference checkout not present")
+
+
+def test_live_greedy_frame_matches_reference():
+    cfg = tiny_config(n_oar_layer=1).greedy()
+    sd = synthetic_state_dict(cfg, seed=11)
+    model = refimport.build_reference_model(cfg, sd, greedy=True)
+    scene = synthetic_scene(4, n_frames=2)
+    ref = model.inference(new_frames=1, cond_frames=2, pred_task="pose_map_bbox3d_image",
+                          input_cond_tokens={k: torch.from_numpy(v) for k, v in scene.items()}, init_tokens=None,
+                          input_cond_frames=2, control_test=False)
+    out = OracleUMGen(cfg, sd).inference(1, 2, scene, input_cond_frames=2)
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(out[m], ref[m], err_msg=m)
+
+
+def test_pose_decode_and_collision_helpers_match_reference_functions():
+    _, refcfg = refimport.import_reference()
+    mc = refcfg.model_config
+    toks = np.random.default_rng(0).integers(0, 1024, size=(7, 3))
+    ref = mc.ego_norm.unnormalize_ego(mc.ego_tokenlizer.decode(toks.copy()))
+    np.testing.assert_array_equal(decode_pose_values(toks), ref.astype(np.float32))
+    from projects.plugin.misc.misc import BoxOverlap
+    bo = BoxOverlap()
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        n = int(rng.integers(2, 12))
+        boxes = [np.concatenate([rng.uniform(-30, 70, 2), [0], rng.uniform(0.1, 8, 2), [1.5], rng.uniform(-3.14, 3.14, 1), [0, 0, 0]])
+                 for _ in range(n)]
+        assert check_collision(boxes) == bool(bo.check_collision(boxes, fliter=True))
