@@ -96,6 +96,8 @@ def main():
     from umgen_amd.engine import Engine
 
     cfg = {"large": large_config, "tiny": tiny_config, "wide2x": wide2x_config}[args.config]()
+    if os.environ.get("UMGEN_BENCH_OAR_LAYERS"):      # experiment knob (not a bench configuration)
+        cfg.n_oar_layer = int(os.environ["UMGEN_BENCH_OAR_LAYERS"])
     T = min(20, cfg.max_frame_len - 1)
     B = args.batch
     eng = Engine(cfg, precision=args.precision, max_batch=B, max_cond_frames=T, device=local_rank, use_graphs=not args.no_graphs)

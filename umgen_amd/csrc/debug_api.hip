@@ -80,7 +80,7 @@ int umgen_dbg_attn_temporal(int bf16, const void* qkv, int B, int T, int S, int 
 int umgen_dbg_attn_decode(int bf16, const float* q, const void* kv, int NQ, int L, int H, float* y) {
     const int E = H * kHeadDim;
     const size_t es = bf16 ? 2 : 4;
-    DevBuf dQ((size_t)NQ * E * 4), dKV((size_t)L * 2 * E * es), dP((size_t)NQ * H * kAttnSplit * kAttnPart * 4), dW((size_t)E * E * 4), dX((size_t)NQ * E * 4);
+    DevBuf dQ((size_t)NQ * E * 4), dKV((size_t)L * 2 * E * es), dP((size_t)NQ * H * kAttnRec * 4), dW((size_t)E * E * 4), dX((size_t)NQ * E * 4);
     if (!dQ.p || !dKV.p || !dP.p || !dW.p || !dX.p) return UMGEN_E_NOMEM;
     if (up(dQ.p, q, (size_t)NQ * E * 4) || up(dKV.p, kv, (size_t)L * 2 * E * es)) return UMGEN_E_HIP;
     std::vector<float> eye((size_t)E * E, 0.f);

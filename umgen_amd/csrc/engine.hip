@@ -717,7 +717,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (int rc = dalloc(e, &e->xdec, 3 * Bm * E)) return rc;
     if (int rc = dalloc(e, &e->qdec, 3 * Bm * E)) return rc;
     if (int rc = dalloc(e, &e->qkv3, 3 * Bm * 3 * E)) return rc;
-    if (int rc = dalloc(e, &e->part, 3 * Bm * e->H * kAttnSplit * kAttnPart)) return rc;
+    if (int rc = dalloc(e, &e->part, 3 * Bm * e->H * kAttnRec)) return rc;
     if (int rc = dalloc(e, &e->hdec, 3 * Bm * 4 * E)) return rc;
     if (int rc = dalloc(e, &e->logits, 3 * Bm * 8192)) return rc;
     if (int rc = dalloc(e, &e->logits_tar, Bm * 8192)) return rc;

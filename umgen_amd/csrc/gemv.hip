@@ -195,33 +195,68 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
         // merge the split-softmax partials (m, l, o[48]) of every (row, head): o = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s.
         // Stage A: the (row, head, split) statistics go to LDS; stage B: every output column folds its own weights from LDS
         // (<= 18 LDS reads) and streams the o_s values with independent loads.
-        float* s_m = as + (long)a.M * K;                      // [M][H][kAttnSplit]
-        float* s_l = s_m + (long)a.M * a.H * kAttnSplit;
+        float* s_w = as + (long)a.M * K;                      // [M][H][kAttnPad] normalised split weights e^{m_s - M} / L
         const int ns = a.ns;
-        for (int e = threadIdx.x; e < a.M * a.H * ns; e += 256) {
-            const int sp = e % ns, mh = e / ns;
-            const float* p = a.part + ((long)mh * kAttnSplit + sp) * kAttnPart;
-            s_m[mh * kAttnSplit + sp] = p[0];
-            s_l[mh * kAttnSplit + sp] = p[1];
+        const int tid = threadIdx.x;
+        const int n_el = a.M * K;
+        // 1. request the first 768 columns' o_s values (independent of the weights) before anything else
+        float4 ov[3][kAttnPad / 4];
+        auto load_chunk = [&](int base) {
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int e = base + tid + 256 * it;
+                if (e < n_el) {
+                    const int m = e / K, col = e % K;
+                    const float4* po = reinterpret_cast<const float4*>(a.part + (long)(m * a.H + col / kHeadDim) * kAttnRec + 2 * kAttnPad +
+                                                                       (col % kHeadDim) * kAttnPad);
+#pragma unroll
+                    for (int i = 0; i < kAttnPad / 4; ++i) ov[it][i] = (4 * i < ns) ? po[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        load_chunk(0);
+        // 2. one thread per (row, head): softmax-merge weights
+        if (tid < a.M * a.H) {
+            const float* p = a.part + (long)tid * kAttnRec;
+            float pm[kAttnPad], pl[kAttnPad];
+#pragma unroll
+            for (int i = 0; i < kAttnPad / 4; ++i) {
+                const float4 m4 = (4 * i < ns) ? reinterpret_cast<const float4*>(p)[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                const float4 l4 = (4 * i < ns) ? reinterpret_cast<const float4*>(p + kAttnPad)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                pm[4 * i] = m4.x; pm[4 * i + 1] = m4.y; pm[4 * i + 2] = m4.z; pm[4 * i + 3] = m4.w;
+                pl[4 * i] = l4.x; pl[4 * i + 1] = l4.y; pl[4 * i + 2] = l4.z; pl[4 * i + 3] = l4.w;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sp = 0; sp < kAttnPad; ++sp) { if (sp >= ns) pm[sp] = -INFINITY; mx = fmaxf(mx, pm[sp]); }
+            float l = 0.f;
+#pragma unroll
+            for (int sp = 0; sp < kAttnPad; ++sp) { pm[sp] = expf(pm[sp] - mx); l = fmaf(pm[sp], (sp < ns) ? pl[sp] : 0.f, l); }
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int sp = 0; sp < kAttnPad; ++sp) s_w[tid * kAttnPad + sp] = pm[sp] * inv;
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < a.M * K; e += 256) {
-            const int m = e / K, col = e % K;
-            const int h = col / kHeadDim, d = col % kHeadDim;
-            const int mh = m * a.H + h;
-            const float* p = a.part + ((long)mh * kAttnSplit) * kAttnPart + 2 + d;
-            const float* pm = s_m + mh * kAttnSplit;
-            const float* pl = s_l + mh * kAttnSplit;
-            float mx = pm[0];
-            for (int sp = 1; sp < ns; ++sp) mx = fmaxf(mx, pm[sp]);
-            float l = 0.f, o = 0.f;
-#pragma unroll 6
-            for (int sp = 0; sp < ns; ++sp) {
-                const float ww = expf(pm[sp] - mx);
-                l = fmaf(ww, pl[sp], l);
-                o = fmaf(ww, p[sp * kAttnPart], o);
+        // 3. fold, 768 columns at a time
+        for (int base = 0; base < n_el; base += 768) {
+            if (base) load_chunk(base);
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int e = base + tid + 256 * it;
+                if (e < n_el) {
+                    const int m = e / K, col = e % K;
+                    const float* w = s_w + (m * a.H + col / kHeadDim) * kAttnPad;
+                    float o = 0.f;
+#pragma unroll
+                    for (int i = 0; i < kAttnPad / 4; ++i) {
+                        o = fmaf(w[4 * i], ov[it][i].x, o);
+                        o = fmaf(w[4 * i + 1], ov[it][i].y, o);
+                        o = fmaf(w[4 * i + 2], ov[it][i].z, o);
+                        o = fmaf(w[4 * i + 3], ov[it][i].w, o);
+                    }
+                    as[e] = o;
+                }
             }
-            as[e] = o / l;
         }
         __syncthreads();
     }
@@ -272,7 +307,7 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
 template <typename T, int NCH, bool COMBINE>
 static void launch_resid_nch(hipStream_t s, const GemvResidArgs& a) {
     const int grid = (a.N + 3) / 4;
-    const size_t shm = COMBINE ? ((size_t)a.M * a.K + 2 * (size_t)a.M * a.H * kAttnSplit) * sizeof(float) : 0;
+    const size_t shm = COMBINE ? ((size_t)a.M * a.K + (size_t)a.M * a.H * kAttnPad) * sizeof(float) : 0;
     constexpr int MBmax = (NCH <= 3) ? 4 : (NCH <= 6 ? 2 : 1);
     if (a.M == 1 || MBmax == 1) hipLaunchKernelGGL((gemv_resid_kernel<T, 1, NCH, COMBINE>), dim3(grid), dim3(256), shm, s, a);
     else if (a.M == 2 || MBmax == 2) hipLaunchKernelGGL((gemv_resid_kernel<T, (MBmax >= 2 ? 2 : 1), NCH, COMBINE>), dim3(grid), dim3(256), shm, s, a);
@@ -287,7 +322,7 @@ void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a0) {
         for (int m = 0; m < a0.M; m += 8) {
             GemvResidArgs b = a0;
             b.M = min(8, a0.M - m);
-            b.part = a0.part + (long)m * a0.H * kAttnSplit * kAttnPart;
+            b.part = a0.part + (long)m * a0.H * kAttnRec;
             b.x = a0.x + (long)m * a0.ldx;
             launch_gemv_resid<T>(s, b);
         }
@@ -400,9 +435,9 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restri
     }
     if (lane == 0) s_sum[wave] = ls;
     __syncthreads();
-    float* out = part + (((long)qi * H + h) * kAttnSplit + split) * kAttnPart;
-    if (tid < kHeadDim) out[2 + tid] = ((s_o[0][tid] + s_o[1][tid]) + s_o[2][tid]) + s_o[3][tid];
-    if (tid == 0) { out[0] = mx; out[1] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3]; }
+    float* out = part + ((long)qi * H + h) * kAttnRec;
+    if (tid < kHeadDim) out[2 * kAttnPad + tid * kAttnPad + split] = ((s_o[0][tid] + s_o[1][tid]) + s_o[2][tid]) + s_o[3][tid];
+    if (tid == 0) { out[split] = mx; out[kAttnPad + split] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3]; }
 }
 
 template <typename T>

@@ -53,11 +53,13 @@ template <typename T> void launch_attn_temporal(hipStream_t s, const T* qkv, T* 
 //   V row at + v_off.  Row-major k|v rows [L][2E]: head_stride 48, key_stride 2E, v_off E.  Decode cache (head-major, so a
 //   split's keys are one contiguous 96 B x n_keys run): [2][H][Lmax][48] -> head_stride Lmax*48, key_stride 48, v_off H*Lmax*48.
 //   L   = *d_len + len_add  when d_len != nullptr, else len_add;  scene of query qi = qi / q_per_scene
-//   part [NQ][H][NSPLIT][50] = (m, l, o[48])
+//   part [NQ][H][kAttnRec]: per (query, head) the split statistics m[sp], l[sp] and o[d][sp] with the split index fastest, so
+//   the merge in the projection prologue reads each output column's <= 18 partials with five 16-byte loads
 constexpr int kAttnSplit = 18;
 constexpr int kAttnChunk = 128;   // split s owns keys [128 s, 128 s + 128); the host launches ns = ceil(L / 128) splits (L <= 2304)
 inline int attn_nsplit(int L) { return L <= 0 ? 1 : (L + kAttnChunk - 1) / kAttnChunk; }
-constexpr int kAttnPart = 50;
+constexpr int kAttnPad = 20;                    // split dimension padded so every o-row is 16-byte aligned
+constexpr int kAttnRec = 2 * kAttnPad + kHeadDim * kAttnPad;   // floats per (query, head): m[20] | l[20] | o[48][20] (split fastest)
 template <typename T> void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long head_stride,
                                                long key_stride, long v_off, int NQ, int q_per_scene, int H, const int* d_len, int len_add,
                                                int ns, float* part);
