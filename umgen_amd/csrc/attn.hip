@@ -13,22 +13,66 @@ constexpr float kLog2e = 1.4426950408889634f;
 //   O^T[d][query]  += Vt[d][key] . P^T[key][query]   (16x16x32; the k-slot -> key map is chosen so that each lane's own
 //                                                     P registers are exactly its B-operand elements: no cross-lane traffic)
 // Q, K are row-major [token][2E]; V is stored transposed per (frame, head) by the QKV GEMM epilogue (GEMM_VT).
-// One wave owns QT*16 queries; a workgroup = 4 waves.  K / Vt fragments are read straight from L2 (a (frame, head)
-// K+V set is 2 x 212 KB and is shared by every workgroup of that frame/head).
+// A workgroup = 4 waves x (QT*16) queries of one (frame, head).  The 64-key K tile [64][48] and Vt tile [48][64] are staged
+// once per workgroup into double-buffered LDS (16-byte global loads prefetched into registers one tile ahead; row strides
+// 112 B / 144 B make the ds_read_b128 / ds_read_b64 fragment reads bank-conflict free) and shared by the 4 waves.
+// Blocks of one (frame, head) are mapped to the same XCD (block b runs on XCD b % 8) so its K/V stay in one L2.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kKStride = 112;   // bytes per K row in LDS  (96 used)
+constexpr int kVStride = 144;   // bytes per Vt row in LDS (128 used)
+constexpr int kTileBytes = 64 * kKStride + 48 * kVStride;   // 14080
+
 template <int QT>
 __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
-                                                                bf16_t* __restrict__ y, int S, int S_pad, int H) {
+                                                                bf16_t* __restrict__ y, int S, int S_pad, int H, int nq, int npairs) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTileBytes];
     const int E = H * kHeadDim;
-    const int f = blockIdx.z, h = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // XCD-aware decode of the flat block id: 8 consecutive (frame, head) pairs form a group; inside it b = q*8 + j
+    const int b = blockIdx.x;
+    const int group = b / (8 * nq), rem = b % (8 * nq);
+    const int pair = group * 8 + (rem & 7), qb = rem >> 3;
+    if (pair >= npairs) return;
+    const int f = pair / H, h = pair % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g = lane >> 4;
-    const int q0 = (blockIdx.x * 4 + wave) * (QT * 16);
-    if (q0 >= S) return;
+    const int q0 = (qb * 4 + wave) * (QT * 16);
     const long ld = 2L * E;
     const bf16_t* qbase = qk + (long)f * S * ld + h * kHeadDim;
     const bf16_t* kbase = qbase + E;
     const bf16_t* vbase = vt + ((long)f * H + h) * kHeadDim * S_pad;
+
+    // staging assignment: 768 16-byte chunks per tile (K: 64 rows x 6, Vt: 48 rows x 8), 3 per thread
+    const bf16_t* gsrc[3];
+    int ldst[3];
+    bool is_k[3];
+    int krow[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = tid + 256 * i;
+        if (c < 384) {
+            const int r = c / 6, p = c % 6;
+            is_k[i] = true; krow[i] = r;
+            gsrc[i] = kbase + p * 8;                    // + row*ld per tile
+            ldst[i] = r * kKStride + p * 16;
+        } else {
+            const int cc = c - 384, r = cc >> 3, p = cc & 7;
+            is_k[i] = false; krow[i] = 0;
+            gsrc[i] = vbase + (long)r * S_pad + p * 8;  // + k0 per tile
+            ldst[i] = 64 * kKStride + r * kVStride + p * 16;
+        }
+    }
+    uint4 stage[3];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (is_k[i]) stage[i] = *reinterpret_cast<const uint4*>(gsrc[i] + (long)min(k0 + krow[i], S - 1) * ld);
+            else stage[i] = *reinterpret_cast<const uint4*>(gsrc[i] + k0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<uint4*>(lds + buf * kTileBytes + ldst[i]) = stage[i];
+    };
 
     bf16x8_t qlo[QT];
     s16x4_t qhi[QT];
@@ -48,13 +92,21 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
         for (int d = 0; d < 3; ++d) o[t][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     const float c = kScale * kLog2e;
-    for (int k0 = 0; k0 < S; k0 += 64) {
+    const int ntile = (S + 63) / 64;
+    gload(0);
+    lstore(0);
+    if (ntile > 1) gload(64);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int k0 = it * 64;
+        const unsigned char* kt_l = lds + (it & 1) * kTileBytes;
+        const unsigned char* vt_l = kt_l + 64 * kKStride;
         f32x4_t st[QT][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            const int kr = min(k0 + kt * 16 + c16, S - 1);
-            const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kbase + kr * ld + 8 * g);
-            const s16x4_t khi = *reinterpret_cast<const s16x4_t*>(kbase + kr * ld + 32 + 4 * g);
+            const unsigned char* kr = kt_l + (kt * 16 + c16) * kKStride;
+            const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kr + 16 * g);
+            const s16x4_t khi = *reinterpret_cast<const s16x4_t*>(kr + 64 + 8 * g);
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(klo, qlo[t], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -106,16 +158,22 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
         }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const bf16_t* vr = vbase + (long)(d * 16 + c16) * S_pad + k0 + 4 * g;
+            const unsigned char* vr = vt_l + (d * 16 + c16) * kVStride + 8 * g;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 union { bf16x8_t v; uint2 u[2]; } a;
-                a.u[0] = *reinterpret_cast<const uint2*>(vr + hh * 32);        // keys k0 + 32hh + 4g .. +3
-                a.u[1] = *reinterpret_cast<const uint2*>(vr + hh * 32 + 16);   // keys k0 + 32hh + 16 + 4g .. +3
+                a.u[0] = *reinterpret_cast<const uint2*>(vr + hh * 64);        // keys k0 + 32hh + 4g .. +3
+                a.u[1] = *reinterpret_cast<const uint2*>(vr + hh * 64 + 32);   // keys k0 + 32hh + 16 + 4g .. +3
 #pragma unroll
                 for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, pb[t][hh], o[t][d], 0, 0, 0);
             }
         }
+        // publish tile it+1 (already in registers) into the other buffer, then fetch tile it+2
+        if (it + 1 < ntile) {
+            lstore((it + 1) & 1);
+            if (it + 2 < ntile) gload(k0 + 128);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -135,13 +193,15 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
     }
 }
 
-void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int S_pad, int H) {
 #ifndef UMGEN_ATTN_QT
-#define UMGEN_ATTN_QT 2   // QT=4 (204 VGPR + 88 AGPR) miscomputes the 4th query tile on ROCm 7.2 -- see DESIGN.md
+#define UMGEN_ATTN_QT 2   // measured: 2 query tiles per wave (2 waves/SIMD) beats 4 (1 wave/SIMD)
 #endif
+void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int S_pad, int H) {
     constexpr int QT = UMGEN_ATTN_QT;
-    dim3 grid((S + 4 * QT * 16 - 1) / (4 * QT * 16), H, F);
-    hipLaunchKernelGGL(attn_spatial_mfma_kernel<QT>, grid, dim3(256), 0, s, qk, vt, y, S, S_pad, H);
+    const int nq = (S + 4 * QT * 16 - 1) / (4 * QT * 16);
+    // F*H pairs; groups of 8 pairs need F*H % 8 == 0 -- pad the pair count up and let the surplus blocks exit
+    const int pairs = ((F * H + 7) / 8) * 8;
+    hipLaunchKernelGGL(attn_spatial_mfma_kernel<QT>, dim3(pairs * nq), dim3(256), 0, s, qk, vt, y, S, S_pad, H, nq, F * H);
 }
 
 // ---------------------------------------------------------------------------------------------------------
