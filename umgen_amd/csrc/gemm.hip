@@ -51,14 +51,25 @@ constexpr int BM = 128, BN = 128, BK = 64;
 __device__ inline int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }  // byte offset
 
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * BK * 2];
-    unsigned char* ldsP = lds;
-    unsigned char* ldsQ = lds + BM * BK * 2;
+__global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a, int nI, int nJ) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * BM * BK * 2];   // double buffered: [buf][P tile | Q tile]
     const int z = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    const int i_base = blockIdx.x * BM, j_base = blockIdx.y * BN;
+    // XCD-aware tile map (block b runs on XCD b % 8): the nI feature tiles that share one activation (Q) tile are issued
+    // back-to-back on the same XCD, so every activation tile is fetched into exactly one L2.
+#ifndef UMGEN_GEMM_XCD
+#define UMGEN_GEMM_XCD 1
+#endif
+    const int b = blockIdx.x;
+#if UMGEN_GEMM_XCD
+    const int grp = b / (8 * nI), rem = b % (8 * nI);
+    const int tj = grp * 8 + (rem & 7), ti = rem >> 3;
+#else
+    const int tj = b / nI, ti = b % nI;
+#endif
+    if (tj >= nJ) return;
+    const int i_base = ti * BM, j_base = tj * BN;
     const bf16_t* P = reinterpret_cast<const bf16_t*>(a.P) + (long)z * a.strideP;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q) + (long)z * a.strideQ;
 
@@ -82,6 +93,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a) {
             rq[it] = ok ? *reinterpret_cast<const uint4*>(qq[it] + k0) : make_uint4(0, 0, 0, 0);
         }
     };
+    auto lstore = [&](int buf) {
+        unsigned char* ldsP = lds[buf];
+        unsigned char* ldsQ = lds[buf] + BM * BK * 2;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int r = srow + 32 * it;
+            *reinterpret_cast<uint4*>(ldsP + swz(r, schunk)) = rp[it];
+            *reinterpret_cast<uint4*>(ldsQ + swz(r, schunk)) = rq[it];
+        }
+    };
     f32x4_t acc[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -91,15 +112,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a) {
     const int frow = lane & 15, g = lane >> 4;
     const int nkt = (a.K + BK - 1) / BK;
     gload(0);
+    lstore(0);
+    if (nkt > 1) gload(BK);
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int r = srow + 32 * it;
-            *reinterpret_cast<uint4*>(ldsP + swz(r, schunk)) = rp[it];
-            *reinterpret_cast<uint4*>(ldsQ + swz(r, schunk)) = rq[it];
-        }
-        __syncthreads();
-        if (kt + 1 < nkt) gload((kt + 1) * BK);
+        const unsigned char* ldsP = lds[kt & 1];
+        const unsigned char* ldsQ = lds[kt & 1] + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t af[4], bfr[4];
@@ -112,6 +130,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a) {
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        }
+        // tile kt+1 (already in registers) goes to the other buffer (last read in iteration kt-1), then tile kt+2 is requested
+        if (kt + 1 < nkt) {
+            lstore((kt + 1) & 1);
+            if (kt + 2 < nkt) gload((kt + 2) * BK);
         }
         __syncthreads();
     }
@@ -127,13 +150,97 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a) {
         }
 }
 
+// Same tile and MFMA schedule, but the operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, 1 KB per wave
+// instruction, no staging VGPRs, no ds_write pass).  The LDS image is lane-linear per wave instruction, so the XOR swizzle is
+// applied to the per-lane SOURCE address (chunk c' of the image holds global chunk c' ^ (row & 7)).  Two LDS buffers: the
+// loads of tile kt+1 are in flight while tile kt is multiplied; one barrier per k-tile.  Requires K % 64 == 0.
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs a, int nI, int nJ) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * BM * BK * 2];
+    const int z = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int b = blockIdx.x;
+    const int grp = b / (8 * nI), rem = b % (8 * nI);
+    const int tj = grp * 8 + (rem & 7), ti = rem >> 3;
+    if (tj >= nJ) return;
+    const int i_base = ti * BM, j_base = tj * BN;
+    const bf16_t* P = reinterpret_cast<const bf16_t*>(a.P) + (long)z * a.strideP;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q) + (long)z * a.strideQ;
+    // wave w fills the 1 KB segments w, w+4, w+8, w+12 (8 rows each) of both operand images
+    const bf16_t* pp[4];
+    const bf16_t* qq[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (wave + 4 * it) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
+        pp[it] = P + (long)min(i_base + r, a.Mi - 1) * a.ldp + c * 8;
+        qq[it] = Q + (long)min(j_base + r, a.Nj - 1) * a.ldq + c * 8;
+    }
+    auto issue = [&](int buf, int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            unsigned char* dp = lds[buf] + (wave + 4 * it) * 1024;
+            __builtin_amdgcn_global_load_lds((const void*)(pp[it] + k0), (__attribute__((address_space(3))) void*)dp, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(qq[it] + k0), (__attribute__((address_space(3))) void*)(dp + BM * BK * 2), 16, 0, 0);
+        }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, g = lane >> 4;
+    const int nkt = a.K / BK;
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) issue((kt + 1) & 1, (kt + 1) * BK);
+        const unsigned char* ldsP = lds[kt & 1];
+        const unsigned char* ldsQ = lds[kt & 1] + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[4], bfr[4];
+            const int c = kk * 4 + g;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const bf16x8_t*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bfr[n] = *reinterpret_cast<const bf16x8_t*>(ldsQ + swz(wj * 64 + n * 16 + frow, c));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int i0 = i_base + wi * 64 + m * 16 + 4 * g;
+            const int j = j_base + wj * 64 + n * 16 + frow;
+            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+            epilogue4<MODE, bf16_t>(a, z, i0, j, v);
+        }
+}
+
 void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a) {
-    dim3 grid((a.Mi + BM - 1) / BM, (a.Nj + BN - 1) / BN, a.batch), block(256);
+    const int nI = (a.Mi + BM - 1) / BM, nJ = (a.Nj + BN - 1) / BN;
+    dim3 grid(((nJ + 7) / 8) * 8 * nI, 1, a.batch), block(256);
+    if (a.K % BK == 0) {
+        switch (a.mode) {
+            case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_STORE>, grid, block, 0, s, a, nI, nJ); break;
+            case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_RESID>, grid, block, 0, s, a, nI, nJ); break;
+            case GEMM_STORE_F32: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_STORE_F32>, grid, block, 0, s, a, nI, nJ); break;
+            default: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_VT>, grid, block, 0, s, a, nI, nJ); break;
+        }
+        return;
+    }
     switch (a.mode) {
-        case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_STORE>, grid, block, 0, s, a); break;
-        case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_RESID>, grid, block, 0, s, a); break;
-        case GEMM_STORE_F32: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_STORE_F32>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_VT>, grid, block, 0, s, a); break;
+        case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_STORE>, grid, block, 0, s, a, nI, nJ); break;
+        case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_RESID>, grid, block, 0, s, a, nI, nJ); break;
+        case GEMM_STORE_F32: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_STORE_F32>, grid, block, 0, s, a, nI, nJ); break;
+        default: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_VT>, grid, block, 0, s, a, nI, nJ); break;
     }
 }
 

@@ -39,6 +39,9 @@ __device__ inline void wunpack(const WChunk<float>& w, float (&o)[8]) {
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int MB, int NCH, int RPW>
 __global__ __launch_bounds__(256) void gemv_ln_kernel(GemvArgs a) {
+#ifdef UMGEN_DRY_DECODE
+    return;   // launch-floor experiment: same graph, no work
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
@@ -175,6 +178,9 @@ template void launch_gemv<bf16_t>(hipStream_t, const GemvArgs&);
 
 template <typename T, int MB, int NCH, bool COMBINE>
 __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
+#ifdef UMGEN_DRY_DECODE
+    return;
+#endif
     extern __shared__ __attribute__((aligned(16))) float as[];   // [M][K] when COMBINE
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = a.K;
@@ -356,6 +362,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ kv_base, long scene_stride,
                                                            long head_stride, long key_stride, long v_off, int q_per_scene, int H,
                                                            const int* __restrict__ d_len, int len_add, int kmax, float* __restrict__ part) {
+#ifdef UMGEN_DRY_DECODE
+    return;
+#endif
     __shared__ float s_max[4];
     __shared__ float s_sum[4];
     __shared__ float s_o[4][kHeadDim];
