@@ -100,3 +100,36 @@ def test_fp32_sampled_rollout_matches_oracle_and_is_batch_invariant():
             np.testing.assert_array_equal(single[i][m], ref[i][m], err_msg=f"scene {i} {m}")
             np.testing.assert_array_equal(both[m][i:i + 1], single[i][m], err_msg=f"batch scene {i} {m}")
     e.close()
+
+
+def test_dropin_model_class_through_registry_matches_golden():
+    """The reference's call sequence (evaluate.py:193-214, model_pl.py:237): build_from_cfg(dict(type=UMGen, config=Namespace))
+    -> load_state_dict(strict=False) -> inference(**setting) returns the golden token dict."""
+    from argparse import Namespace
+
+    from umgen_amd.model import UMGen
+    from umgen_amd.registry import MODELS, build_from_cfg
+
+    g = np.load(os.path.join(GOLD, "tiny_video_greedy.npz"))
+    ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
+    c = tiny_config().greedy()
+    ns = Namespace(n_embd=c.n_embd, n_head=c.n_head, n_ego_tar_layer=1, n_ego_ca_layer=1, n_map_tar_layer=1, n_box_tar_layer=1,
+                   n_tar_layer=1, n_oar_layer=c.n_oar_layer, pose_vocab_size=1024, map_vocab_size=8192, bbox3d_vocab_size=1028,
+                   img_vocab_size=8192, aux_vocab_size=8, n_map_embd=16, n_img_embd=16, max_frame_len=c.max_frame_len, task_num=7,
+                   task_name_id={"pose_map_bbox3d_image": 6}, sample_method="topk", top_k=1, top_k_map=1, p=0.4, sfmx_temp=1.0,
+                   rule_constrain=True, split_map_tar=True, split_box_tar=True, map_transform=True, box_transform=False, n_step=1,
+                   sample_img=True, bias=False, merage_ar_tar=True, only_ar=False)
+    model = build_from_cfg(dict(type=UMGen, config=ns, precision="fp32"), MODELS)
+    model.rcfg.topk_image = 1            # the reference hard-codes topk_image on the instance (UMGen.py:103)
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(c, seed=ws).items()}
+    sd["transformer.head_tar_pose.weight"] = torch.zeros(1024, c.n_embd)     # present in real checkpoints, unused by the rollout
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.missing_keys and res.unexpected_keys == ["transformer.head_tar_pose.weight"]
+    model.eval()
+    scene = synthetic_scene(sid, n_frames=icf)
+    out = model.inference(new_frames=nf, cond_frames=cf, pred_task="pose_map_bbox3d_image",
+                          input_cond_tokens={k: torch.from_numpy(v) for k, v in scene.items()}, init_tokens=None,
+                          input_cond_frames=icf, control_test=False, cond_on_par=True, infer_from_gt=False)
+    for m in MOD_ORDER:
+        assert out[m].dtype == np.int64
+        np.testing.assert_array_equal(out[m], g[f"out_{m}"].astype(np.int64), err_msg=m)

@@ -50,10 +50,23 @@ __device__ inline float wave_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, true));   // row_bcast:31 -> lane 63
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// wave64 max / integer min with the same DPP schedule (lanes without a valid source keep their own value)
+#define UMGEN_DPP_STEP(op, T, ctrl, rmask, bmask) v = op(v, T##_from_int(__builtin_amdgcn_update_dpp(T##_to_int(v), T##_to_int(v), ctrl, rmask, bmask, false)))
+__device__ inline int f32_to_int(float x) { return __float_as_int(x); }
+__device__ inline float f32_from_int(int x) { return __int_as_float(x); }
+__device__ inline int i32_to_int(int x) { return x; }
+__device__ inline int i32_from_int(int x) { return x; }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    UMGEN_DPP_STEP(fmaxf, f32, 0x111, 0xf, 0xf); UMGEN_DPP_STEP(fmaxf, f32, 0x112, 0xf, 0xf);
+    UMGEN_DPP_STEP(fmaxf, f32, 0x114, 0xf, 0xe); UMGEN_DPP_STEP(fmaxf, f32, 0x118, 0xf, 0xc);
+    UMGEN_DPP_STEP(fmaxf, f32, 0x142, 0xa, 0xf); UMGEN_DPP_STEP(fmaxf, f32, 0x143, 0xc, 0xf);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ inline int wave_min_i32(int v) {
+    UMGEN_DPP_STEP(min, i32, 0x111, 0xf, 0xf); UMGEN_DPP_STEP(min, i32, 0x112, 0xf, 0xf);
+    UMGEN_DPP_STEP(min, i32, 0x114, 0xf, 0xe); UMGEN_DPP_STEP(min, i32, 0x118, 0xf, 0xc);
+    UMGEN_DPP_STEP(min, i32, 0x142, 0xa, 0xf); UMGEN_DPP_STEP(min, i32, 0x143, 0xc, 0xf);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // exact GELU (nn.GELU default, module.py:239): 0.5 x (1 + erf(x / sqrt(2)))

@@ -203,11 +203,11 @@ __device__ inline void finish_step(OarState* st) {
 // sampling on the build's counter-based uniform (bit-for-bit the oracle's OracleUMGen.sample)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxKept = 64;
+constexpr int kMaxK = 32;
 struct SampleShared {
-    float red_v[4];
-    int red_i[4];
-    float win_v;
-    int win_i;
+    float cand_v[4 * kMaxK];
+    int cand_i[4 * kMaxK];
+    float kth;
     int n_kept;
     int kept_i[kMaxKept];
     float kept_v[kMaxKept];
@@ -215,6 +215,8 @@ struct SampleShared {
 };
 
 // all 256 threads call; returns the sampled index.  mask_idx (>=0) is treated as -inf.
+// k-th largest value: every wave extracts its own top-k (k rounds of register arg-max + two DPP wave reductions, no
+// barriers), thread 0 merges the 4k candidates.
 __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k, float temp, float u, int mask_idx, SampleShared& sh) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float v[32];
@@ -223,8 +225,7 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
         const int idx = tid + 256 * i;
         v[i] = (idx < V && idx != mask_idx) ? logits[idx] : -INFINITY;
     }
-    float kth = -INFINITY;
-    const int kk = min(k, V);
+    const int kk = min(min(k, V), kMaxK);
     for (int it = 0; it < kk; ++it) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
@@ -233,34 +234,33 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
             const int idx = tid + 256 * i;
             if (v[i] > bv) { bv = v[i]; bi = idx; }   // ascending idx within a thread => lowest index kept on ties
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        if (lane == 0) { sh.red_v[wave] = bv; sh.red_i[wave] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            float wv = sh.red_v[0];
-            int wi = sh.red_i[0];
-            for (int w2 = 1; w2 < 4; ++w2)
-                if (sh.red_v[w2] > wv || (sh.red_v[w2] == wv && sh.red_i[w2] < wi)) { wv = sh.red_v[w2]; wi = sh.red_i[w2]; }
-            sh.win_v = wv;
-            sh.win_i = wi;
-        }
-        __syncthreads();
-        kth = sh.win_v;
-        const int wi = sh.win_i;
-        if ((wi & 255) == tid) {
+        const float wv = wave_max(bv);
+        const int wi = wave_min_i32(bv == wv ? bi : 0x7fffffff);   // lowest index among the lanes holding the wave maximum
+        if (lane == 0) { sh.cand_v[wave * kMaxK + it] = wv; sh.cand_i[wave * kMaxK + it] = wi; }
+        if (bi == wi) {
 #pragma unroll
             for (int i = 0; i < 32; ++i)
                 if (tid + 256 * i == wi) v[i] = -INFINITY;
         }
-        __syncthreads();
     }
-    if (tid == 0) sh.n_kept = 0;
     __syncthreads();
+    if (tid == 0) {
+        // k-th largest of the union of the four descending per-wave lists (4-way merge by value)
+        int p[4] = {0, 0, 0, 0};
+        float kth = -INFINITY;
+        for (int it = 0; it < kk; ++it) {
+            int bw = -1;
+            float bvv = -INFINITY;
+            for (int w2 = 0; w2 < 4; ++w2)
+                if (p[w2] < kk && (bw < 0 || sh.cand_v[w2 * kMaxK + p[w2]] > bvv)) { bw = w2; bvv = sh.cand_v[w2 * kMaxK + p[w2]]; }
+            kth = bvv;
+            ++p[bw];
+        }
+        sh.kth = kth;
+        sh.n_kept = 0;
+    }
+    __syncthreads();
+    const float kth = sh.kth;
     for (int idx = tid; idx < V; idx += 256) {
         const float l = (idx != mask_idx) ? logits[idx] : -INFINITY;
         if (l >= kth && l > -INFINITY) {
