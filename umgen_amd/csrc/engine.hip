@@ -476,7 +476,14 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     HIPCHK(e, hipMemcpyAsync(e->d_tokens, tok0.data(), tok0.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->d_prev_box, prevbox.data(), prevbox.size() * 4, hipMemcpyHostToDevice, st));
     if (io.control_slot) HIPCHK(e, hipMemcpyAsync(e->d_control, io.control_slot, (size_t)B * kSlots, hipMemcpyHostToDevice, st));
-    OarState s0{0, io.frame_idx, forced ? 1 : 0, io.control_slot ? 1 : 0, 0, sp};
+    // measurement knob (never set in production): UMGEN_DEBUG_OAR_STEPS="a:b" runs only decode steps j in [a, b) so that
+    // per-dispatch PMC collection (which serialises every kernel) stays bounded; results are meaningless then.
+    int j_begin = 0, j_end = kImgEos;
+    if (const char* dbg = getenv("UMGEN_DEBUG_OAR_STEPS")) {
+        int a0 = 0, b0 = kImgEos;
+        if (sscanf(dbg, "%d:%d", &a0, &b0) == 2 && a0 >= 0 && b0 <= kImgEos && a0 < b0) { j_begin = a0; j_end = b0; }
+    }
+    OarState s0{j_begin, io.frame_idx, forced ? 1 : 0, io.control_slot ? 1 : 0, 0, sp};
     HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
 
     // Step 2: the three TAR stacks (UMGen.py:1484-1494) and the conditioning rows (1496-1511)
@@ -502,7 +509,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                 if (g) { hipGraphExecDestroy(g); g = nullptr; }
         e->step_graph_B = B;
     }
-    for (int j = 0; j < kImgEos; ++j) {   // the img-eos step (j = 2206) produces nothing that is consumed
+    for (int j = j_begin; j < j_end; ++j) {   // the img-eos step (j = 2206) produces nothing that is consumed
         int mod = 0;
         if (j >= kMapC0 && j < kMapEos) mod = 1;
         else if (j >= kBoxC0 && j < kBoxEos) mod = 2;

@@ -160,10 +160,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
     const int z = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
+    // XCD-aware 2-D tile map (block b runs on XCD b % 8).  Measured with FETCH_SIZE: when every XCD walks all feature
+    // tiles, a 4.7 MB weight matrix does not stay in the 4 MB L2 and is re-streamed for every token tile (7x the
+    // algorithmic traffic).  So the 8 XCDs form a 2 (feature halves) x 4 (token quarters) grid: each L2 keeps half of the
+    // weight matrix resident, every activation tile is fetched by 2 XCDs, and inside an XCD the feature tiles that share an
+    // activation tile are issued back to back.
     const int b = blockIdx.x;
-    const int grp = b / (8 * nI), rem = b % (8 * nI);
-    const int tj = grp * 8 + (rem & 7), ti = rem >> 3;
-    if (tj >= nJ) return;
+    const int xcd = b & 7, lb = b >> 3;
+    const int hI = (nI + 1) >> 1, qJ = (nJ + 3) >> 2;
+    const int ti = (xcd & 1) * hI + lb % hI, tj = (xcd >> 1) * qJ + lb / hI;
+    if (ti >= nI || tj >= nJ || ti >= ((xcd & 1) + 1) * hI || tj >= ((xcd >> 1) + 1) * qJ) return;
     const int i_base = ti * BM, j_base = tj * BN;
     const bf16_t* P = reinterpret_cast<const bf16_t*>(a.P) + (long)z * a.strideP;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q) + (long)z * a.strideQ;
@@ -228,6 +234,7 @@ void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a) {
     const int nI = (a.Mi + BM - 1) / BM, nJ = (a.Nj + BN - 1) / BN;
     dim3 grid(((nJ + 7) / 8) * 8 * nI, 1, a.batch), block(256);
     if (a.K % BK == 0) {
+        grid = dim3(8 * ((nI + 1) / 2) * ((nJ + 3) / 4), 1, a.batch);
         switch (a.mode) {
             case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_STORE>, grid, block, 0, s, a, nI, nJ); break;
             case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_RESID>, grid, block, 0, s, a, nI, nJ); break;
