@@ -81,6 +81,8 @@ typedef struct umgen_trace {
     float *logits_bbox3d;   /* [660][bbox3d_vocab]                               (UMGen.py:1072)      */
     float *logits_image;    /* [512][img_vocab]                                  (UMGen.py:1132)      */
     const int64_t *forced_pose, *forced_map, *forced_bbox3d, *forced_image; /* teacher forcing, [S_mod] */
+    int32_t *counters;      /* [8] events of the frame: 0 pad-avoid resamples, 1 control resamples, 2 rule checks,
+                               3 rule collisions, 4 slots blanked, 5 sampled != forced token (teacher forcing only) */
 } umgen_trace;
 
 /* Event-timed phases of the last umgen_rollout call (milliseconds, HIP events on the engine stream). */

@@ -385,28 +385,17 @@ class OracleUMGen:
         else:
             z = l / temp
             pr = np.exp(z - z.max()).astype(np.float32)
-            pr = pr / np.float32(pr.sum(dtype=np.float32))
-            order = np.argsort(-pr, kind="stable")
+            pr = pr / np.cumsum(pr, dtype=np.float32)[-1]      # sequential fp32 sum in index order (mirrored on the device)
+            order = np.argsort(-pr, kind="stable")              # ties: ascending index
             ps = pr[order]
-            keep = []
-            c = np.float32(0)
-            for j in range(ps.shape[0]):
-                if c > np.float32(p):      # (cumsum - p_j) > p  (UMGen.py:950)
-                    break
-                keep.append(j)
-                c = np.float32(c + ps[j])
-            idx = order[keep]
-            e = ps[keep]
-        total = np.float32(0)
-        for x in e:
-            total = np.float32(total + x)
-        target = np.float32(u * total)
-        c = np.float32(0)
-        for j, x in enumerate(e):
-            c = np.float32(c + x)
-            if c > target:
-                return int(idx[j])
-        return int(idx[-1])
+            cum = np.cumsum(ps, dtype=np.float32)                # sequential fp32 prefix sums
+            n = 1 + int(np.sum(cum[:-1] <= np.float32(p)))       # entry j is masked when (cumsum - p_j) > p  (UMGen.py:950)
+            idx = order[:n]
+            e = ps[:n]
+        c = np.cumsum(e, dtype=np.float32)                        # == the sequential loop total += x
+        target = np.float32(u * c[-1])
+        hit = np.nonzero(c > target)[0]
+        return int(idx[hit[0]]) if hit.size else int(idx[-1])
 
     # ---- one frame (UMGen._inference, UMGen.py:1406-1540) ---------------------------------------
     def _frame(self, window: Dict[str, torch.Tensor], init: Optional[Dict[str, torch.Tensor]], control_test: bool,
@@ -489,7 +478,8 @@ class OracleUMGen:
                 if mod == "map":
                     tok = self.sample(lg, cfg.top_k_map, cfg.p_map, u)
                 elif mod == "image":
-                    tok = self.sample(lg, cfg.topk_image, cfg.p, u)
+                    # UMGen.py:1133 passes topk_image as the sampler parameter: in top-p mode that is p = 16.0 (keep everything)
+                    tok = self.sample(lg, cfg.topk_image, float(cfg.topk_image), u)
                 else:
                     tok = self._sample_bbox(lg, cond[0, pos - 1], pos, prev_box, control_slots, seed, frame_idx, u)
                 if forced is None and mod == "bbox3d" and cfg.rule_constrain:

@@ -107,4 +107,4 @@ def test_engine_fails_loudly_without_gpu():
 def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_lib.Config) == 24 * 4
     assert ctypes.sizeof(_lib.Sampling) == 48
-    assert ctypes.sizeof(_lib.Trace) == 9 * 8
+    assert ctypes.sizeof(_lib.Trace) == 10 * 8

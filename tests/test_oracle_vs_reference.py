@@ -45,3 +45,29 @@ def test_pose_decode_and_collision_helpers_match_reference_functions():
         boxes = [np.concatenate([rng.uniform(-30, 70, 2), [0], rng.uniform(0.1, 8, 2), [1.5], rng.uniform(-3.14, 3.14, 1), [0, 0, 0]])
                  for _ in range(n)]
         assert check_collision(boxes) == bool(bo.check_collision(boxes, fliter=True))
+
+
+def test_top_p_sampler_matches_reference_nucleus(monkeypatch):
+    """sample_top_p (UMGen.py:915-965) with torch.multinomial replaced by the build's inverse-CDF draw must pick the
+    same token as OracleUMGen.sample on the same uniform."""
+    cfg = tiny_config(n_oar_layer=1)
+    cfg.sample_method = "topp"
+    sd = synthetic_state_dict(cfg, seed=12)
+    model = refimport.build_reference_model(cfg, sd, greedy=False)
+    o = OracleUMGen(cfg, sd)
+    rng = np.random.default_rng(0)
+    state = {}
+
+    def fake_multinomial(probs, num_samples=1):
+        c = torch.cumsum(probs[0].float(), 0)
+        hit = torch.nonzero(c > state["u"] * c[-1])
+        return (hit[0] if hit.numel() else torch.tensor([probs.shape[-1] - 1])).view(1, 1)
+
+    monkeypatch.setattr(torch, "multinomial", fake_multinomial)
+    for trial in range(40):
+        V = int(rng.choice([1028, 8192]))
+        logits = torch.from_numpy((rng.standard_normal(V) * rng.uniform(0.5, 4.0)).astype(np.float32))
+        p = float(rng.choice([0.1, 0.4, 0.9]))
+        state["u"] = np.float32(rng.random())
+        ref = int(model.sample_top_p(logits.clone()[None], p)[0, 0])
+        assert o.sample(logits, 5, p, state["u"]) == ref, (trial, V, p)

@@ -42,7 +42,8 @@ class Trace(C.Structure):
                 ("logits_map", C.POINTER(C.c_float)), ("logits_bbox3d", C.POINTER(C.c_float)),
                 ("logits_image", C.POINTER(C.c_float)),
                 ("forced_pose", C.POINTER(C.c_int64)), ("forced_map", C.POINTER(C.c_int64)),
-                ("forced_bbox3d", C.POINTER(C.c_int64)), ("forced_image", C.POINTER(C.c_int64))]
+                ("forced_bbox3d", C.POINTER(C.c_int64)), ("forced_image", C.POINTER(C.c_int64)),
+                ("counters", C.POINTER(C.c_int32))]
 
 
 class Timings(C.Structure):

@@ -534,6 +534,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     e->tm.oar_steps += kImgEos;
     HIPCHK(e, hipEventRecord(e->ev[3], st));
     HIPCHK(e, hipMemcpyAsync(io.out_tokens, e->d_tokens, (size_t)B * kTokPerFrame * 4, hipMemcpyDeviceToHost, st));
+    if (tr && tr->counters) HIPCHK(e, hipMemcpyAsync(tr->counters, e->d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
     float ms;
     hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->tm.ego_ms += ms;
@@ -841,7 +842,8 @@ int umgen_get_timings(umgen_engine* e, umgen_timings* out) {
 
 static int check_sampling(umgen_engine* e, const umgen_sampling* s) {
     if (!s) return e->fail(UMGEN_E_INVALID, "sampling is null");
-    if (s->method != UMGEN_SAMPLE_TOPK) return e->fail(UMGEN_E_UNSUPPORTED, "only sample_method='topk' (the evaluate.py default) is implemented");
+    if (s->method != UMGEN_SAMPLE_TOPK && s->method != UMGEN_SAMPLE_TOPP) return e->fail(UMGEN_E_INVALID, "sample method %d", s->method);
+    if (s->method == UMGEN_SAMPLE_TOPP && !(s->p > 0.f && s->p_map > 0.f)) return e->fail(UMGEN_E_INVALID, "top-p mass must be > 0");
     if (s->top_k < 1 || s->top_k > 32 || s->top_k_map < 1 || s->top_k_map > 32 || s->topk_image < 1 || s->topk_image > 32)
         return e->fail(UMGEN_E_INVALID, "top-k values must be in [1, 32]");
     if (!(s->temperature > 0.f)) return e->fail(UMGEN_E_INVALID, "temperature must be > 0");

@@ -299,6 +299,92 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// sample_top_p (UMGen.py:915-965): softmax -> sort descending -> keep while (cumsum - p_j) <= p -> renormalise -> draw.
+// Mirrors OracleUMGen.sample bit for bit: sequential fp32 sums (index order for the softmax denominator, sorted order for
+// the nucleus), stable descending order (ties by ascending index) from a block-wide bitonic sort in LDS.
+// Not the default path (evaluate.py resolves sample_method="topk"); ~0.1 ms per token.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kTopPMax = 8192;
+struct TopPShared {
+    float pr[kTopPMax];
+    int ix[kTopPMax];
+    float red[4];
+    float total;
+    int result;
+};
+__device__ int block_sample_topp(const float* __restrict__ logits, int V, float p, float temp, float u, int mask_idx, TopPShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid; i < kTopPMax; i += 256) {
+        const float z = (i < V && i != mask_idx) ? logits[i] / temp : -INFINITY;
+        sh.pr[i] = z;
+        sh.ix[i] = i;
+        mx = fmaxf(mx, z);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) sh.red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sh.red[0], sh.red[1]), fmaxf(sh.red[2], sh.red[3]));
+    for (int i = tid; i < kTopPMax; i += 256) sh.pr[i] = expf(sh.pr[i] - mx);   // exp(-inf) = 0 for padding / masked
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int i = 0; i < V; ++i) t = __fadd_rn(t, sh.pr[i]);
+        sh.total = t;
+    }
+    __syncthreads();
+    const float total = sh.total;
+    for (int i = tid; i < kTopPMax; i += 256) sh.pr[i] = (i < V) ? sh.pr[i] / total : -1.f;   // padding sorts last
+    __syncthreads();
+    // bitonic sort, descending by probability, ascending index among equals
+    for (int k2 = 2; k2 <= kTopPMax; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < kTopPMax; i += 256) {
+                const int l2 = i ^ j;
+                if (l2 > i) {
+                    const float a = sh.pr[i], b2 = sh.pr[l2];
+                    const int ia = sh.ix[i], ib = sh.ix[l2];
+                    const bool a_first = (a > b2) || (a == b2 && ia < ib);   // a should precede b in the final order
+                    const bool up = ((i & k2) == 0);
+                    if (up ? !a_first : a_first) { sh.pr[i] = b2; sh.pr[l2] = a; sh.ix[i] = ib; sh.ix[l2] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        float c = 0.f;
+        int n = 0;
+        while (n < V && !(c > p)) { c = __fadd_rn(c, sh.pr[n]); ++n; }      // (cumsum - p_j) > p masks entry j
+        float t2 = 0.f;
+        for (int i = 0; i < n; ++i) t2 = __fadd_rn(t2, sh.pr[i]);
+        const float target = __fmul_rn(u, t2);
+        float cc = 0.f;
+        int res = sh.ix[n - 1];
+        for (int i = 0; i < n; ++i) {
+            cc = __fadd_rn(cc, sh.pr[i]);
+            if (cc > target) { res = sh.ix[i]; break; }
+        }
+        sh.result = res;
+    }
+    __syncthreads();
+    const int r = sh.result;
+    __syncthreads();
+    return r;
+}
+
+union SamplerLds {
+    SampleShared k;
+    TopPShared p;
+};
+// dispatch on the sampling method (UMGen.py:119-126): kparam is the top-k value, pparam the nucleus mass
+__device__ inline int block_sample(const SamplerParams& sp, const float* logits, int V, int kparam, float pparam, float u, int mask_idx,
+                                   SamplerLds& sh) {
+    return sp.method == 0 ? block_sample_topk(logits, V, kparam, sp.temperature, u, mask_idx, sh.k)
+                          : block_sample_topp(logits, V, pparam, sp.temperature, u, mask_idx, sh.p);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // rule-based constraint (UMGen.py:1275-1383) and its helpers, evaluated by one thread
 //   decode: BBox3DTokenizer.decode_single_objects (tokenizer.py:679-687) + Normalize.unnormalize_bbox3d (normalize.py:136-229)
 //   collision: BoxOverlap.check_collision(fliter=True) (misc.py:591-630), bbox3d2bevcorners (143-177), box_collision_test (203-311)
@@ -380,7 +466,7 @@ __global__ __launch_bounds__(256) void fixed_token_kernel(SampleArgs a) {
 void launch_fixed_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchKernelGGL(fixed_token_kernel, dim3(B), dim3(256), 0, s, a); }
 
 __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
-    __shared__ SampleShared sh;
+    __shared__ SamplerLds sh;
     __shared__ float cor[64][8];
     __shared__ int s_tok;
     const int b = blockIdx.x, j = a.st->step, frame = a.st->frame_idx, E = a.tb.E;
@@ -390,7 +476,9 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
     const unsigned long long seed = a.seeds[b];
     const float* lg = a.logits + (long)b * a.ld_logits;
     const int topk = a.mod == 1 ? sp.top_k_map : (a.mod == 3 ? sp.topk_image : sp.top_k);
-    int tok = block_sample_topk(lg, a.vocab, topk, sp.temperature, rng_uniform(seed, frame, pos1, DRAW_MAIN), -1, sh);
+    // top-p: the image head receives topk_image as its "p" (UMGen.py:1133) => the whole distribution is kept
+    const float topp = a.mod == 1 ? sp.p_map : (a.mod == 3 ? (float)sp.topk_image : sp.p);
+    int tok = block_sample(sp, lg, a.vocab, topk, topp, rng_uniform(seed, frame, pos1, DRAW_MAIN), -1, sh);
     int off, k;
     if (a.mod == 1) { off = kOffMap; k = j - kMapC0; }
     else if (a.mod == 2) { off = kOffBox; k = j - kBoxC0; }
@@ -402,12 +490,12 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
         if (use_control) {   // UMGen.py:1083-1089
             const int object_id = (pos1 - 1032) / kSlotLen;
             if (object_id < kSlots && a.control_slot[b * kSlots + object_id]) {
-                tok = block_sample_topk(lt, a.vocab, sp.top_k, sp.temperature, rng_uniform(seed, frame, pos1, DRAW_CONTROL), a.vocab - 1, sh);
+                tok = block_sample(sp, lt, a.vocab, sp.top_k, sp.p, rng_uniform(seed, frame, pos1, DRAW_CONTROL), a.vocab - 1, sh);
                 if (threadIdx.x == 0) atomicAdd(a.counters + 1, 1);
             }
         }
         if (tok == kBoxPad && sp.merge_ar_tar && prev != kBoxPad && !sp.only_ar) {   // UMGen.py:1092-1104
-            tok = block_sample_topk(lt, a.vocab, sp.top_k, sp.temperature, rng_uniform(seed, frame, pos1, DRAW_PAD_AVOID), -1, sh);
+            tok = block_sample(sp, lt, a.vocab, sp.top_k, sp.p, rng_uniform(seed, frame, pos1, DRAW_PAD_AVOID), -1, sh);
             if (threadIdx.x == 0) atomicAdd(a.counters + 0, 1);
         }
         if (sp.rule_constrain && !use_forced && tok != kBoxPad && (pos1 - 1032) % kSlotLen == 0) {   // UMGen.py:1116-1123
@@ -445,7 +533,11 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
             tok = s_tok;
         }
     }
-    if (use_forced) tok = a.forced[(long)b * kTokPerFrame + off + k];
+    if (use_forced) {
+        const int ft = a.forced[(long)b * kTokPerFrame + off + k];
+        if (threadIdx.x == 0 && ft != tok) atomicAdd(a.counters + 5, 1);
+        tok = ft;
+    }
     if (threadIdx.x == 0) toks[off + k] = tok;
     const float* emb = (a.mod == 1) ? a.tb.gmap + (long)tok * E : (a.mod == 3 ? a.tb.gimg + (long)tok * E : a.tb.be + (long)tok * E);
     write_next_input(a, b, j, emb, nullptr);
@@ -456,10 +548,10 @@ void launch_sample_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchK
 __global__ __launch_bounds__(256) void sample_ego_kernel(const float* __restrict__ logits, int vocab, SamplerParams sp,
                                                          const unsigned long long* __restrict__ seeds, int frame_idx,
                                                          const int* __restrict__ forced, int* __restrict__ out_tokens) {
-    __shared__ SampleShared sh;
+    __shared__ SamplerLds sh;
     const int b = blockIdx.x / 3, jq = blockIdx.x % 3;
-    int tok = block_sample_topk(logits + (long)blockIdx.x * vocab, vocab, sp.top_k, sp.temperature,
-                                rng_uniform(seeds[b], frame_idx, kSeq + jq, DRAW_MAIN), -1, sh);
+    int tok = block_sample(sp, logits + (long)blockIdx.x * vocab, vocab, sp.top_k, sp.p,
+                           rng_uniform(seeds[b], frame_idx, kSeq + jq, DRAW_MAIN), -1, sh);
     if (forced) tok = forced[(long)b * kTokPerFrame + jq];
     if (threadIdx.x == 0) out_tokens[b * 3 + jq] = tok;
 }

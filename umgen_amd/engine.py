@@ -152,6 +152,8 @@ class Engine:
         fz = None
         if trace or forced is not None:
             tr = _lib.Trace()
+            counters = np.zeros(8, np.int32)
+            tr.counters = counters.ctypes.data_as(C.POINTER(C.c_int32))
             fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
             if trace:
                 tbuf = {"cond": np.zeros((SEQ_LEN, cfg.n_embd), np.float32),
@@ -170,6 +172,10 @@ class Engine:
             int(control_test), C.byref(smp), frame_idx, C.byref(tr) if tr is not None else None,
             _p64(outs["pose"]), _p64(outs["map"]), _p64(outs["bbox3d"]), _p64(outs["image"])), "frame")
         del keep, fz
+        if tr is not None:
+            tbuf = tbuf if tbuf is not None else {}
+            tbuf["counters"] = dict(zip(("pad_avoid", "control_resample", "rule_checked", "rule_collision", "rule_blanked",
+                                         "sampled_ne_forced"), counters[:6].tolist()))
         return outs, tbuf
 
     # -- measurement ---------------------------------------------------------------------------
