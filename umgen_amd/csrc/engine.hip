@@ -61,6 +61,7 @@ struct umgen_engine {
     // workspace
     float *X = nullptr, *mapfeat = nullptr, *warped_last = nullptr, *cond = nullptr, *pose_diff = nullptr, *pego = nullptr;
     void *A = nullptr, *QKV = nullptr, *VT = nullptr, *Hb = nullptr;
+    float *kvnew = nullptr;
     float *xdec = nullptr, *qdec = nullptr, *part = nullptr, *hdec = nullptr, *logits = nullptr, *logits_tar = nullptr, *qkv3 = nullptr;
     void* kvcache = nullptr;
     long kv_layer_stride = 0, kv_scene_stride = 0;
@@ -75,6 +76,7 @@ struct umgen_engine {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     umgen_timings tm{};
     bool profiling = false;
+    bool fused_decode = false;            // UMGEN_FUSED_DECODE=1 (experiment, see oar_layers)
     // decode step graphs per (kind: fixed / map / bbox3d / image, number of attention key splits 1..8)
     hipGraphExec_t step_graph[4][kAttnSplit + 1] = {};
     int step_graph_B = 0;
@@ -352,18 +354,39 @@ void run_ego(umgen_engine* e, const WindowTokens& w, const SamplerParams& sp, in
 
 // one OAR decode step through the 36 BlockOAR layers (module.py:402-416) for the B scenes
 template <typename T>
-void oar_layers(umgen_engine* e, int B, int ns) {
+void oar_layers(umgen_engine* e, int B, int ns, int ns_cached) {
     const int E = e->E, H = e->H;
     const int* d_len = &e->d_state->step;
     for (size_t li = 0; li < e->oar.size(); ++li) {
         const SubW& w = e->oar[li];
         T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
-        GemvArgs a{};
-        a.x = e->xdec; a.ldx = E; a.ln_w = w.ln_a; a.W = w.attn.Wqkv; a.bias = w.attn.bqkv; a.N = 3 * E; a.K = E; a.M = B;
-        a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len; a.Lmax = e->Lmax; a.E = E;
-        launch_gemv<T>(e->stream, a);
-        launch_attn_partial<T>(e->stream, e->qdec, cache, e->kv_scene_stride, (long)e->Lmax * kHeadDim, kHeadDim, (long)H * e->Lmax * kHeadDim, B, 1, H, d_len, 1, ns, e->part);
-        gemv_resid<T>(e, nullptr, 0, e->part, w.attn.Wo, w.attn.bo, E, E, B, e->xdec, E, ns);
+        if (e->fused_decode) {
+            // EXPERIMENT (UMGEN_FUSED_DECODE=1): q|k|v of the new token + attention partials over the cached keys in ONE launch
+            // (attention blocks recompute their 48 q rows), self term merged in the projection.  Measured slower than the
+            // two-launch form (9.7 + 6.8 us vs 4.8 + 5.5 + 5.5 us per layer): the 74 KB of Wq per attention block is bound by
+            // per-CU load bandwidth.  Kept because it is parity-tested and is the starting point for round 2.
+            QkvAttnArgs qa{};
+            GemvArgs& a = qa.g;
+            a.x = e->xdec; a.ldx = E; a.ln_w = w.ln_a; a.W = w.attn.Wqkv; a.bias = w.attn.bqkv; a.N = 3 * E; a.K = E; a.M = B;
+            a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len;
+            a.Lmax = e->Lmax; a.E = E; a.kv_f32 = e->kvnew;
+            qa.head_stride = (long)e->Lmax * kHeadDim; qa.key_stride = kHeadDim; qa.v_off = (long)H * e->Lmax * kHeadDim; qa.H = H;
+            qa.ns = ns_cached; qa.part = e->part;
+            launch_qkv_attn<T>(e->stream, qa);
+            GemvResidArgs r{};
+            r.part = e->part; r.H = H; r.ns = ns_cached; r.self_q = e->qdec; r.self_kv = e->kvnew;
+            r.W = w.attn.Wo; r.bias = w.attn.bo; r.N = E; r.K = E; r.M = B; r.x = e->xdec; r.ldx = E;
+            launch_gemv_resid<T>(e->stream, r);
+        } else {
+            GemvArgs a{};
+            a.x = e->xdec; a.ldx = E; a.ln_w = w.ln_a; a.W = w.attn.Wqkv; a.bias = w.attn.bqkv; a.N = 3 * E; a.K = E; a.M = B;
+            a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len;
+            a.Lmax = e->Lmax; a.E = E;
+            launch_gemv<T>(e->stream, a);
+            launch_attn_partial<T>(e->stream, e->qdec, cache, e->kv_scene_stride, (long)e->Lmax * kHeadDim, kHeadDim,
+                                   (long)H * e->Lmax * kHeadDim, B, 1, H, d_len, 1, ns, e->part);
+            gemv_resid<T>(e, nullptr, 0, e->part, w.attn.Wo, w.attn.bo, E, E, B, e->xdec, E, ns);
+        }
         gemv<T>(e, e->xdec, E, w.ln_b, w.mlp.Wfc, nullptr, 4 * E, E, B, GEMV_OUT_GELU, e->hdec, 4L * E);
         gemv_resid<T>(e, e->hdec, 4L * E, nullptr, w.mlp.Wproj, nullptr, E, 4 * E, B, e->xdec, E);
     }
@@ -382,10 +405,10 @@ struct FrameIO {
 
 // kernels of one decode step of kind mod (0 fixed token, 1 map, 2 bbox3d, 3 image) for B scenes
 template <typename T>
-int enqueue_step(umgen_engine* e, int B, int mod, int ns, const umgen_trace* tr, int j) {
+int enqueue_step(umgen_engine* e, int B, int mod, int ns, int ns_cached, const umgen_trace* tr, int j) {
     const int E = e->E;
     hipStream_t st = e->stream;
-    oar_layers<T>(e, B, ns);
+    oar_layers<T>(e, B, ns, ns_cached);
     SampleArgs sa{};
     sa.st = e->d_state; sa.tb = e->tb; sa.logits = e->logits; sa.logits_tar = e->logits_tar; sa.ld_logits = 8192;
     sa.cond = e->cond; sa.x_next = e->xdec; sa.tokens = e->d_tokens; sa.prev_box = e->d_prev_box; sa.control_slot = e->d_control;
@@ -514,22 +537,24 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         if (j >= kMapC0 && j < kMapEos) mod = 1;
         else if (j >= kBoxC0 && j < kBoxEos) mod = 2;
         else if (j >= kImgC0 && j < kImgEos) mod = 3;
-        const int ns = attn_nsplit(j + 1);
+        const int ns = attn_nsplit(j + 1);          // key splits over the j cached keys + the new one
+        const int ns_cached = attn_nsplit(j);       // fused-decode experiment: splits over the cached keys only
+        const int gkey = e->fused_decode ? ns_cached : ns;
         if (graphs) {
-            hipGraphExec_t& ge = e->step_graph[mod][ns];
+            hipGraphExec_t& ge = e->step_graph[mod][gkey];
             if (!ge) {
                 hipGraph_t g;
                 HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                enqueue_step<T>(e, B, mod, ns, nullptr, 0);
+                enqueue_step<T>(e, B, mod, ns, ns_cached, nullptr, 0);
                 HIPCHK(e, hipStreamEndCapture(st, &g));
                 HIPCHK(e, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
                 HIPCHK(e, hipGraphDestroy(g));
             }
             HIPCHK(e, hipGraphLaunch(ge, st));
-        } else if (int rc = enqueue_step<T>(e, B, mod, ns, tr, j)) {
+        } else if (int rc = enqueue_step<T>(e, B, mod, ns, ns_cached, tr, j)) {
             return rc;
         }
-        e->tm.oar_kernels += 5 * (int64_t)e->oar.size() + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
+        e->tm.oar_kernels += (e->fused_decode ? 4 : 5) * (int64_t)e->oar.size() + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
     }
     e->tm.oar_steps += kImgEos;
     HIPCHK(e, hipEventRecord(e->ev[3], st));
@@ -631,6 +656,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
     e->E = cfg->n_embd;
     e->H = cfg->n_head;
+    if (const char* fd = getenv("UMGEN_FUSED_DECODE")) e->fused_decode = fd[0] == '1';
     e->tsz = cfg->precision == UMGEN_PREC_BF16 ? 2 : 4;
     const int64_t E = e->E;
     const std::string t = "transformer.";
@@ -726,6 +752,8 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (int rc = dalloc(e, &e->qdec, 3 * Bm * E)) return rc;
     if (int rc = dalloc(e, &e->qkv3, 3 * Bm * 3 * E)) return rc;
     if (int rc = dalloc(e, &e->part, 3 * Bm * e->H * kAttnRec)) return rc;
+    HIPCHK(e, hipMemset(e->part, 0, 3 * Bm * e->H * kAttnRec * sizeof(float)));   // never-written split slots are read with weight 0
+    if (int rc = dalloc(e, &e->kvnew, Bm * 2 * E)) return rc;
     if (int rc = dalloc(e, &e->hdec, 3 * Bm * 4 * E)) return rc;
     if (int rc = dalloc(e, &e->logits, 3 * Bm * 8192)) return rc;
     if (int rc = dalloc(e, &e->logits_tar, Bm * 8192)) return rc;

@@ -38,14 +38,11 @@ __device__ inline void wunpack(const WChunk<float>& w, float (&o)[8]) {
 // out[m][n] = LN(x[m]) . W[n] + bias[n]     K = n_embd (<= 1536): NCH = ceil(K / 512) chunks of 8 per lane
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int MB, int NCH, int RPW>
-__global__ __launch_bounds__(256) void gemv_ln_kernel(GemvArgs a) {
-#ifdef UMGEN_DRY_DECODE
-    return;   // launch-floor experiment: same graph, no work
-#endif
+__device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
-    const int n0 = (blockIdx.x * 4 + wave) * RPW;
+    const int n0 = (bid * 4 + wave) * RPW;
     if (n0 >= a.N) return;
     WChunk<T> w[RPW][NCH];
 #pragma unroll
@@ -142,6 +139,7 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(GemvArgs a) {
                                 const long H = a.E / kHeadDim;
                                 reinterpret_cast<T*>(a.cache)[(long)mm * a.scene_stride + ((kvsel * H + hc / kHeadDim) * a.Lmax + pos) * kHeadDim +
                                                               hc % kHeadDim] = Cvt<T>::from_f(v);
+                                if (a.kv_f32) a.kv_f32[(long)mm * 2 * a.E + c] = v;
                             }
                         } else {
                             a.out[(long)mm * a.ldo + n] = (a.out_mode == GEMV_OUT_GELU) ? gelu_erf(v) : v;
@@ -151,6 +149,14 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(GemvArgs a) {
             }
         }
     }
+}
+
+template <typename T, int MB, int NCH, int RPW>
+__global__ __launch_bounds__(256) void gemv_ln_kernel(GemvArgs a) {
+#ifdef UMGEN_DRY_DECODE
+    return;   // launch-floor experiment: same graph, no work
+#endif
+    gemv_ln_body<T, MB, NCH, RPW>(a, blockIdx.x);
 }
 
 template <typename T, int NCH>
@@ -235,12 +241,32 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
             float mx = -INFINITY;
 #pragma unroll
             for (int sp = 0; sp < kAttnPad; ++sp) { if (sp >= ns) pm[sp] = -INFINITY; mx = fmaxf(mx, pm[sp]); }
+            // the new token's own key (fused decode attention): one more softmax term with l = 1, stored in the last pad slot
+            float s_self = -INFINITY;
+            if (a.self_q) {
+                const int m = tid / a.H, h = tid % a.H;
+                const float* qs = a.self_q + (long)m * K + h * kHeadDim;
+                const float* ks = a.self_kv + (long)m * 2 * K + h * kHeadDim;
+                float d = 0.f;
+#pragma unroll
+                for (int e4 = 0; e4 < kHeadDim; e4 += 4) {
+                    float q4[4], k4[4];
+                    load4(qs + e4, q4);
+                    load4(ks + e4, k4);
+                    d = fmaf(q4[0], k4[0], d); d = fmaf(q4[1], k4[1], d); d = fmaf(q4[2], k4[2], d); d = fmaf(q4[3], k4[3], d);
+                }
+                s_self = d * 0.14433756729740643f;
+                mx = fmaxf(mx, s_self);
+            }
             float l = 0.f;
 #pragma unroll
             for (int sp = 0; sp < kAttnPad; ++sp) { pm[sp] = expf(pm[sp] - mx); l = fmaf(pm[sp], (sp < ns) ? pl[sp] : 0.f, l); }
+            const float w_self = a.self_q ? expf(s_self - mx) : 0.f;
+            l += w_self;
             const float inv = 1.0f / l;
 #pragma unroll
-            for (int sp = 0; sp < kAttnPad; ++sp) s_w[tid * kAttnPad + sp] = pm[sp] * inv;
+            for (int sp = 0; sp < kAttnPad - 1; ++sp) s_w[tid * kAttnPad + sp] = pm[sp] * inv;
+            s_w[tid * kAttnPad + kAttnPad - 1] = w_self * inv;     // kAttnSplit <= kAttnPad - 1, so this slot is never a split
         }
         __syncthreads();
         // 3. fold, 768 columns at a time
@@ -258,8 +284,9 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
                         o = fmaf(w[4 * i], ov[it][i].x, o);
                         o = fmaf(w[4 * i + 1], ov[it][i].y, o);
                         o = fmaf(w[4 * i + 2], ov[it][i].z, o);
-                        o = fmaf(w[4 * i + 3], ov[it][i].w, o);
+                        if (4 * i + 3 < kAttnPad - 1) o = fmaf(w[4 * i + 3], ov[it][i].w, o);
                     }
+                    if (a.self_q) o = fmaf(w[kAttnPad - 1], a.self_kv[(long)m * 2 * K + K + col], o);
                     as[e] = o;
                 }
             }
@@ -330,6 +357,7 @@ void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a0) {
             b.M = min(8, a0.M - m);
             b.part = a0.part + (long)m * a0.H * kAttnRec;
             b.x = a0.x + (long)m * a0.ldx;
+            if (a0.self_q) { b.self_q = a0.self_q + (long)m * a0.K; b.self_kv = a0.self_kv + (long)m * 2 * a0.K; }
             launch_gemv_resid<T>(s, b);
         }
         return;
@@ -358,44 +386,119 @@ template void launch_gemv_resid<bf16_t>(hipStream_t, const GemvResidArgs&);
 constexpr float kScale = 0.14433756729740643f;   // float32(1/sqrt(48)), module.py:196-198
 constexpr int kKeyPass = kAttnChunk / 32;        // keys per thread (32 keys per pass of the 256 threads)
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ kv_base, long scene_stride,
-                                                           long head_stride, long key_stride, long v_off, int q_per_scene, int H,
-                                                           const int* __restrict__ d_len, int len_add, int kmax, float* __restrict__ part) {
-#ifdef UMGEN_DRY_DECODE
-    return;
-#endif
+struct AttnGeom {
+    const float* q;            // [NQ][E] (nullptr when the block computes q itself)
+    const void* kv_base; long scene_stride, head_stride, key_stride, v_off;
+    int q_per_scene, H;
+    const int* d_len; int len_add, kmax;
+    float* part;
+};
+
+// One (head h, key split, query qi) block.  FUSEQ: q_h = (LN(x[qi]) . Wq[h*48 .. h*48+47] + bq) is computed here (wave w
+// owns rows 12w .. 12w+11; every weight byte is requested up front together with the K/V rows).
+template <typename T, bool FUSEQ, int NCH>
+__device__ __forceinline__ void attn_body(const AttnGeom& g, const GemvArgs* ga, int h, int split, int qi) {
     __shared__ float s_max[4];
     __shared__ float s_sum[4];
     __shared__ float s_o[4][kHeadDim];
-    const int h = blockIdx.x, split = blockIdx.y, qi = blockIdx.z;
+    __shared__ __attribute__((aligned(16))) float s_q[kHeadDim];
+    const int H = g.H;
     const int E = H * kHeadDim;
-    // fixed key ranges: the K/V addresses do not depend on the device-side length, so every load below is issued before
-    // *d_len has arrived (rows past L are allocated cache rows; they are masked out of the softmax)
     const int k0 = split * kAttnChunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int piece = tid & 7, kg = tid >> 3;        // 32 key groups
     const bool pact = piece < 6;
-    const T* base = kv_base + (long)(qi / q_per_scene) * scene_stride + h * head_stride + piece * 8;
+    WChunk<T> wq[FUSEQ ? 12 : 1][FUSEQ ? NCH : 1];
+    if (FUSEQ) {
+        const T* W = reinterpret_cast<const T*>(ga->W);
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const T* wr = W + (long)(h * kHeadDim + wave * 12 + r) * E;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane * 8 + 512 * i;
+                if (c < E) wload(wq[r][i], wr + c); else wzero(wq[r][i]);
+            }
+        }
+    }
+    const T* base = reinterpret_cast<const T*>(g.kv_base) + (long)(qi / g.q_per_scene) * g.scene_stride + h * g.head_stride + piece * 8;
     float kf[kKeyPass][8], vf[kKeyPass][8];
 #pragma unroll
     for (int i = 0; i < kKeyPass; ++i) {
-        const int k = min(k0 + kg + 32 * i, kmax - 1);
+        const int k = min(k0 + kg + 32 * i, g.kmax - 1);
         if (pact) {
-            load8(base + (long)k * key_stride, kf[i]);
-            load8(base + (long)k * key_stride + v_off, vf[i]);
+            load8(base + (long)k * g.key_stride, kf[i]);
+            load8(base + (long)k * g.key_stride + g.v_off, vf[i]);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { kf[i][e] = 0.f; vf[i][e] = 0.f; }
         }
     }
     float q8[8];
-    if (pact) load8(q + (long)qi * E + h * kHeadDim + piece * 8, q8);
-    else {
+    if (FUSEQ) {
+        // LayerNorm of x[qi] in registers (chunk layout of the dot products), redundantly per wave
+        float xv[NCH][8], lw[NCH][8];
+        const float* xr = ga->x + (long)qi * ga->ldx;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q8[e] = 0.f;
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < E) { load8(xr + c, xv[i]); load8(ga->ln_w + c, lw[i]); }
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xv[i][e] = 0.f; lw[i][e] = 0.f; }
+            }
+        }
+        float bq = 0.f;
+        if (lane < 12) bq = ga->bias[h * kHeadDim + wave * 12 + lane];
+        float sx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sx += xv[i][e];
+        const float mean = wave_sum(sx) / (float)E;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (lane * 8 + 512 * i < E) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; sq += d * d; }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)E + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (lane * 8 + 512 * i < E) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[i][e] = (xv[i][e] - mean) * rstd * lw[i][e];
+            }
+        float qr = 0.f;   // lane r (< 12) ends up holding row r's dot product
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                float w8[8];
+                wunpack(wq[r][i], w8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(w8[e], xv[i][e], acc);
+            }
+            acc = wave_sum(acc);
+            if (lane == r) qr = acc;
+        }
+        if (lane < 12) s_q[wave * 12 + lane] = qr + bq;
+        __syncthreads();
+        if (pact) load8(s_q + piece * 8, q8);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q8[e] = 0.f;
+        }
+    } else {
+        if (pact) load8(g.q + (long)qi * E + h * kHeadDim + piece * 8, q8);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q8[e] = 0.f;
+        }
     }
-    const int L = (d_len ? *d_len : 0) + len_add;
+    const int L = (g.d_len ? *g.d_len : 0) + g.len_add;
     const int k1 = min(L, k0 + kAttnChunk);
     float sc[kKeyPass];
     float mx = -INFINITY;
@@ -444,18 +547,62 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const float* __restri
     }
     if (lane == 0) s_sum[wave] = ls;
     __syncthreads();
-    float* out = part + ((long)qi * H + h) * kAttnRec;
+    float* out = g.part + ((long)qi * H + h) * kAttnRec;
     if (tid < kHeadDim) out[2 * kAttnPad + tid * kAttnPad + split] = ((s_o[0][tid] + s_o[1][tid]) + s_o[2][tid]) + s_o[3][tid];
     if (tid == 0) { out[split] = mx; out[kAttnPad + split] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3]; }
 }
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_partial_kernel(AttnGeom g) {
+#ifdef UMGEN_DRY_DECODE
+    return;
+#endif
+    attn_body<T, false, 1>(g, nullptr, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// fused decode kernel: blocks [0, nA) = role A (LN + c_attn GEMV of the new token), the rest = role B (attention partials over
+// the cached keys with q recomputed per block)
+template <typename T, int MB, int NCH, int RPW>
+__global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a, AttnGeom g, int nA) {
+#ifdef UMGEN_DRY_DECODE
+    return;
+#endif
+    if ((int)blockIdx.x < nA) {
+        gemv_ln_body<T, MB, NCH, RPW>(a.g, blockIdx.x);
+    } else {
+        const int bid = blockIdx.x - nA;
+        const int h = bid % a.H, split = (bid / a.H) % a.ns, qi = bid / (a.H * a.ns);
+        attn_body<T, true, NCH>(g, &a.g, h, split, qi);
+    }
+}
+
+template <typename T, int NCH>
+static void launch_qkv_attn_nch(hipStream_t s, const QkvAttnArgs& a) {
+    constexpr int RPW = 2;
+    const int nA = (a.g.N + 4 * RPW - 1) / (4 * RPW);
+    AttnGeom g{nullptr, a.g.cache, a.g.scene_stride, a.head_stride, a.key_stride, a.v_off, 1, a.H, a.g.d_len, 0,
+               kAttnSplit * kAttnChunk, a.part};
+    const int grid = nA + a.H * a.ns * a.g.M;
+    if (a.g.M == 1) hipLaunchKernelGGL((qkv_attn_kernel<T, 1, NCH, RPW>), dim3(grid), dim3(256), 0, s, a, g, nA);
+    else if (a.g.M == 2) hipLaunchKernelGGL((qkv_attn_kernel<T, 2, NCH, RPW>), dim3(grid), dim3(256), 0, s, a, g, nA);
+    else hipLaunchKernelGGL((qkv_attn_kernel<T, 4, NCH, RPW>), dim3(grid), dim3(256), 0, s, a, g, nA);
+}
+template <typename T>
+void launch_qkv_attn(hipStream_t s, const QkvAttnArgs& a) {
+    if (a.g.K <= 512) launch_qkv_attn_nch<T, 1>(s, a);
+    else if (a.g.K <= 1024) launch_qkv_attn_nch<T, 2>(s, a);
+    else launch_qkv_attn_nch<T, 3>(s, a);
+}
+template void launch_qkv_attn<float>(hipStream_t, const QkvAttnArgs&);
+template void launch_qkv_attn<bf16_t>(hipStream_t, const QkvAttnArgs&);
 
 template <typename T>
 void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long head_stride, long key_stride, long v_off,
                          int NQ, int q_per_scene, int H, const int* d_len, int len_add, int ns, float* part) {
     // kmax: rows that exist behind kv_base for one (scene, head): loads are clamped to it, the softmax masks by the true length
     const int kmax = d_len ? kAttnSplit * kAttnChunk : len_add;
-    hipLaunchKernelGGL(attn_partial_kernel<T>, dim3(H, ns, NQ), dim3(256), 0, s, q, kv_base, scene_stride, head_stride, key_stride,
-                       v_off, q_per_scene, H, d_len, len_add, kmax, part);
+    AttnGeom g{q, kv_base, scene_stride, head_stride, key_stride, v_off, q_per_scene, H, d_len, len_add, kmax, part};
+    hipLaunchKernelGGL(attn_partial_kernel<T>, dim3(H, ns, NQ), dim3(256), 0, s, g);
 }
 template void launch_attn_partial<float>(hipStream_t, const float*, const float*, long, long, long, long, int, int, int, const int*, int, int, float*);
 template void launch_attn_partial<bf16_t>(hipStream_t, const float*, const bf16_t*, long, long, long, long, int, int, int, const int*, int, int, float*);

@@ -80,6 +80,7 @@ struct GemvArgs {
     int out_mode;
     float* out; long ldo;
     void* cache; long scene_stride; const int* d_len; int Lmax;   // GEMV_OUT_QKV
+    float* kv_f32;                 // GEMV_OUT_QKV, optional: fp32 copy [M][2E] of the new k | v rows (self term of the fused decode attention)
     int E;
 };
 template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
@@ -89,9 +90,23 @@ template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
 struct GemvResidArgs {
     const float* a; long lda; const float* part; int H;
     int ns;                          // number of attention splits to merge (attn_nsplit of the key count)
+    const float* self_q;             // optional [M][E]: the current token attends to itself with these q / k|v rows (fp32), merged as one
+    const float* self_kv;            // more softmax term (the fused decode attention only covers the cached keys)  [M][2E]
     const void* W; const float* bias; int N, K, M;
     float* x; long ldx;
 };
 template <typename T> void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a);
+
+// Fused decode kernel: ONE launch computes q | k | v of the new token (role A: the LN + c_attn GEMV, K/V appended to the cache)
+// and, concurrently, the attention partials of every (scene, head, key split) over the cached keys < *d_len (role B: those
+// blocks recompute their own 48 rows of q from x -- 74 KB of weights -- instead of waiting for role A).  The new token's
+// self-attention term is merged by launch_gemv_resid (self_q / self_kv).
+struct QkvAttnArgs {
+    GemvArgs g;            // role A: out_mode GEMV_OUT_QKV, M scenes
+    long head_stride, key_stride, v_off;   // cache geometry (see launch_attn_partial)
+    int H, ns;             // heads, key splits to launch (attn_nsplit of the cached length)
+    float* part;
+};
+template <typename T> void launch_qkv_attn(hipStream_t s, const QkvAttnArgs& a);
 
 }  // namespace umgen
