@@ -174,3 +174,34 @@ def test_fp32_sampled_frame_exercises_pad_avoid_and_matches_oracle_counters():
     assert c["rule_checked"] == o.counters.get("rule_checked", 0)
     assert c["rule_blanked"] == o.counters.get("rule_blanked", 0)
     e.close()
+
+
+def test_edge_cases_single_history_frame_zero_new_frames_and_errors():
+    """Ragged / degenerate calls: T_in = 1 history frame (window grows 1 -> 2), new_frames = 0 (history returned unchanged),
+    B = 3 with max_batch = 3, and loud failures on invalid arguments (no silent fallback)."""
+    from umgen_amd.engine import UMGenError
+    cfg = tiny_config().greedy()
+    sd = synthetic_state_dict(cfg, seed=9)
+    e = make_engine(cfg, 9, "fp32", max_batch=3)
+    scene = synthetic_scene(30, n_frames=1)
+    ref = OracleUMGen(cfg, sd).inference(2, 2, scene, input_cond_frames=1)     # window: 1 -> 2 -> slides
+    out = e.rollout(scene, 2, cond_frames=2, input_cond_frames=1, seeds=[0])
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(out[m], ref[m], err_msg=m)
+    same = e.rollout(scene, 0, cond_frames=2, input_cond_frames=1, seeds=[0])
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(same[m], scene[m])
+    three = {m: np.concatenate([synthetic_scene(30 + i, n_frames=1)[m] for i in range(3)]) for m in MOD_ORDER}
+    out3 = e.rollout(three, 1, cond_frames=2, input_cond_frames=1, seeds=[0, 0, 0])
+    np.testing.assert_array_equal(out3["map"][0], out["map"][0, :2])
+    with pytest.raises(UMGenError):
+        e.rollout({m: np.concatenate([three[m], three[m]]) for m in MOD_ORDER}, 1, cond_frames=2, input_cond_frames=1)   # B = 6 > max_batch
+    with pytest.raises(UMGenError):
+        e.rollout(scene, 1, cond_frames=99, input_cond_frames=1)                                                       # window > max_cond_frames
+    e2 = Engine(cfg, precision="fp32", max_batch=1, max_cond_frames=2)
+    with pytest.raises(UMGenError):
+        e2.finalize()                                                                                                   # weights missing
+    with pytest.raises(UMGenError):
+        e2.load_tensor("transformer.spe.weight", np.zeros((7, 7), np.float32))                                          # wrong shape
+    e2.close()
+    e.close()
