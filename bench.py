@@ -32,6 +32,30 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak
 
 
+def pmc_traffic_per_step(cfg):
+    """HBM bytes per decode step from the committed rocprofv3 PMC pass (profiles/r01_pmc_fetch_size.csv: mean FETCH_SIZE [KB]
+    per launch of each kernel at KV length ~2000; x2 = the gfx950 correction of MI355X_MICROARCH.md for wide streaming reads).
+    PMC serialises every dispatch, so it cannot be collected inside the timed region; null when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.csv")
+    if not os.path.exists(path):
+        return None
+    per_kernel = {}
+    for line in open(path).read().splitlines()[1:]:
+        name, _, rest = line.rpartition('",')
+        f = rest.split(",")
+        per_kernel[name.strip('"')] = float(f[2])
+    def mean(sub):
+        for k, v in per_kernel.items():
+            if sub in k:
+                return v
+        return 0.0
+    L = cfg.n_oar_layer
+    kb = L * (2 * mean("gemv_ln_kernel<unsigned short, 1") + mean("attn_partial_kernel<unsigned short>") +
+              mean("gemv_resid_kernel<unsigned short, 1, 6, false>") + mean("gemv_resid_kernel<unsigned short, 1, 2, true>"))
+    kb += mean("gemv_ln_kernel<unsigned short, 1")      # head GEMV
+    return kb * 2.0 * 1024.0
+
+
 def cpu_baseline(cfg_name: str, threads: int):
     """The CPU oracle ("port" of the reference path) timed on this box's host cores on a BOUNDED sample:
     one full-size BlockTAR per stack sequence length (S = 1031, 1693, 2207; T = 20) and 16 OAR decode steps at
@@ -138,8 +162,11 @@ def main():
         total_scenes = B * world
         value = total_scenes * args.steps * SEQ_LEN / dt
         frames = max(1, tm["frames"])
-        # dominant kernel: the bf16 MFMA GEMM of the TAR/ego stacks (per-launch HIP events on the engine stream)
         gemm_tfs = (tm["gemm_flops"] / (tm["gemm_ms"] * 1e-3) / 1e12) if tm["gemm_ms"] > 0 else 0.0
+        attn_tfs = (tm["attn_flops"] / (tm["attn_ms"] * 1e-3) / 1e12) if tm["attn_ms"] > 0 else 0.0
+        steps_total = max(1, tm["oar_steps"])
+        step_us = tm["oar_ms"] * 1e3 / steps_total
+        bytes_per_step = tm["oar_bytes"] / steps_total / B        # algorithmic: weights once + KV read/write
         oar_gbs = (tm["oar_bytes"] / (tm["oar_ms"] * 1e-3) / 1e9) if tm["oar_ms"] > 0 else 0.0
         res = {
             "metric": "scene_tokens_per_sec", "value": value, "unit": "scene-tokens/s", "n_gpus": world,
@@ -149,13 +176,19 @@ def main():
             "config": {"workload": f"UMGen_{args.config} --infer_task video, {args.steps}-frame rollout, "
                                    f"{B} scene(s)/GPU, T={T} history frames, top-k 5/5/16 sampling, rule_constrain",
                        "scenes_per_gpu": B, "history_frames": T, "sec_per_frame": dt / args.steps},
-            "roofline": {"bound": "mfma", "achieved": gemm_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                         "frac": gemm_tfs / MFMA_BF16_PEAK_TFS, "traffic": None,
-                         "kernel": "gemm_bf16_mfma_kernel (TAR/ego stacks)",
-                         "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(1, tm["gemm_launches"])},
-            "roofline_decode": {"bound": "hbm", "achieved": oar_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": oar_gbs / HBM_PEAK_GBS, "traffic": None,
-                                "scope": "whole OAR decode phase (algorithmic bytes of all steps / event-timed phase)"},
+            # dominant unit of work (~80 % of the frame): the OAR decode step = 36 x (gemv_ln, attn_partial, gemv_resid,
+            # gemv_ln, gemv_resid) + head + sampler, replayed from a hipGraph; HIP events bracket the decode phase of every frame
+            "roofline": {"bound": "hbm", "achieved": oar_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": oar_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic_per_step(cfg),
+                         "kernel": "OAR decode step (gemv_ln_kernel x73, attn_partial_kernel x36, gemv_resid_kernel x72, sample_token_kernel)",
+                         "launches": tm["oar_kernels"], "avg_launch_us": tm["oar_ms"] * 1e3 / max(1, tm["oar_kernels"]),
+                         "avg_step_us": step_us, "algorithmic_bytes_per_step": bytes_per_step},
+            "roofline_gemm": {"bound": "mfma", "achieved": gemm_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+                              "frac": gemm_tfs / MFMA_BF16_PEAK_TFS, "kernel": "gemm_bf16_glds_kernel (TAR/ego stacks)",
+                              "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(1, tm["gemm_launches"])},
+            "roofline_attn": {"bound": "mfma", "achieved": attn_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+                              "frac": attn_tfs / MFMA_BF16_PEAK_TFS, "kernel": "attn_spatial_mfma_kernel",
+                              "launches": tm["attn_launches"], "avg_launch_ms": tm["attn_ms"] / max(1, tm["attn_launches"])},
             "phases_ms_per_frame": {"ego": tm["ego_ms"] / frames, "tar": tm["tar_ms"] / frames, "oar": tm["oar_ms"] / frames},
             "weight_load_s": t_load,
         }

@@ -93,6 +93,9 @@ typedef struct umgen_timings {
     int64_t gemm_launches;
     double gemm_flops;      /* algorithmic FLOPs of those launches */
     double oar_bytes;       /* algorithmic HBM bytes of the decode steps */
+    double attn_ms;         /* sum over launches of the spatial attention kernel (when profiling enabled) */
+    int64_t attn_launches;
+    double attn_flops;
 } umgen_timings;
 
 /* UMGen(config)  -- UMGen.py:53 */

@@ -49,7 +49,8 @@ class Trace(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("ego_ms", C.c_double), ("tar_ms", C.c_double), ("oar_ms", C.c_double),
                 ("frames", C.c_int64), ("oar_steps", C.c_int64), ("oar_kernels", C.c_int64),
-                ("gemm_ms", C.c_double), ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("oar_bytes", C.c_double)]
+                ("gemm_ms", C.c_double), ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("oar_bytes", C.c_double),
+                ("attn_ms", C.c_double), ("attn_launches", C.c_int64), ("attn_flops", C.c_double)]
 
 
 def hipcc_path() -> str:

@@ -80,9 +80,9 @@ struct umgen_engine {
     // decode step graphs per (kind: fixed / map / bbox3d / image, number of attention key splits 1..8)
     hipGraphExec_t step_graph[4][kAttnSplit + 1] = {};
     int step_graph_B = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev;
-    size_t gemm_ev_used = 0;
-    double gemm_flops_pending = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev, attn_ev;
+    size_t gemm_ev_used = 0, attn_ev_used = 0;
+    double gemm_flops_pending = 0, attn_flops_pending = 0;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -279,7 +279,21 @@ void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal
         g.Mi = S; g.Nj = E; g.K = E; g.ldp = E; g.ldq = E; g.strideP = (long)S * E; g.strideQ = 0; g.batch = B * Tn;
         g.mode = GEMM_VT; g.bias = w.attn.bqkv + 2 * E; g.out = e->VT; g.ldo = e->S_pad; g.H = H;
         gemm_timed<T>(e, g);
-        Path<T>::attn_spatial(e->stream, QKV, reinterpret_cast<const T*>(e->VT), A, B * Tn, S, e->S_pad, H);
+        if (e->profiling) {
+            if (e->attn_ev_used == e->attn_ev.size()) {
+                hipEvent_t a0, a1;
+                hipEventCreate(&a0);
+                hipEventCreate(&a1);
+                e->attn_ev.emplace_back(a0, a1);
+            }
+            auto& pr = e->attn_ev[e->attn_ev_used++];
+            hipEventRecord(pr.first, e->stream);
+            Path<T>::attn_spatial(e->stream, QKV, reinterpret_cast<const T*>(e->VT), A, B * Tn, S, e->S_pad, H);
+            hipEventRecord(pr.second, e->stream);
+            e->attn_flops_pending += 4.0 * (double)S * (double)S * kHeadDim * (double)H * (double)(B * Tn);
+        } else {
+            Path<T>::attn_spatial(e->stream, QKV, reinterpret_cast<const T*>(e->VT), A, B * Tn, S, e->S_pad, H);
+        }
     }
     linear_resid<T>(e, w.attn.Wo, w.attn.bo, E, E, A, R, e->X);
     launch_layernorm<T>(e->stream, e->X, E, R, E, w.ln_b, A);
@@ -576,6 +590,14 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         e->tm.gemm_flops += e->gemm_flops_pending;
         e->gemm_ev_used = 0;
         e->gemm_flops_pending = 0;
+        for (size_t i = 0; i < e->attn_ev_used; ++i) {
+            hipEventElapsedTime(&ms, e->attn_ev[i].first, e->attn_ev[i].second);
+            e->tm.attn_ms += ms;
+        }
+        e->tm.attn_launches += (int64_t)e->attn_ev_used;
+        e->tm.attn_flops += e->attn_flops_pending;
+        e->attn_ev_used = 0;
+        e->attn_flops_pending = 0;
     }
     // algorithmic HBM bytes of this frame's decode steps: weights once per step + KV read + KV write
     {
@@ -1001,6 +1023,7 @@ int umgen_destroy(umgen_engine* e) {
     for (void* p : e->allocs) hipFree(p);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : e->gemm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : e->attn_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (e->tb.gmap) {}   // tables are in allocs
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
