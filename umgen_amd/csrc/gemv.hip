@@ -17,10 +17,27 @@ template <typename T> struct WChunk;                      // 8 consecutive weigh
 template <> struct WChunk<bf16_t> { uint4 v; };
 template <> struct WChunk<float> { float4 a, b; };
 
-__device__ inline void wload(WChunk<bf16_t>& w, const bf16_t* p) { w.v = *reinterpret_cast<const uint4*>(p); }
+// weights are streamed exactly once per launch: non-temporal loads (MI355X_MICROARCH.md "nt-weights": issue->landed -18 %)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+__device__ inline void wload(WChunk<bf16_t>& w, const bf16_t* p) {
+#ifndef UMGEN_NO_NT
+    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    w.v = make_uint4(t.x, t.y, t.z, t.w);
+#else
+    w.v = *reinterpret_cast<const uint4*>(p);
+#endif
+}
 __device__ inline void wload(WChunk<float>& w, const float* p) {
+#ifndef UMGEN_NO_NT
+    const f32x4v_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4v_t*>(p));
+    const f32x4v_t b = __builtin_nontemporal_load(reinterpret_cast<const f32x4v_t*>(p + 4));
+    w.a = make_float4(a.x, a.y, a.z, a.w);
+    w.b = make_float4(b.x, b.y, b.z, b.w);
+#else
     w.a = *reinterpret_cast<const float4*>(p);
     w.b = *reinterpret_cast<const float4*>(p + 4);
+#endif
 }
 __device__ inline void wzero(WChunk<bf16_t>& w) { w.v = make_uint4(0, 0, 0, 0); }
 __device__ inline void wzero(WChunk<float>& w) { w.a = make_float4(0, 0, 0, 0); w.b = w.a; }
@@ -133,7 +150,7 @@ __device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
                     if (mm < a.M) {
                         const float v = acc[m] + bias[r];
                         if (a.out_mode == GEMV_OUT_QKV) {
-                            if (n < a.E) a.out[(long)mm * a.ldo + n] = v;
+                            if (n < a.E) __builtin_nontemporal_store(v, &a.out[(long)mm * a.ldo + n]);
                             else {
                                 const int c = n - a.E, kvsel = c / a.E, hc = c % a.E;   // kvsel 0 = K, 1 = V
                                 const long H = a.E / kHeadDim;
@@ -142,7 +159,7 @@ __device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
                                 if (a.kv_f32) a.kv_f32[(long)mm * 2 * a.E + c] = v;
                             }
                         } else {
-                            a.out[(long)mm * a.ldo + n] = (a.out_mode == GEMV_OUT_GELU) ? gelu_erf(v) : v;
+                            __builtin_nontemporal_store((a.out_mode == GEMV_OUT_GELU) ? gelu_erf(v) : v, &a.out[(long)mm * a.ldo + n]);
                         }
                     }
                 }
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
         if (lane == 0) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
-                if (m0 + m < a.M) a.x[(long)(m0 + m) * a.ldx + n] = xold[m] + (acc[m] + bias);
+                if (m0 + m < a.M) __builtin_nontemporal_store(xold[m] + (acc[m] + bias), &a.x[(long)(m0 + m) * a.ldx + n]);
         }
     }
 }
@@ -426,9 +443,12 @@ __device__ __forceinline__ void attn_body(const AttnGeom& g, const GemvArgs* ga,
 #pragma unroll
     for (int i = 0; i < kKeyPass; ++i) {
         const int k = min(k0 + kg + 32 * i, g.kmax - 1);
-        if (pact) {
-            load8(base + (long)k * g.key_stride, kf[i]);
-            load8(base + (long)k * g.key_stride + g.v_off, vf[i]);
+        if (pact) {   // cached K/V rows are read once per step: non-temporal, like the weights
+            WChunk<T> ck, cv;
+            wload(ck, base + (long)k * g.key_stride);
+            wload(cv, base + (long)k * g.key_stride + g.v_off);
+            wunpack(ck, kf[i]);
+            wunpack(cv, vf[i]);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { kf[i][e] = 0.f; vf[i][e] = 0.f; }
