@@ -286,9 +286,10 @@ template void launch_attn_spatial_valu<bf16_t>(hipStream_t, const bf16_t*, const
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTmax = 32;
 template <typename T, int HG>
-__global__ __launch_bounds__(128) void attn_temporal_kernel(const T* __restrict__ qkv, T* __restrict__ y, int T_, int S, int H) {
+__global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* __restrict__ qkv, T* __restrict__ y, int T_, int S, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [T][3][HG*48]
     constexpr int W = HG * kHeadDim;
+    constexpr int NT = HG * kTmax * 4;
     const int hg = blockIdx.x % (H / HG);
     const long bs = blockIdx.x / (H / HG);          // b*S + s
     const int s = (int)(bs % S);
@@ -296,44 +297,66 @@ __global__ __launch_bounds__(128) void attn_temporal_kernel(const T* __restrict_
     const int E = H * kHeadDim;
     const long ld = 3L * E;
     const int tid = threadIdx.x;
-    const int chunks_per_seg = W / 8;
+    constexpr int chunks_per_seg = W / 8;
     const int n_chunks = T_ * 3 * chunks_per_seg;
-    for (int c = tid; c < n_chunks; c += 128) {
-        const int cc = c % chunks_per_seg, seg = (c / chunks_per_seg) % 3, t = c / (3 * chunks_per_seg);
-        float v8[8];
-        load8(qkv + (((long)b * T_ + t) * S + s) * ld + (long)seg * E + hg * W + cc * 8, v8);
-        float* d = sm + ((t * 3 + seg) * W + cc * 8);
+    constexpr int kIter = (kTmax * 3 * chunks_per_seg + NT - 1) / NT;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] = v8[e];
+    for (int it = 0; it < kIter; ++it) {   // all 16-byte loads of the thread are in flight together
+        const int c = tid + NT * it;
+        if (c < n_chunks) {
+            const int cc = c % chunks_per_seg, seg = (c / chunks_per_seg) % 3, t = c / (3 * chunks_per_seg);
+            float v8[8];
+            load8(qkv + (((long)b * T_ + t) * S + s) * ld + (long)seg * E + hg * W + cc * 8, v8);
+            float* d = sm + ((t * 3 + seg) * W + cc * 8);
+            *reinterpret_cast<float4*>(d) = make_float4(v8[0], v8[1], v8[2], v8[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(v8[4], v8[5], v8[6], v8[7]);
+        }
     }
     __syncthreads();
-    const int hl = tid / kTmax, tq = tid % kTmax;
-    if (hl >= HG || tq >= T_) return;
-    float q[kHeadDim], o[kHeadDim];
-    const float* qp = sm + (tq * 3 + 0) * W + hl * kHeadDim;
+    // 4 lanes per (head, query frame): lane part p owns head-dim slice [12p, 12p+12)
+    const int part = tid & 3, tq = (tid >> 2) % kTmax, hl = tid / (4 * kTmax);
+    const bool active = tq < T_;
+    float q[12], o[12];
+    const float* qp = sm + ((active ? tq : 0) * 3 + 0) * W + hl * kHeadDim + part * 12;
 #pragma unroll
-    for (int d = 0; d < kHeadDim; ++d) { q[d] = qp[d]; o[d] = 0.f; }
+    for (int d = 0; d < 12; d += 4) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qp + d);
+        q[d] = q4.x; q[d + 1] = q4.y; q[d + 2] = q4.z; q[d + 3] = q4.w;
+        o[d] = 0.f; o[d + 1] = 0.f; o[d + 2] = 0.f; o[d + 3] = 0.f;
+    }
     float m = -INFINITY, l = 0.f;
-#pragma unroll 1
-    for (int tk = 0; tk <= tq; ++tk) {
-        const float* kp = sm + (tk * 3 + 1) * W + hl * kHeadDim;
+    const int tmax = active ? tq : -1;
+    for (int tk = 0; tk < T_; ++tk) {      // uniform trip count (shuffles below need the 4 partner lanes); masked past tq
+        const float* kp = sm + (tk * 3 + 1) * W + hl * kHeadDim + part * 12;
         const float* vp = kp + W;
         float a = 0.f;
 #pragma unroll
-        for (int d = 0; d < kHeadDim; ++d) a = fmaf(q[d], kp[d], a);
-        a *= kScale;
-        const float mn = fmaxf(m, a);
-        const float alpha = expf(m - mn);
-        const float p = expf(a - mn);
-        m = mn;
-        l = l * alpha + p;
+        for (int d = 0; d < 12; d += 4) {
+            const float4 k4 = *reinterpret_cast<const float4*>(kp + d);
+            a = fmaf(q[d], k4.x, a); a = fmaf(q[d + 1], k4.y, a); a = fmaf(q[d + 2], k4.z, a); a = fmaf(q[d + 3], k4.w, a);
+        }
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        if (tk <= tmax) {
+            a *= kScale;
+            const float mn = fmaxf(m, a);
+            const float alpha = expf(m - mn);
+            const float p = expf(a - mn);
+            m = mn;
+            l = l * alpha + p;
 #pragma unroll
-        for (int d = 0; d < kHeadDim; ++d) o[d] = fmaf(p, vp[d], o[d] * alpha);
+            for (int d = 0; d < 12; d += 4) {
+                const float4 v4 = *reinterpret_cast<const float4*>(vp + d);
+                o[d] = fmaf(p, v4.x, o[d] * alpha); o[d + 1] = fmaf(p, v4.y, o[d + 1] * alpha);
+                o[d + 2] = fmaf(p, v4.z, o[d + 2] * alpha); o[d + 3] = fmaf(p, v4.w, o[d + 3] * alpha);
+            }
+        }
     }
+    if (!active) return;
     const float inv = 1.0f / l;
-    T* yp = y + (((long)b * T_ + tq) * S + s) * (long)E + (hg * HG + hl) * kHeadDim;
+    T* yp = y + (((long)b * T_ + tq) * S + s) * (long)E + (hg * HG + hl) * kHeadDim + part * 12;
 #pragma unroll
-    for (int d = 0; d < kHeadDim; d += 4) {
+    for (int d = 0; d < 12; d += 4) {
         float t4[4] = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
         store4(yp + d, t4);
     }
@@ -341,16 +364,16 @@ __global__ __launch_bounds__(128) void attn_temporal_kernel(const T* __restrict_
 
 template <typename T>
 void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int T_, int S, int H) {
-    // T_ <= kTmax (32 >= max_cond_frames checked at engine creation); 4 heads per workgroup when H allows
+    // T_ <= kTmax (checked at engine creation); 4 heads per workgroup when H allows
     if (H % 4 == 0) {
         const size_t shm = (size_t)T_ * 3 * 4 * kHeadDim * sizeof(float);
-        hipLaunchKernelGGL((attn_temporal_kernel<T, 4>), dim3((unsigned)((long)B * S * (H / 4))), dim3(128), shm, s, qkv, y, T_, S, H);
+        hipLaunchKernelGGL((attn_temporal_kernel<T, 4>), dim3((unsigned)((long)B * S * (H / 4))), dim3(4 * kTmax * 4), shm, s, qkv, y, T_, S, H);
     } else if (H % 2 == 0) {
         const size_t shm = (size_t)T_ * 3 * 2 * kHeadDim * sizeof(float);
-        hipLaunchKernelGGL((attn_temporal_kernel<T, 2>), dim3((unsigned)((long)B * S * (H / 2))), dim3(128), shm, s, qkv, y, T_, S, H);
+        hipLaunchKernelGGL((attn_temporal_kernel<T, 2>), dim3((unsigned)((long)B * S * (H / 2))), dim3(2 * kTmax * 4), shm, s, qkv, y, T_, S, H);
     } else {
         const size_t shm = (size_t)T_ * 3 * 1 * kHeadDim * sizeof(float);
-        hipLaunchKernelGGL((attn_temporal_kernel<T, 1>), dim3((unsigned)((long)B * S * H)), dim3(128), shm, s, qkv, y, T_, S, H);
+        hipLaunchKernelGGL((attn_temporal_kernel<T, 1>), dim3((unsigned)((long)B * S * H)), dim3(1 * kTmax * 4), shm, s, qkv, y, T_, S, H);
     }
 }
 template void launch_attn_temporal<float>(hipStream_t, const float*, float*, int, int, int, int);

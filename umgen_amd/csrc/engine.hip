@@ -895,8 +895,8 @@ static int check_sampling(umgen_engine* e, const umgen_sampling* s) {
     if (!s) return e->fail(UMGEN_E_INVALID, "sampling is null");
     if (s->method != UMGEN_SAMPLE_TOPK && s->method != UMGEN_SAMPLE_TOPP) return e->fail(UMGEN_E_INVALID, "sample method %d", s->method);
     if (s->method == UMGEN_SAMPLE_TOPP && !(s->p > 0.f && s->p_map > 0.f)) return e->fail(UMGEN_E_INVALID, "top-p mass must be > 0");
-    if (s->top_k < 1 || s->top_k > 32 || s->top_k_map < 1 || s->top_k_map > 32 || s->topk_image < 1 || s->topk_image > 32)
-        return e->fail(UMGEN_E_INVALID, "top-k values must be in [1, 32]");
+    if (s->top_k < 1 || s->top_k > 16 || s->top_k_map < 1 || s->top_k_map > 16 || s->topk_image < 1 || s->topk_image > 16)
+        return e->fail(UMGEN_E_INVALID, "top-k values must be in [1, 16] (reference: 5 / 5 / 16)");
     if (!(s->temperature > 0.f)) return e->fail(UMGEN_E_INVALID, "temperature must be > 0");
     return 0;
 }

@@ -203,7 +203,7 @@ __device__ inline void finish_step(OarState* st) {
 // sampling on the build's counter-based uniform (bit-for-bit the oracle's OracleUMGen.sample)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxKept = 64;
-constexpr int kMaxK = 32;
+constexpr int kMaxK = 16;   // top-k <= 16 (the reference uses 5 / 5 / 16): 4 waves x 16 candidates = one per lane of wave 0
 struct SampleShared {
     float cand_v[4 * kMaxK];
     int cand_i[4 * kMaxK];
@@ -216,7 +216,9 @@ struct SampleShared {
 
 // all 256 threads call; returns the sampled index.  mask_idx (>=0) is treated as -inf.
 // k-th largest value: every wave extracts its own top-k (k rounds of register arg-max + two DPP wave reductions, no
-// barriers), thread 0 merges the 4k candidates.
+// barriers); wave 0 then holds the 4k candidates one per lane and ranks them with uniform readlane loops.  The final
+// softmax / inverse-CDF walk is sequential in ascending token index (bit-for-bit the oracle's order) but runs on
+// register values fetched with v_readlane, not on LDS round trips.
 __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k, float temp, float u, int mask_idx, SampleShared& sh) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float v[32];
@@ -226,6 +228,9 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
         v[i] = (idx < V && idx != mask_idx) ? logits[idx] : -INFINITY;
     }
     const int kk = min(min(k, V), kMaxK);
+    if (tid < 4 * kMaxK) { sh.cand_v[tid] = -INFINITY; sh.cand_i[tid] = 0x7fffffff; }
+    if (tid == 0) sh.n_kept = 0;
+    __syncthreads();
     for (int it = 0; it < kk; ++it) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
@@ -244,20 +249,17 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        // k-th largest of the union of the four descending per-wave lists (4-way merge by value)
-        int p[4] = {0, 0, 0, 0};
-        float kth = -INFINITY;
-        for (int it = 0; it < kk; ++it) {
-            int bw = -1;
-            float bvv = -INFINITY;
-            for (int w2 = 0; w2 < 4; ++w2)
-                if (p[w2] < kk && (bw < 0 || sh.cand_v[w2 * kMaxK + p[w2]] > bvv)) { bw = w2; bvv = sh.cand_v[w2 * kMaxK + p[w2]]; }
-            kth = bvv;
-            ++p[bw];
+    if (wave == 0) {
+        // rank of each candidate = number of candidates that precede it (greater value, or equal value and lower index)
+        const float cv = sh.cand_v[lane];
+        const int ci = sh.cand_i[lane];
+        int rank = 0;
+        for (int j = 0; j < 4 * kMaxK; ++j) {
+            const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j));
+            const int oi = __builtin_amdgcn_readlane(ci, j);
+            rank += (ov > cv || (ov == cv && oi < ci)) ? 1 : 0;
         }
-        sh.kth = kth;
-        sh.n_kept = 0;
+        if (rank == kk - 1) sh.kth = cv;   // exactly one lane (ranks are a permutation)
     }
     __syncthreads();
     const float kth = sh.kth;
@@ -269,28 +271,29 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {
         const int n = min(sh.n_kept, kMaxKept);
-        for (int a = 1; a < n; ++a) {   // insertion sort by index
-            const int ki = sh.kept_i[a];
-            const float kv = sh.kept_v[a];
-            int bpos = a - 1;
-            while (bpos >= 0 && sh.kept_i[bpos] > ki) { sh.kept_i[bpos + 1] = sh.kept_i[bpos]; sh.kept_v[bpos + 1] = sh.kept_v[bpos]; --bpos; }
-            sh.kept_i[bpos + 1] = ki;
-            sh.kept_v[bpos + 1] = kv;
-        }
-        float zmax = -INFINITY;
-        for (int a = 0; a < n; ++a) { sh.kept_v[a] = sh.kept_v[a] / temp; zmax = fmaxf(zmax, sh.kept_v[a]); }
+        // sort the kept set by token index: rank by uniform readlane loop, scatter through LDS, read back sorted
+        const int ki = lane < n ? sh.kept_i[lane] : 0x7fffffff;
+        const float kv = lane < n ? sh.kept_v[lane] : -INFINITY;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (__builtin_amdgcn_readlane(ki, j) < ki) ? 1 : 0;
+        if (lane < n) { sh.cand_i[rank] = ki; sh.cand_v[rank] = kv; }
+        __builtin_amdgcn_wave_barrier();
+        const int si = lane < n ? sh.cand_i[lane] : 0;
+        const float z = lane < n ? sh.cand_v[lane] / temp : -INFINITY;
+        const float zmax = wave_max(z);
+        const float ev = lane < n ? expf(z - zmax) : 0.f;
         float total = 0.f;
-        for (int a = 0; a < n; ++a) { sh.kept_v[a] = expf(sh.kept_v[a] - zmax); total = __fadd_rn(total, sh.kept_v[a]); }
+        for (int a = 0; a < n; ++a) total = __fadd_rn(total, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev), a)));
         const float target = __fmul_rn(u, total);
         float c = 0.f;
-        int res = sh.kept_i[n - 1];
+        int res = __builtin_amdgcn_readlane(si, n - 1);
         for (int a = 0; a < n; ++a) {
-            c = __fadd_rn(c, sh.kept_v[a]);
-            if (c > target) { res = sh.kept_i[a]; break; }
+            c = __fadd_rn(c, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev), a)));
+            if (c > target) { res = __builtin_amdgcn_readlane(si, a); break; }
         }
-        sh.result = res;
+        if (lane == 0) sh.result = res;
     }
     __syncthreads();
     const int r = sh.result;
