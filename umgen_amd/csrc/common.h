@@ -69,6 +69,12 @@ __device__ inline int wave_min_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// DPP lane exchanges inside a row of 16 lanes (one VALU op each, no LDS crossbar round trip)
+__device__ inline float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)); }   // quad_perm [1,0,3,2]
+__device__ inline float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)); }   // quad_perm [2,3,0,1]
+__device__ inline float dpp_half_mirror(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true)); }   // lane i <- lane 7-i (per 8)
+__device__ inline float dpp_xor8(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true)); }   // row_ror:8
+
 // exact GELU (nn.GELU default, module.py:239): 0.5 x (1 + erf(x / sqrt(2)))
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -416,8 +416,8 @@ struct AttnGeom {
 template <typename T, bool FUSEQ, int NCH>
 __device__ __forceinline__ void attn_body(const AttnGeom& g, const GemvArgs* ga, int h, int split, int qi) {
     __shared__ float s_max[4];
-    __shared__ float s_sum[4];
-    __shared__ float s_o[4][kHeadDim];
+    __shared__ float s_sum[16];
+    __shared__ float s_o[16][kHeadDim];          // one partial per (wave, row of 16 lanes)
     __shared__ __attribute__((aligned(16))) float s_q[kHeadDim];
     const int H = g.H;
     const int E = H * kHeadDim;
@@ -527,16 +527,14 @@ __device__ __forceinline__ void attn_body(const AttnGeom& g, const GemvArgs* ga,
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) d = fmaf(q8[e], kf[i][e], d);
-        d += __shfl_xor(d, 1);
-        d += __shfl_xor(d, 2);
-        d += __shfl_xor(d, 4);
+        d += dpp_xor1(d);            // sum over the 8 lanes of the key (pieces 6, 7 hold zeros)
+        d += dpp_xor2(d);
+        d += dpp_half_mirror(d);
         d = (k0 + kg + 32 * i < k1) ? d * kScale : -INFINITY;
         sc[i] = d;
         mx = fmaxf(mx, d);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 8));
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = wave_max(mx);
     if (lane == 0) s_max[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
@@ -551,25 +549,31 @@ __device__ __forceinline__ void attn_body(const AttnGeom& g, const GemvArgs* ga,
 #pragma unroll
         for (int e = 0; e < 8; ++e) o8[e] = fmaf(p, vf[i][e], o8[e]);
     }
-    // reduce over the 8 key groups of the wave (lanes with equal piece): xor 8, 16, 32
+    // the two key groups of a 16-lane row are folded with one DPP rotate; the 4 rows x 4 waves meet in LDS
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        o8[e] += __shfl_xor(o8[e], 8);
-        o8[e] += __shfl_xor(o8[e], 16);
-        o8[e] += __shfl_xor(o8[e], 32);
-    }
-    ls += __shfl_xor(ls, 8);
-    ls += __shfl_xor(ls, 16);
-    ls += __shfl_xor(ls, 32);
-    if (lane < 6) {
+    for (int e = 0; e < 8; ++e) o8[e] += dpp_xor8(o8[e]);
+    ls += dpp_xor8(ls);
+    const int row = wave * 4 + (lane >> 4);
+    if ((lane & 15) < 6) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_o[wave][lane * 8 + e] = o8[e];
+        for (int e = 0; e < 8; ++e) s_o[row][(lane & 15) * 8 + e] = o8[e];
     }
-    if (lane == 0) s_sum[wave] = ls;
+    if ((lane & 15) == 0) s_sum[row] = ls;
     __syncthreads();
     float* out = g.part + ((long)qi * H + h) * kAttnRec;
-    if (tid < kHeadDim) out[2 * kAttnPad + tid * kAttnPad + split] = ((s_o[0][tid] + s_o[1][tid]) + s_o[2][tid]) + s_o[3][tid];
-    if (tid == 0) { out[split] = mx; out[kAttnPad + split] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3]; }
+    if (tid < kHeadDim) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += s_o[r][tid];
+        out[2 * kAttnPad + tid * kAttnPad + split] = acc;
+    }
+    if (tid == 0) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += s_sum[r];
+        out[split] = mx;
+        out[kAttnPad + split] = acc;
+    }
 }
 
 template <typename T>
