@@ -96,6 +96,36 @@ int umgen_dbg_attn_decode(int bf16, const float* q, const void* kv, int NQ, int 
     return down(y, dX.p, (size_t)NQ * E * 4);
 }
 
+// times `iters` launches of the bf16 MFMA GEMM (mode: GEMM_STORE / GEMM_RESID) on device-resident random operands;
+// returns the average milliseconds per launch through *ms.  tokens R, features N, reduction K.
+int umgen_dbg_gemm_bench(int R, int N, int K, int mode, int iters, float* ms) {
+    DevBuf dA((size_t)R * K * 2), dW((size_t)N * K * 2), dO((size_t)R * N * 4);
+    if (!dA.p || !dW.p || !dO.p) return UMGEN_E_NOMEM;
+    std::vector<bf16_t> h((size_t)R * K);
+    unsigned x = 12345u;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = f32_to_bf16(((x >> 8) & 0xffff) / 32768.0f - 1.0f); }
+    if (up(dA.p, h.data(), h.size() * 2)) return UMGEN_E_HIP;
+    h.resize((size_t)N * K);
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = f32_to_bf16((((x >> 8) & 0xffff) / 32768.0f - 1.0f) * 0.05f); }
+    if (up(dW.p, h.data(), h.size() * 2)) return UMGEN_E_HIP;
+    (void)hipMemset(dO.p, 0, (size_t)R * N * 4);
+    GemmArgs g{};
+    g.P = dW.p; g.Q = dA.p; g.Mi = N; g.Nj = R; g.K = K; g.ldp = K; g.ldq = K; g.batch = 1;
+    g.mode = mode; g.out = dO.p; g.ldo = N;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    launch_gemm_bf16_mfma(nullptr, g);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) launch_gemm_bf16_mfma(nullptr, g);
+    (void)hipEventRecord(e1, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms = t / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
 // few-row linear: out[M][N] = LN(x[M][K]; ln_w) . W[N][K]^T + bias, optional GELU.  W dtype bf16/fp32, activations fp32.
 int umgen_dbg_gemv(int bf16, const float* x, const float* ln_w, const void* W, const float* bias, int M, int N, int K, int gelu, float* out) {
     const size_t es = bf16 ? 2 : 4;

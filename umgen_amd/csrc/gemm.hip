@@ -155,11 +155,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a, int nI,
 // applied to the per-lane SOURCE address (chunk c' of the image holds global chunk c' ^ (row & 7)).  Two LDS buffers: the
 // loads of tile kt+1 are in flight while tile kt is multiplied; one barrier per k-tile.  Requires K % 64 == 0.
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs a, int nI, int nJ) {
+__global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmArgs a, int nI, int nJ) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * BM * BK * 2];
     const int z = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
+    // 8 waves: 2 (i) x 4 (j); each wave owns a 64 x 32 sub-tile (4 x 2 MFMA tiles).  Twice the waves of the 4-wave form at the
+    // same LDS footprint: 4 waves per SIMD hide the short-K (12 k-tiles) prologue / epilogue bubbles of the TAR shapes.
+    const int wi = wave >> 2, wj = wave & 3;
     // XCD-aware 2-D tile map (block b runs on XCD b % 8).  Measured with FETCH_SIZE: when every XCD walks all feature
     // tiles, a 4.7 MB weight matrix does not stay in the 4 MB L2 and is re-streamed for every token tile (7x the
     // algorithmic traffic).  So the 8 XCDs form a 2 (feature halves) x 4 (token quarters) grid: each L2 keeps half of the
@@ -173,29 +175,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
     const int i_base = ti * BM, j_base = tj * BN;
     const bf16_t* P = reinterpret_cast<const bf16_t*>(a.P) + (long)z * a.strideP;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q) + (long)z * a.strideQ;
-    // wave w fills the 1 KB segments w, w+4, w+8, w+12 (8 rows each) of both operand images
-    const bf16_t* pp[4];
-    const bf16_t* qq[4];
+    // wave w fills the 1 KB segments w, w+8 (8 rows each) of both operand images
+    const bf16_t* pp[2];
+    const bf16_t* qq[2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int r = (wave + 4 * it) * 8 + (lane >> 3);
+    for (int it = 0; it < 2; ++it) {
+        const int r = (wave + 8 * it) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (r & 7);
         pp[it] = P + (long)min(i_base + r, a.Mi - 1) * a.ldp + c * 8;
         qq[it] = Q + (long)min(j_base + r, a.Nj - 1) * a.ldq + c * 8;
     }
     auto issue = [&](int buf, int k0) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            unsigned char* dp = lds[buf] + (wave + 4 * it) * 1024;
+        for (int it = 0; it < 2; ++it) {
+            unsigned char* dp = lds[buf] + (wave + 8 * it) * 1024;
             __builtin_amdgcn_global_load_lds((const void*)(pp[it] + k0), (__attribute__((address_space(3))) void*)dp, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const void*)(qq[it] + k0), (__attribute__((address_space(3))) void*)(dp + BM * BK * 2), 16, 0, 0);
         }
     };
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][2];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, g = lane >> 4;
     const int nkt = a.K / BK;
     issue(0, 0);
@@ -206,25 +208,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
         const unsigned char* ldsQ = lds[kt & 1] + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t af[4], bfr[4];
+            bf16x8_t af[4], bfr[2];
             const int c = kk * 4 + g;
 #pragma unroll
             for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const bf16x8_t*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bfr[n] = *reinterpret_cast<const bf16x8_t*>(ldsQ + swz(wj * 64 + n * 16 + frow, c));
+            for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const bf16x8_t*>(ldsQ + swz(wj * 32 + n * 16 + frow, c));
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < 2; ++n) {
             const int i0 = i_base + wi * 64 + m * 16 + 4 * g;
-            const int j = j_base + wj * 64 + n * 16 + frow;
+            const int j = j_base + wj * 32 + n * 16 + frow;
             float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
             epilogue4<MODE, bf16_t>(a, z, i0, j, v);
         }
@@ -235,11 +237,12 @@ void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a) {
     dim3 grid(((nJ + 7) / 8) * 8 * nI, 1, a.batch), block(256);
     if (a.K % BK == 0) {
         grid = dim3(8 * ((nI + 1) / 2) * ((nJ + 3) / 4), 1, a.batch);
+        const dim3 block8(512);
         switch (a.mode) {
-            case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_STORE>, grid, block, 0, s, a, nI, nJ); break;
-            case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_RESID>, grid, block, 0, s, a, nI, nJ); break;
-            case GEMM_STORE_F32: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_STORE_F32>, grid, block, 0, s, a, nI, nJ); break;
-            default: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_VT>, grid, block, 0, s, a, nI, nJ); break;
+            case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_STORE>, grid, block8, 0, s, a, nI, nJ); break;
+            case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_RESID>, grid, block8, 0, s, a, nI, nJ); break;
+            case GEMM_STORE_F32: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_STORE_F32>, grid, block8, 0, s, a, nI, nJ); break;
+            default: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_VT>, grid, block8, 0, s, a, nI, nJ); break;
         }
         return;
     }
