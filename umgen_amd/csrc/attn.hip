@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mn = fmaxf(m[t], mx);
-            const float alpha = exp2f((m[t] - mn) * c);
+            const float alpha = __builtin_amdgcn_exp2f((m[t] - mn) * c);   // raw v_exp_f32: arguments are <= 0, denormal results may flush
             m[t] = mn;
             const float mc = mn * c;
             float ps = 0.f;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    p[kt][r] = exp2f(st[t][kt][r] * c - mc);
+                    p[kt][r] = __builtin_amdgcn_exp2f(st[t][kt][r] * c - mc);
                     ps += p[kt][r];
                 }
             l[t] = l[t] * alpha + ps;
