@@ -74,13 +74,18 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
         for (int i = 0; i < 3; ++i) *reinterpret_cast<uint4*>(lds + buf * kTileBytes + ldst[i]) = stage[i];
     };
 
-    bf16x8_t qlo[QT];
-    s16x4_t qhi[QT];
+    // head_dim 48 = one full K=32 MFMA (d 0..31) + one half-filled K=32 MFMA (d 32..47 in k-slots 8g..8g+3, zeros in 8g+4..8g+7).
+    // (The legacy v_mfma_f32_16x16x16_bf16 for the 16-wide remainder gave tile-dependent wrong results under some register
+    //  allocations on ROCm 7.2 -- chained behind the 8-pass 16x16x32 through SrcC -- so it is not used.)
+    bf16x8_t qlo[QT], qhi[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int qr = min(q0 + t * 16 + c16, S - 1);
         qlo[t] = *reinterpret_cast<const bf16x8_t*>(qbase + qr * ld + 8 * g);
-        qhi[t] = *reinterpret_cast<const s16x4_t*>(qbase + qr * ld + 32 + 4 * g);
+        union { bf16x8_t v; uint2 u[2]; } qh;
+        qh.u[0] = *reinterpret_cast<const uint2*>(qbase + qr * ld + 32 + 4 * g);
+        qh.u[1] = make_uint2(0u, 0u);
+        qhi[t] = qh.v;
     }
     f32x4_t o[QT][3];
     float m[QT], l[QT];
@@ -106,11 +111,13 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
         for (int kt = 0; kt < 4; ++kt) {
             const unsigned char* kr = kt_l + (kt * 16 + c16) * kKStride;
             const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kr + 16 * g);
-            const s16x4_t khi = *reinterpret_cast<const s16x4_t*>(kr + 64 + 8 * g);
+            union { bf16x8_t v; uint2 u[2]; } khi;
+            khi.u[0] = *reinterpret_cast<const uint2*>(kr + 64 + 8 * g);
+            khi.u[1] = make_uint2(0u, 0u);
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(klo, qlo[t], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                st[t][kt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(khi, qhi[t], a, 0, 0, 0);
+                st[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(khi.v, qhi[t], a, 0, 0, 0);
             }
         }
         if (k0 + 64 > S) {   // key tail: rows past S are masked out
@@ -147,10 +154,12 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
                     ps += p[kt][r];
                 }
             l[t] = l[t] * alpha + ps;
+            if (!__all(alpha == 1.0f)) {   // the running maxima of a tile's 16 queries stop moving after a few tiles: skip the no-op rescale
 #pragma unroll
-            for (int d = 0; d < 3; ++d)
+                for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[t][d][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) o[t][d][r] *= alpha;
+            }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
