@@ -12,7 +12,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libumgen_hip.so")
+# UMGEN_LIB_PATH selects an alternative build of the SAME library (kernel experiments with extra -D flags); never a fallback
+LIB_PATH = os.environ.get("UMGEN_LIB_PATH") or os.path.join(HERE, "libumgen_hip.so")
 SOURCES = ["engine.hip", "gemm.hip", "attn.hip", "gemv.hip", "rowops.hip", "frame.hip", "debug_api.hip"]
 EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen_rollout", "umgen_frame",
            "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",

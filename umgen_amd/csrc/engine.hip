@@ -76,6 +76,7 @@ struct umgen_engine {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     umgen_timings tm{};
     bool profiling = false;
+    bool dbg_same_layer = false;          // UMGEN_DEBUG_SAME_LAYER=1: timing experiment, every decode layer reads layer 0's weights
     bool fused_decode = false;            // UMGEN_FUSED_DECODE=1 (experiment, see oar_layers)
     // decode step graphs per (kind: fixed / map / bbox3d / image, number of attention key splits 1..8)
     hipGraphExec_t step_graph[4][kAttnSplit + 1] = {};
@@ -372,7 +373,7 @@ void oar_layers(umgen_engine* e, int B, int ns, int ns_cached) {
     const int E = e->E, H = e->H;
     const int* d_len = &e->d_state->step;
     for (size_t li = 0; li < e->oar.size(); ++li) {
-        const SubW& w = e->oar[li];
+        const SubW& w = e->oar[e->dbg_same_layer ? 0 : li];
         T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
         if (e->fused_decode) {
             // EXPERIMENT (UMGEN_FUSED_DECODE=1): q|k|v of the new token + attention partials over the cached keys in ONE launch
@@ -680,6 +681,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     e->E = cfg->n_embd;
     e->H = cfg->n_head;
     if (const char* fd = getenv("UMGEN_FUSED_DECODE")) e->fused_decode = fd[0] == '1';
+    if (const char* sl = getenv("UMGEN_DEBUG_SAME_LAYER")) e->dbg_same_layer = sl[0] == '1';
     e->tsz = cfg->precision == UMGEN_PREC_BF16 ? 2 : 4;
     const int64_t E = e->E;
     const std::string t = "transformer.";
