@@ -87,7 +87,7 @@ typedef struct umgen_trace {
 
 /* Event-timed phases of the last umgen_rollout call (milliseconds, HIP events on the engine stream). */
 typedef struct umgen_timings {
-    double total_ms, ego_ms, tar_ms, oar_ms;
+    double total_ms, ego_ms, tar_ms, oar_ms;   /* foreground stream: ego net, TAR stacks (or their last slot), decode loop */
     int64_t frames, oar_steps, oar_kernels;
     double gemm_ms;         /* sum over launches of the TAR/ego GEMM kernel (when profiling enabled) */
     int64_t gemm_launches;
@@ -96,6 +96,8 @@ typedef struct umgen_timings {
     double attn_ms;         /* sum over launches of the spatial attention kernel (when profiling enabled) */
     int64_t attn_launches;
     double attn_flops;
+    double bg_ms;           // busy time of the background stream (next frame's history slots run beside the decode loop)
+    int64_t overlapped_frames; /* frames whose TAR stacks only had to compute their last history slot */
 } umgen_timings;
 
 /* UMGen(config)  -- UMGen.py:53 */

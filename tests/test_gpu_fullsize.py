@@ -8,6 +8,7 @@
   its own output samples exactly that output again, the history is returned untouched and every token is in range.
 """
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -107,6 +108,8 @@ def test_large_batch_of_two_equals_two_single_rollouts(large):
     scenes = [synthetic_scene(1000 + i, n_frames=20) for i in range(2)]
     seeds = [7, 8]
     single = [e.rollout(scenes[i], 2, cond_frames=20, seeds=[seeds[i]]) for i in range(2)]
+    # frame 2 of a one-scene rollout takes the overlapped path: history slots 0..18 went through the stacks beside frame 1's decode
+    assert e.timings()["overlapped_frames"] == 1
     both_in = {m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}
     both = e.rollout(both_in, 2, cond_frames=20, seeds=seeds)
     check_structure(cfg, both_in, both, 20, 2)
@@ -142,19 +145,26 @@ def test_large_frame_entry_point_and_self_forcing(large):
         np.testing.assert_array_equal(toks2[m], toks1[m], err_msg=m)
 
 
-def test_large_control_rollout_copies_control_pose_and_graph_replay_equals_eager(large):
+def test_large_control_rollout_copies_control_pose_and_overlapped_graph_path_equals_plain_eager(large):
     """configs[2] shape (control, 13 history frames, one controlled agent): control pose tokens are copied verbatim into the
-    output (UMGen.py:1640-1651), and the hipGraph replay of the decode step gives the same tokens as eager launches."""
+    output (UMGen.py:1640-1651); the production path (hipGraph replay of the decode step, next frame's history slots pushed
+    through the stacks on the background stream) gives the same tokens as the plain path (eager launches, one pass)."""
     cfg, e = large
     scene = synthetic_scene(1005, n_frames=13)
     init = synthetic_control(1005, n_frames=2)
     out = e.rollout(scene, 2, cond_frames=20, input_cond_frames=13, init_tokens=init, control_test=True, seeds=[9])
     check_structure(cfg, scene, out, 13, 2)
     np.testing.assert_array_equal(out["pose"][:, 13:15], init["pose"][:, :2])
-    eager = Engine(cfg, precision="bf16", max_batch=1, max_cond_frames=20, use_graphs=False)
+    assert e.timings()["overlapped_frames"] == 1       # growing window (13 -> 14 slots), pose given: ego prefix skipped
+    os.environ["UMGEN_OVERLAP"] = "0"                  # plain path: whole window in one foreground pass, eager launches
+    try:
+        eager = Engine(cfg, precision="bf16", max_batch=1, max_cond_frames=20, use_graphs=False)
+    finally:
+        del os.environ["UMGEN_OVERLAP"]
     eager.load_state_dict(synthetic_items(cfg, seed=0))
     eager.finalize()
     out2 = eager.rollout(scene, 2, cond_frames=20, input_cond_frames=13, init_tokens=init, control_test=True, seeds=[9])
+    assert eager.timings()["overlapped_frames"] == 0
     eager.close()
     for m in MOD_ORDER:
         np.testing.assert_array_equal(out2[m], out[m], err_msg=m)

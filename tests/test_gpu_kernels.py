@@ -85,7 +85,12 @@ def test_attn_temporal(bf16, B, T, S, H):
     if bf16:
         qkv = bf16_round(qkv)
     y = np.zeros((B, T, S, E), dtype=np.uint16 if bf16 else np.float32)
-    check(lib().umgen_dbg_attn_temporal(bf16, vp(bf16_bits(qkv) if bf16 else qkv), B, T, S, H, vp(y)))
+    bits = bf16_bits(qkv) if bf16 else qkv
+    check(lib().umgen_dbg_attn_temporal(bf16, vp(bits), B, T, S, H, 0, vp(y)))
+    # slots 0..T-2 ahead of time, the last slot against the slot cache (the rollout's overlapped TAR pass): same bits
+    y2 = np.zeros_like(y)
+    check(lib().umgen_dbg_attn_temporal(bf16, vp(bits), B, T, S, H, T - 1, vp(y2)))
+    np.testing.assert_array_equal(y2, y)
     got = from_bits(y) if bf16 else y
     x = qkv.transpose(0, 2, 1, 3).reshape(B * S, T, 3 * E)        # (b s) t c
     ref = ref_attention(np.ascontiguousarray(x[..., :E]), np.ascontiguousarray(x[..., E:2 * E]),

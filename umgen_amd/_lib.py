@@ -51,7 +51,8 @@ class Timings(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("ego_ms", C.c_double), ("tar_ms", C.c_double), ("oar_ms", C.c_double),
                 ("frames", C.c_int64), ("oar_steps", C.c_int64), ("oar_kernels", C.c_int64),
                 ("gemm_ms", C.c_double), ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("oar_bytes", C.c_double),
-                ("attn_ms", C.c_double), ("attn_launches", C.c_int64), ("attn_flops", C.c_double)]
+                ("attn_ms", C.c_double), ("attn_launches", C.c_int64), ("attn_flops", C.c_double),
+                ("bg_ms", C.c_double), ("overlapped_frames", C.c_int64)]
 
 
 def hipcc_path() -> str:
@@ -105,7 +106,7 @@ def load_library() -> C.CDLL:
     fp = C.POINTER(C.c_float)
     lib.umgen_dbg_linear.argtypes = [i32, vp, vp, fp, i32, i32, i32, i32, i32, vp]
     lib.umgen_dbg_attn_spatial.argtypes = [i32, vp, vp, i32, i32, i32, vp]
-    lib.umgen_dbg_attn_temporal.argtypes = [i32, vp, i32, i32, i32, i32, vp]
+    lib.umgen_dbg_attn_temporal.argtypes = [i32, vp, i32, i32, i32, i32, i32, vp]
     lib.umgen_dbg_attn_decode.argtypes = [i32, fp, vp, i32, i32, i32, fp]
     lib.umgen_dbg_gemv.argtypes = [i32, fp, fp, vp, fp, i32, i32, i32, i32, fp]
     lib.umgen_dbg_gemm_bench.argtypes = [i32, i32, i32, i32, i32, fp]

@@ -294,8 +294,13 @@ template void launch_attn_spatial_valu<bf16_t>(hipStream_t, const bf16_t*, const
 // from global, measured 5.5x the algorithmic HBM traffic with FETCH_SIZE), then thread (head, tq) runs its causal row.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTmax = 32;
+// Slot ranges (TemporalRange, kernels.h): the qkv rows hold the Tn "new" history slots [t0, t0 + Tn) of every (scene, position);
+// the k | v rows of the t0 earlier slots come from the layer's persistent cache [B][Tcap][S][2E] (written by an earlier launch with
+// write = 1).  Every query runs the same sequential online softmax over keys 0 .. tq whichever launch its keys came from, so a
+// split pass (slots 0..P-1 ahead of time, slot P later) is bit-identical to one pass over all P + 1 slots.
 template <typename T, int HG>
-__global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* __restrict__ qkv, T* __restrict__ y, int T_, int S, int H) {
+__global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* __restrict__ qkv, T* __restrict__ y, int Tn, int S, int H,
+                                                                       TemporalRange tr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [T][3][HG*48]
     constexpr int W = HG * kHeadDim;
     constexpr int NT = HG * kTmax * 4;
@@ -306,6 +311,8 @@ __global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* 
     const int E = H * kHeadDim;
     const long ld = 3L * E;
     const int tid = threadIdx.x;
+    const int t0 = tr.t0, T_ = tr.t0 + Tn;
+    T* cache = reinterpret_cast<T*>(tr.cache);
     constexpr int chunks_per_seg = W / 8;
     const int n_chunks = T_ * 3 * chunks_per_seg;
     constexpr int kIter = (kTmax * 3 * chunks_per_seg + NT - 1) / NT;
@@ -314,19 +321,27 @@ __global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* 
         const int c = tid + NT * it;
         if (c < n_chunks) {
             const int cc = c % chunks_per_seg, seg = (c / chunks_per_seg) % 3, t = c / (3 * chunks_per_seg);
+            if (t < t0 && seg == 0) continue;        // queries of cached slots are not needed
             float v8[8];
-            load8(qkv + (((long)b * T_ + t) * S + s) * ld + (long)seg * E + hg * W + cc * 8, v8);
+            T* cp = cache ? cache + (((long)b * tr.Tcap + t) * S + s) * 2L * E + (long)(seg - 1) * E + hg * W + cc * 8 : nullptr;
+            if (t < t0) load8(cp, v8);
+            else load8(qkv + (((long)b * Tn + (t - t0)) * S + s) * ld + (long)seg * E + hg * W + cc * 8, v8);
             float* d = sm + ((t * 3 + seg) * W + cc * 8);
             *reinterpret_cast<float4*>(d) = make_float4(v8[0], v8[1], v8[2], v8[3]);
             *reinterpret_cast<float4*>(d + 4) = make_float4(v8[4], v8[5], v8[6], v8[7]);
+            if (tr.write && t >= t0 && seg > 0) {
+                const float lo4[4] = {v8[0], v8[1], v8[2], v8[3]}, hi4[4] = {v8[4], v8[5], v8[6], v8[7]};
+                store4(cp, lo4);
+                store4(cp + 4, hi4);
+            }
         }
     }
     __syncthreads();
     // 4 lanes per (head, query frame): lane part p owns head-dim slice [12p, 12p+12)
     const int part = tid & 3, tq = (tid >> 2) % kTmax, hl = tid / (4 * kTmax);
-    const bool active = tq < T_;
+    const bool active = tq >= t0 && tq < T_;
     float q[12], o[12];
-    const float* qp = sm + ((active ? tq : 0) * 3 + 0) * W + hl * kHeadDim + part * 12;
+    const float* qp = sm + ((active ? tq : t0) * 3 + 0) * W + hl * kHeadDim + part * 12;
 #pragma unroll
     for (int d = 0; d < 12; d += 4) {
         const float4 q4 = *reinterpret_cast<const float4*>(qp + d);
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* 
     }
     if (!active) return;
     const float inv = 1.0f / l;
-    T* yp = y + (((long)b * T_ + tq) * S + s) * (long)E + (hg * HG + hl) * kHeadDim + part * 12;
+    T* yp = y + (((long)b * Tn + (tq - t0)) * S + s) * (long)E + (hg * HG + hl) * kHeadDim + part * 12;
 #pragma unroll
     for (int d = 0; d < 12; d += 4) {
         float t4[4] = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
@@ -372,20 +387,21 @@ __global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* 
 }
 
 template <typename T>
-void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int T_, int S, int H) {
-    // T_ <= kTmax (checked at engine creation); 4 heads per workgroup when H allows
+void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int Tn, int S, int H, TemporalRange tr) {
+    // t0 + Tn <= kTmax (checked at engine creation); 4 heads per workgroup when H allows
+    const int T_ = tr.t0 + Tn;
     if (H % 4 == 0) {
         const size_t shm = (size_t)T_ * 3 * 4 * kHeadDim * sizeof(float);
-        hipLaunchKernelGGL((attn_temporal_kernel<T, 4>), dim3((unsigned)((long)B * S * (H / 4))), dim3(4 * kTmax * 4), shm, s, qkv, y, T_, S, H);
+        hipLaunchKernelGGL((attn_temporal_kernel<T, 4>), dim3((unsigned)((long)B * S * (H / 4))), dim3(4 * kTmax * 4), shm, s, qkv, y, Tn, S, H, tr);
     } else if (H % 2 == 0) {
         const size_t shm = (size_t)T_ * 3 * 2 * kHeadDim * sizeof(float);
-        hipLaunchKernelGGL((attn_temporal_kernel<T, 2>), dim3((unsigned)((long)B * S * (H / 2))), dim3(2 * kTmax * 4), shm, s, qkv, y, T_, S, H);
+        hipLaunchKernelGGL((attn_temporal_kernel<T, 2>), dim3((unsigned)((long)B * S * (H / 2))), dim3(2 * kTmax * 4), shm, s, qkv, y, Tn, S, H, tr);
     } else {
         const size_t shm = (size_t)T_ * 3 * 1 * kHeadDim * sizeof(float);
-        hipLaunchKernelGGL((attn_temporal_kernel<T, 1>), dim3((unsigned)((long)B * S * H)), dim3(1 * kTmax * 4), shm, s, qkv, y, T_, S, H);
+        hipLaunchKernelGGL((attn_temporal_kernel<T, 1>), dim3((unsigned)((long)B * S * H)), dim3(1 * kTmax * 4), shm, s, qkv, y, Tn, S, H, tr);
     }
 }
-template void launch_attn_temporal<float>(hipStream_t, const float*, float*, int, int, int, int);
-template void launch_attn_temporal<bf16_t>(hipStream_t, const bf16_t*, bf16_t*, int, int, int, int);
+template void launch_attn_temporal<float>(hipStream_t, const float*, float*, int, int, int, int, TemporalRange);
+template void launch_attn_temporal<bf16_t>(hipStream_t, const bf16_t*, bf16_t*, int, int, int, int, TemporalRange);
 
 }  // namespace umgen

@@ -62,17 +62,43 @@ int umgen_dbg_attn_spatial(int bf16, const void* qk, const void* v, int F, int S
     return down(y, dY.p, R * E * es);
 }
 
-// temporal causal attention on qkv rows [B*T*S][3E] -> y [B*T*S][E]
-int umgen_dbg_attn_temporal(int bf16, const void* qkv, int B, int T, int S, int H, void* y) {
+// temporal causal attention on qkv rows [B*T*S][3E] -> y [B*T*S][E].  split = P > 0: slots 0..P-1 first (k | v appended to a
+// slot cache), then slots P..T-1 against that cache -- must equal the single pass bit for bit.
+int umgen_dbg_attn_temporal(int bf16, const void* qkv, int B, int T, int S, int H, int split, void* y) {
     const int E = H * kHeadDim;
     const size_t es = bf16 ? 2 : 4, R = (size_t)B * T * S;
-    DevBuf dQ(R * 3 * E * es), dY(R * E * es);
-    if (!dQ.p || !dY.p) return UMGEN_E_NOMEM;
-    if (up(dQ.p, qkv, R * 3 * E * es)) return UMGEN_E_HIP;
-    if (bf16) launch_attn_temporal<bf16_t>(nullptr, (const bf16_t*)dQ.p, (bf16_t*)dY.p, B, T, S, H);
-    else launch_attn_temporal<float>(nullptr, (const float*)dQ.p, (float*)dY.p, B, T, S, H);
-    if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
-    return down(y, dY.p, R * E * es);
+    if (split <= 0 || split >= T) {
+        DevBuf dQ(R * 3 * E * es), dY(R * E * es);
+        if (!dQ.p || !dY.p) return UMGEN_E_NOMEM;
+        if (up(dQ.p, qkv, R * 3 * E * es)) return UMGEN_E_HIP;
+        if (bf16) launch_attn_temporal<bf16_t>(nullptr, (const bf16_t*)dQ.p, (bf16_t*)dY.p, B, T, S, H);
+        else launch_attn_temporal<float>(nullptr, (const float*)dQ.p, (float*)dY.p, B, T, S, H);
+        if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
+        return down(y, dY.p, R * E * es);
+    }
+    const int Tcap = T + 1;
+    DevBuf dC((size_t)B * Tcap * S * 2 * E * es);
+    if (!dC.p) return UMGEN_E_NOMEM;
+    const int t0s[2] = {0, split}, tns[2] = {split, T - split};
+    const size_t row = (size_t)3 * E * es, orow = (size_t)E * es;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int t0 = t0s[pass], Tn = tns[pass];
+        const size_t Rn = (size_t)B * Tn * S;
+        std::vector<unsigned char> hq(Rn * row), hy(Rn * orow);
+        for (int b = 0; b < B; ++b)   // gather the [b][t0 .. t0+Tn) slots into a compact [B][Tn][S] block
+            memcpy(&hq[(size_t)b * Tn * S * row], (const unsigned char*)qkv + ((size_t)b * T + t0) * S * row, (size_t)Tn * S * row);
+        DevBuf dQ(hq.size()), dY(hy.size());
+        if (!dQ.p || !dY.p) return UMGEN_E_NOMEM;
+        if (up(dQ.p, hq.data(), hq.size())) return UMGEN_E_HIP;
+        TemporalRange tr{t0, dC.p, Tcap, pass == 0 ? 1 : 0};
+        if (bf16) launch_attn_temporal<bf16_t>(nullptr, (const bf16_t*)dQ.p, (bf16_t*)dY.p, B, Tn, S, H, tr);
+        else launch_attn_temporal<float>(nullptr, (const float*)dQ.p, (float*)dY.p, B, Tn, S, H, tr);
+        if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
+        if (down(hy.data(), dY.p, hy.size())) return UMGEN_E_HIP;
+        for (int b = 0; b < B; ++b)
+            memcpy((unsigned char*)y + ((size_t)b * T + t0) * S * orow, &hy[(size_t)b * Tn * S * orow], (size_t)Tn * S * orow);
+    }
+    return UMGEN_OK;
 }
 
 // decode-style attention: q [NQ][E] fp32, kv [L][2E] (k | v) of dtype bf16/fp32 shared by all queries -> y [NQ][E] fp32

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>
@@ -72,6 +73,24 @@ struct umgen_engine {
     double* d_boxes = nullptr;
     unsigned long long* d_seeds = nullptr;
     OarState* d_state = nullptr;
+    // Overlapped TAR pass.  Causal temporal attention + frame-local spatial attention make every history
+    // slot but the last one of the NEXT frame's window independent of the frame being decoded, so those slots are pushed through
+    // the ego / map / box / TAR stacks on `bg_stream` (a CU-masked stream) while the latency-bound decode loop runs on the
+    // other CUs; their temporal k | v rows are kept per layer in `tcache`.  The next frame then only computes its last slot.
+    bool overlap = false, overlap_suspended = false;
+    int overlap_mode = 1;                // UMGEN_OVERLAP: 0 off, 1 on for one scene per GPU (default), 2 always
+    hipStream_t bg_stream = nullptr;
+    hipEvent_t ev_tar_done = nullptr, ev_bg_done = nullptr, ev_bg0 = nullptr;
+    bool bg_pending = false;
+    std::vector<void*> tcache[4];        // per stack, per BlockTAR: [max_batch][max_cond_frames][S_stack][2E] of T
+    struct Prefix {
+        bool valid = false, has_ego = false;
+        int B = 0, P = 0, Tfull = 0;
+        std::vector<int> pose, map, box, img;   // slots 0..P-1 of the window the pass was computed for, [B][P][S_mod]
+        std::vector<int> pose_next;             // [B][3] pose tokens the new frame must carry (they sit in shifted slot P-1)
+    } px;
+    std::vector<int> px_up[4], px_pshift;   // host staging of the background pass's uploads (must outlive the async copies)
+    std::vector<float> px_pdiff;
     // timing
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     umgen_timings tm{};
@@ -263,7 +282,7 @@ void linear_resid(umgen_engine* e, const void* W, const float* bias, int N, int 
 
 // one (LayerNorm -> attention -> residual -> LayerNorm -> MLP -> residual) sub-block of BlockTAR (module.py:332-359)
 template <typename T>
-void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal) {
+void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal, TemporalRange tr = TemporalRange{0, nullptr, 0, 0}) {
     const int E = e->E, H = e->H;
     const long R = (long)B * Tn * S;
     T* A = reinterpret_cast<T*>(e->A);
@@ -271,7 +290,7 @@ void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal
     launch_layernorm<T>(e->stream, e->X, E, R, E, w.ln_a, A);
     if (temporal) {
         linear_store<T>(e, w.attn.Wqkv, w.attn.bqkv, 3 * E, E, A, R, QKV, 3L * E, 0);
-        launch_attn_temporal<T>(e->stream, QKV, A, B, Tn, S, H);
+        launch_attn_temporal<T>(e->stream, QKV, A, B, Tn, S, H, tr);
     } else {
         // q | k row-major, V transposed per (frame, head) for the attention kernel
         linear_store<T>(e, w.attn.Wqkv, w.attn.bqkv, 2 * E, E, A, R, QKV, 2L * E, 0);
@@ -302,15 +321,19 @@ void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal
     linear_resid<T>(e, w.mlp.Wproj, nullptr, E, 4 * E, e->Hb, R, e->X);
 }
 
+// cache_mode: 0 = one pass over the whole window; 1 = prefix pass (slots [0, w.T), k | v appended to the slot caches);
+// 2 = last-slot pass (slots [w.t0, w.t0 + w.T) against the caches)
 template <typename T>
-void run_stack(umgen_engine* e, int stack, const WindowTokens& w) {
+void run_stack(umgen_engine* e, int stack, const WindowTokens& w, int cache_mode = 0) {
     const int S = stack_len(stack);
     launch_embed_stack(e->stream, stack, e->tb, w, e->X, e->mapfeat);
     if (stack != STACK_EGO) launch_warp_map(e->stream, stack, e->tb, w.B, w.T, e->mapfeat, e->pose_diff, e->X,
-                                            stack == STACK_MAP ? e->warped_last : nullptr);
-    for (const TarW& blk : e->stk[stack]) {
+                                            stack == STACK_MAP ? e->warped_last : nullptr, w.Tfull, w.t0);
+    for (size_t i = 0; i < e->stk[stack].size(); ++i) {
+        const TarW& blk = e->stk[stack][i];
+        TemporalRange tr{w.t0, cache_mode ? e->tcache[stack][i] : nullptr, e->cfg.max_cond_frames, cache_mode == 1 ? 1 : 0};
         tar_sub<T>(e, blk.sub[0], w.B, w.T, S, false);
-        tar_sub<T>(e, blk.sub[1], w.B, w.T, S, true);
+        tar_sub<T>(e, blk.sub[1], w.B, w.T, S, true, tr);
         tar_sub<T>(e, blk.sub[2], w.B, w.T, S, false);
     }
 }
@@ -335,15 +358,16 @@ void gemv_resid(umgen_engine* e, const float* a_in, long lda, const float* part,
 // infer_ego_net / forward_ego_net (UMGen.py:994-1005, 634-687).  The Decoder is frame-local and only t = -1 is consumed
 // (UMGen.py:1002), so the 12 decoder blocks run on the last frame only -- identical outputs, 1/T of the work.
 template <typename T>
-void run_ego(umgen_engine* e, const WindowTokens& w, const SamplerParams& sp, int frame_idx, bool forced, float* trace_logits) {
-    const int E = e->E, H = e->H, B = w.B, Tn = w.T;
-    run_stack<T>(e, STACK_EGO, w);
+void run_ego(umgen_engine* e, const WindowTokens& w, const SamplerParams& sp, int frame_idx, bool forced, float* trace_logits,
+             int cache_mode = 0) {
+    const int E = e->E, H = e->H, B = w.B, Tn = w.T;   // Tn: slots in this pass (the last one is the window's last frame)
+    run_stack<T>(e, STACK_EGO, w, cache_mode);
     // p = ln_ego_tar(x) of the last frame, kept in fp32 (every decoder block re-normalises it with its own ln_3)
     for (int b = 0; b < B; ++b)
         launch_layernorm<float>(e->stream, e->X + (((long)b * Tn + (Tn - 1)) * kSeq) * E, E, kSeq, E, e->ln_ego_tar,
                                 e->pego + (long)b * kSeq * E);
     float* x = e->xdec;   // [3B][E] ego queries
-    launch_ego_queries(e->stream, e->tb, B, Tn, x);
+    launch_ego_queries(e->stream, e->tb, B, w.Tfull ? w.Tfull : Tn, x);
     const int M = 3 * B;
     T* PN = reinterpret_cast<T*>(e->A);         // ln_3(p)           [B*2207][E]
     T* KV = reinterpret_cast<T*>(e->QKV);       // k | v of ln_3(p)  [B*2207][2E]
@@ -416,7 +440,39 @@ struct FrameIO {
     const umgen_sampling* smp;
     const umgen_trace* trace;                    // B == 1 only
     int* out_tokens;                             // host [B][2199]
+    int cond_cap = 0;                            // window cap (cond_frames) of the rollout; 0 = single frame, nothing follows
+    bool next_follows = false;                   // another frame of the same rollout follows: run its prefix pass beside the decode
+    bool next_has_ctrl_pose = false;             // ... and its pose is given, so the ego net's prefix is not needed
 };
+
+// Does the prefix pass that ran beside the previous frame's decode cover exactly this window's slots 0..P-1 ?
+bool prefix_matches(const umgen_engine* e, const FrameIO& io) {
+    const umgen_engine::Prefix& px = e->px;
+    if (!e->overlap || !px.valid || io.trace || io.B != px.B || io.T != px.Tfull || px.P != io.T - 1 || px.P < 1) return false;
+    if (!io.ctrl_pose && !px.has_ego) return false;
+    const int S[4] = {kNPose, kNMap, kNBox, kNImg};
+    const int* cur[4] = {io.pose, io.map, io.box, io.img};
+    const std::vector<int>* old[4] = {&px.pose, &px.map, &px.box, &px.img};
+    for (int m = 0; m < 4; ++m)
+        for (int b = 0; b < io.B; ++b)
+            if (memcmp(cur[m] + (size_t)b * io.T * S[m], old[m]->data() + (size_t)b * px.P * S[m], (size_t)px.P * S[m] * sizeof(int))) return false;
+    for (int b = 0; b < io.B; ++b)   // the last frame's pose tokens were already baked into shifted slot P-1
+        if (memcmp(io.pose + ((size_t)b * io.T + px.P) * kNPose, &px.pose_next[(size_t)b * 3], 3 * sizeof(int))) return false;
+    return true;
+}
+
+void decode_pose_shift(const int* pose, const int* ego, int B, int Tn, std::vector<int>& pshift, std::vector<float>& pdiff) {
+    // pose shifted one frame ahead (UMGen.py:1445-1452) and its decoded (dx, dy, dtheta) for the map warp
+    pshift.resize((size_t)B * Tn * 3);
+    pdiff.resize((size_t)B * Tn * 3);
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < Tn; ++t)
+            for (int a = 0; a < 3; ++a) {
+                const int v = (t + 1 < Tn) ? pose[((size_t)b * Tn + t + 1) * 3 + a] : ego[b * 3 + a];
+                pshift[((size_t)b * Tn + t) * 3 + a] = v;
+                pdiff[((size_t)b * Tn + t) * 3 + a] = decode_pose_value(v, a);
+            }
+}
 
 // kernels of one decode step of kind mod (0 fixed token, 1 map, 2 bbox3d, 3 image) for B scenes
 template <typename T>
@@ -452,6 +508,61 @@ int enqueue_step(umgen_engine* e, int B, int mod, int ns, int ns_cached, const u
     return 0;
 }
 
+// Background pass for the NEXT frame of the rollout: its window is this window moved on by one frame, and all its slots but the
+// last are known now (the new frame's pose tokens `ego` included).  They run through the four stacks on bg_stream while the
+// decode loop of the current frame owns the other CUs; the temporal k | v rows of every layer land in the slot caches.
+template <typename T>
+int launch_prefix(umgen_engine* e, const FrameIO& io, const std::vector<int>& ego) {
+    const int B = io.B, Tn = io.T;
+    const int Tnext = std::min(Tn + 1, io.cond_cap);
+    const int off = (Tn + 1 > io.cond_cap) ? 1 : 0;     // the window slides (UMGen.py:1600-1603) or still grows
+    const int P = Tnext - 1;
+    if (P < 1 || Tnext > e->cfg.max_cond_frames) return 0;
+    umgen_engine::Prefix& px = e->px;
+    px.valid = false;
+    px.B = B; px.P = P; px.Tfull = Tnext; px.has_ego = !io.next_has_ctrl_pose;
+    const int S[4] = {kNPose, kNMap, kNBox, kNImg};
+    const int* cur[4] = {io.pose, io.map, io.box, io.img};
+    std::vector<int>* keep[4] = {&px.pose, &px.map, &px.box, &px.img};
+    std::vector<int>* up[4] = {&e->px_up[0], &e->px_up[1], &e->px_up[2], &e->px_up[3]};
+    for (int m = 0; m < 4; ++m) {
+        keep[m]->assign((size_t)B * P * S[m], 0);
+        up[m]->assign((size_t)B * Tnext * S[m], 0);
+        for (int b = 0; b < B; ++b) {
+            const int* src = cur[m] + ((size_t)b * Tn + off) * S[m];
+            memcpy(keep[m]->data() + (size_t)b * P * S[m], src, (size_t)P * S[m] * sizeof(int));
+            memcpy(up[m]->data() + (size_t)b * Tnext * S[m], src, (size_t)P * S[m] * sizeof(int));
+        }
+    }
+    px.pose_next.assign(ego.begin(), ego.end());
+    for (int b = 0; b < B; ++b)
+        for (int a = 0; a < 3; ++a) (*up[0])[((size_t)b * Tnext + P) * 3 + a] = ego[b * 3 + a];
+    std::vector<int> zero((size_t)B * 3, 0);
+    decode_pose_shift(up[0]->data(), zero.data(), B, Tnext, e->px_pshift, e->px_pdiff);   // slot P (unknown) is not touched by this pass
+
+    hipStream_t fg = e->stream, bg = e->bg_stream;
+    HIPCHK(e, hipEventRecord(e->ev_tar_done, fg));
+    HIPCHK(e, hipStreamWaitEvent(bg, e->ev_tar_done, 0));
+    HIPCHK(e, hipMemcpyAsync(e->d_pose, up[0]->data(), up[0]->size() * 4, hipMemcpyHostToDevice, bg));
+    HIPCHK(e, hipMemcpyAsync(e->d_map, up[1]->data(), up[1]->size() * 4, hipMemcpyHostToDevice, bg));
+    HIPCHK(e, hipMemcpyAsync(e->d_box, up[2]->data(), up[2]->size() * 4, hipMemcpyHostToDevice, bg));
+    HIPCHK(e, hipMemcpyAsync(e->d_img, up[3]->data(), up[3]->size() * 4, hipMemcpyHostToDevice, bg));
+    HIPCHK(e, hipMemcpyAsync(e->d_pose_shift, e->px_pshift.data(), e->px_pshift.size() * 4, hipMemcpyHostToDevice, bg));
+    HIPCHK(e, hipMemcpyAsync(e->pose_diff, e->px_pdiff.data(), e->px_pdiff.size() * 4, hipMemcpyHostToDevice, bg));
+    HIPCHK(e, hipEventRecord(e->ev_bg0, bg));
+    e->stream = bg;
+    if (px.has_ego) run_stack<T>(e, STACK_EGO, WindowTokens{e->d_pose, e->d_map, e->d_box, e->d_img, B, P, Tnext, 0}, 1);
+    const WindowTokens ws{e->d_pose_shift, e->d_map, e->d_box, e->d_img, B, P, Tnext, 0};
+    run_stack<T>(e, STACK_MAP, ws, 1);
+    run_stack<T>(e, STACK_BOX, ws, 1);
+    run_stack<T>(e, STACK_TAR, ws, 1);
+    e->stream = fg;
+    HIPCHK(e, hipEventRecord(e->ev_bg_done, bg));
+    e->bg_pending = true;
+    px.valid = true;
+    return 0;
+}
+
 // UMGen._inference (UMGen.py:1406-1540) for B scenes
 template <typename T>
 int run_frame(umgen_engine* e, const FrameIO& io) {
@@ -461,6 +572,19 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                      io.smp->rule_constrain, io.smp->merge_ar_tar, io.smp->only_ar};
     const umgen_trace* tr = io.trace;
     const bool forced = tr && tr->forced_map;
+    if (e->bg_pending) {   // the background pass reads the token arrays and owns the TAR scratch buffers until it is done
+        const auto tw0 = std::chrono::steady_clock::now();
+        HIPCHK(e, hipEventSynchronize(e->ev_bg_done));
+        const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+        // the pass only pays while it hides behind the decode loop: if the foreground had to wait for it (many scenes per GPU,
+        // a much wider model), later frames go back to the plain one-pass path
+        if (waited > 25.0 && e->overlap_mode != 2) e->overlap_suspended = true;
+        if (getenv("UMGEN_DEBUG_TIMING")) fprintf(stderr, "[umgen] waited %.1f ms for the background pass\n", waited);
+        float bms = 0.f;
+        hipEventElapsedTime(&bms, e->ev_bg0, e->ev_bg_done);
+        e->tm.bg_ms += bms;
+        e->bg_pending = false;
+    }
     HIPCHK(e, hipMemcpyAsync(e->d_pose, io.pose, (size_t)B * Tn * 3 * 4, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->d_map, io.map, (size_t)B * Tn * kNMap * 4, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->d_box, io.box, (size_t)B * Tn * kNBox * 4, hipMemcpyHostToDevice, st));
@@ -480,28 +604,26 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     HIPCHK(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int), st));
     HIPCHK(e, hipMemsetAsync(e->d_nboxes, 0, (size_t)B * sizeof(int), st));
 
-    WindowTokens w{e->d_pose, e->d_map, e->d_box, e->d_img, B, Tn};
+    // overlapped TAR pass: when the previous frame's background pass covered slots 0..Tn-2 of this very window, only the last slot
+    // is pushed through the stacks now (against the per-layer slot caches)
+    const bool use_px = prefix_matches(e, io);
+    const int t0 = use_px ? Tn - 1 : 0, Tc = use_px ? 1 : Tn, cmode = use_px ? 2 : 0;
+    e->px.valid = false;
+    WindowTokens w{e->d_pose, e->d_map, e->d_box, e->d_img, B, Tc, Tn, t0};
     // Step 1: ego pose tokens (UMGen.py:1440-1455)
     std::vector<int> ego(B * 3);
     HIPCHK(e, hipEventRecord(e->ev[0], st));
     if (io.ctrl_pose) {
         for (int i = 0; i < B * 3; ++i) ego[i] = io.ctrl_pose[i];
     } else {
-        run_ego<T>(e, w, sp, io.frame_idx, forced, tr ? tr->ego_logits : nullptr);
+        run_ego<T>(e, w, sp, io.frame_idx, forced, tr ? tr->ego_logits : nullptr, cmode);
         HIPCHK(e, hipMemcpyAsync(ego.data(), e->d_ego_tok, (size_t)B * 3 * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(e, hipStreamSynchronize(st));
     }
     HIPCHK(e, hipEventRecord(e->ev[1], st));
-    // pose shifted one frame ahead (UMGen.py:1445-1452) and its decoded (dx, dy, dtheta) for the map warp
-    std::vector<int> pshift((size_t)B * Tn * 3);
-    std::vector<float> pdiff((size_t)B * Tn * 3);
-    for (int b = 0; b < B; ++b)
-        for (int t = 0; t < Tn; ++t)
-            for (int a = 0; a < 3; ++a) {
-                const int v = (t + 1 < Tn) ? io.pose[((size_t)b * Tn + t + 1) * 3 + a] : ego[b * 3 + a];
-                pshift[((size_t)b * Tn + t) * 3 + a] = v;
-                pdiff[((size_t)b * Tn + t) * 3 + a] = decode_pose_value(v, a);
-            }
+    std::vector<int> pshift;
+    std::vector<float> pdiff;
+    decode_pose_shift(io.pose, ego.data(), B, Tn, pshift, pdiff);
     HIPCHK(e, hipMemcpyAsync(e->d_pose_shift, pshift.data(), pshift.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->pose_diff, pdiff.data(), pdiff.size() * 4, hipMemcpyHostToDevice, st));
     // new-frame token buffer: pose = ego tokens; previous frame's bbox3d tokens; control mask
@@ -525,13 +647,13 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
 
     // Step 2: the three TAR stacks (UMGen.py:1484-1494) and the conditioning rows (1496-1511)
-    WindowTokens ws{e->d_pose_shift, e->d_map, e->d_box, e->d_img, B, Tn};
-    run_stack<T>(e, STACK_MAP, ws);
-    launch_cond_rows(st, STACK_MAP, B, Tn, E, e->X, e->ln_map_tar, e->warped_last, e->cond);
-    run_stack<T>(e, STACK_BOX, ws);
-    launch_cond_rows(st, STACK_BOX, B, Tn, E, e->X, e->ln_box_tar, nullptr, e->cond);
-    run_stack<T>(e, STACK_TAR, ws);
-    launch_cond_rows(st, STACK_TAR, B, Tn, E, e->X, e->ln_tar, nullptr, e->cond);
+    WindowTokens ws{e->d_pose_shift, e->d_map, e->d_box, e->d_img, B, Tc, Tn, t0};
+    run_stack<T>(e, STACK_MAP, ws, cmode);
+    launch_cond_rows(st, STACK_MAP, B, Tc, E, e->X, e->ln_map_tar, e->warped_last, e->cond);
+    run_stack<T>(e, STACK_BOX, ws, cmode);
+    launch_cond_rows(st, STACK_BOX, B, Tc, E, e->X, e->ln_box_tar, nullptr, e->cond);
+    run_stack<T>(e, STACK_TAR, ws, cmode);
+    launch_cond_rows(st, STACK_TAR, B, Tc, E, e->X, e->ln_tar, nullptr, e->cond);
     if (tr && tr->cond) HIPCHK(e, hipMemcpyAsync(tr->cond, e->cond, (size_t)kSeq * E * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipEventRecord(e->ev[2], st));
 
@@ -540,6 +662,13 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     // A step is a fixed kernel sequence with fixed arguments (all per-step state is device resident), replayed from a
     // hipGraph per step kind; trace mode launches directly so the logits can be copied out between kernels.
     launch_first_input(st, B, E, e->tb.tske + (long)e->cfg.task_id * E, e->cond, e->xdec);
+    if (e->overlap && !e->overlap_suspended && io.next_follows && !tr && !e->profiling && (B == 1 || e->overlap_mode == 2)) {
+        const auto tp0 = std::chrono::steady_clock::now();
+        if (int rc = launch_prefix<T>(e, io, ego)) return rc;
+        if (getenv("UMGEN_DEBUG_TIMING"))
+            fprintf(stderr, "[umgen] host time to enqueue the background pass: %.1f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+    }
     const bool graphs = e->cfg.use_graphs && !tr;
     if (graphs && e->step_graph_B != B) {
         for (auto& row : e->step_graph)
@@ -582,6 +711,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->tm.oar_ms += ms;
     hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->tm.total_ms += ms;
     e->tm.frames += 1;
+    if (use_px) e->tm.overlapped_frames += 1;
     if (e->profiling) {
         for (size_t i = 0; i < e->gemm_ev_used; ++i) {
             hipEventElapsedTime(&ms, e->gemm_ev[i].first, e->gemm_ev[i].second);
@@ -676,7 +806,29 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return e->fail(UMGEN_E_HIP, "no HIP device visible: libumgen_hip has no CPU fallback");
     HIPCHK(e, hipSetDevice(cfg->device));
-    HIPCHK(e, hipStreamCreate(&e->stream));
+    // overlapped TAR pass (UMGEN_OVERLAP=0 disables it): the decode stream and the background stream get disjoint CU masks --
+    // measured on MI355X, a decode loop sharing CUs with a concurrent GEMM stream runs at a quarter of its speed, with disjoint
+    // masks (64 background CUs) it loses 8 %
+    e->overlap = cfg->max_cond_frames >= 2;
+    if (const char* ov = getenv("UMGEN_OVERLAP")) { e->overlap_mode = ov[0] - '0'; e->overlap = e->overlap && ov[0] != '0'; }
+    int bg_cus = 64;   // the mask takes effect in whole XCDs (32 CUs) on MI355X: 64 = 2 of the 8 XCDs for the background stream
+    if (const char* bc = getenv("UMGEN_BG_CUS")) bg_cus = std::max(32, std::min(128, atoi(bc)));
+    if (e->overlap) {
+        hipDeviceProp_t prop;
+        HIPCHK(e, hipGetDeviceProperties(&prop, cfg->device));
+        const int ncu = prop.multiProcessorCount;
+        if (ncu < 2 * bg_cus) e->overlap = false;
+        else {
+            std::vector<uint32_t> mbg((ncu + 31) / 32, 0u), mfg((ncu + 31) / 32, 0u);
+            for (int cu = 0; cu < ncu; ++cu) (cu < bg_cus ? mbg : mfg)[cu / 32] |= 1u << (cu % 32);
+            HIPCHK(e, hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mfg.size(), mfg.data()));
+            HIPCHK(e, hipExtStreamCreateWithCUMask(&e->bg_stream, (uint32_t)mbg.size(), mbg.data()));
+            HIPCHK(e, hipEventCreate(&e->ev_tar_done));
+            HIPCHK(e, hipEventCreate(&e->ev_bg_done));
+            HIPCHK(e, hipEventCreate(&e->ev_bg0));
+        }
+    }
+    if (!e->overlap) HIPCHK(e, hipStreamCreate(&e->stream));
     for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
     e->E = cfg->n_embd;
     e->H = cfg->n_head;
@@ -785,6 +937,21 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     e->kv_scene_stride = (long)e->Lmax * 2 * E;
     e->kv_layer_stride = (long)Bm * e->kv_scene_stride;
     if (int rc = dev_alloc(e, &e->kvcache, (size_t)cfg->n_oar_layer * e->kv_layer_stride * e->tsz)) return rc;
+    if (e->overlap) {   // slot caches of the overlapped TAR pass: k | v rows of every temporal sub-block, all history slots
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
+        size_t need = 0;
+        for (int st = 0; st < 4; ++st) need += e->stk[st].size() * Bm * Tm * (size_t)stack_len(st) * 2 * E * e->tsz;
+        if (need > free_b / 2) {
+            e->overlap = false;     // keep the plain path rather than crowding the KV caches out
+        } else {
+            for (int st = 0; st < 4; ++st) {
+                e->tcache[st].resize(e->stk[st].size(), nullptr);
+                for (auto& c : e->tcache[st])
+                    if (int rc = dev_alloc(e, &c, Bm * Tm * (size_t)stack_len(st) * 2 * E * e->tsz)) return rc;
+            }
+        }
+    }
     if (int rc = dalloc(e, &e->d_pose, Bm * Tm * 3)) return rc;
     if (int rc = dalloc(e, &e->d_pose_shift, Bm * Tm * 3)) return rc;
     if (int rc = dalloc(e, &e->d_map, Bm * Tm * kNMap)) return rc;
@@ -947,6 +1114,7 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
     if (int rc = check_sampling(e, sampling)) return rc;
     if (!pose || !map || !bbox3d || !image || !out_pose || !out_map || !out_bbox3d || !out_image) return e->fail(UMGEN_E_INVALID, "null token buffer");
     e->tm = umgen_timings{};
+    e->overlap_suspended = false;
     const int T_out = T_in + new_frames;
     const int S[4] = {kNPose, kNMap, kNBox, kNImg};
     const int64_t* in[4] = {pose, map, bbox3d, image};
@@ -997,6 +1165,9 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
         }
         FrameIO io{B, T_cur, hist[0].data(), hist[1].data(), hist[2].data(), hist[3].data(), have_ctl ? cp.data() : nullptr,
                    cs.empty() ? nullptr : cs.data(), idx, sampling, nullptr, frame_out.data()};
+        io.cond_cap = cond_frames;
+        io.next_follows = idx + 1 < new_frames;
+        io.next_has_ctrl_pose = have_ctl && idx + 1 < T_ctl;
         if (int rc = run_frame_any(e, io)) return rc;
         // append (UMGen.py:1636-1666): control pose tokens are copied verbatim; everything else is what was generated
         const int off[4] = {0, kOffMap, kOffBox, kOffImg};
@@ -1028,6 +1199,8 @@ int umgen_destroy(umgen_engine* e) {
     for (auto& pr : e->gemm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto& pr : e->attn_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (e->tb.gmap) {}   // tables are in allocs
+    if (e->bg_stream) { hipStreamSynchronize(e->bg_stream); hipStreamDestroy(e->bg_stream); }
+    for (hipEvent_t ev : {e->ev_tar_done, e->ev_bg_done, e->ev_bg0}) if (ev) hipEventDestroy(ev);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return UMGEN_OK;

@@ -29,7 +29,9 @@ struct WindowTokens {
     const int *map;    // [B][T][1024]
     const int *box;    // [B][T][660]
     const int *img;    // [B][T][512]
-    int B, T;
+    int B, T;          // scenes, history slots covered by this pass (rows of X are (b, t_local, s))
+    int Tfull = 0;     // slots per scene in the token arrays / pose_diff (0: = T)
+    int t0 = 0;        // first slot of the pass: tokens and tpe are indexed with t0 + t_local
 };
 
 struct SamplerParams {
@@ -73,7 +75,7 @@ struct SampleArgs {
 void launch_embed_stack(hipStream_t s, int stack, const EmbedTables& tb, const WindowTokens& w, float* X, float* mapfeat);
 // warp the map features by the ego motion and finish the map rows of X (UMGen.py:321-354, 729-736, 799-802, 836-840)
 void launch_warp_map(hipStream_t s, int stack, const EmbedTables& tb, int B, int T, const float* mapfeat, const float* pose_diff,
-                     float* X, float* warped_last);
+                     float* X, float* warped_last, int Tfull = 0, int t0 = 0);
 // conditioning rows: LayerNorm of the last history frame of a stack (+ warped-map prior) -> cond[b][s] (UMGen.py:1496-1511)
 void launch_cond_rows(hipStream_t s, int stack, int B, int T, int E, const float* X, const float* ln_w, const float* warped_last,
                       float* cond);

@@ -25,10 +25,11 @@ __global__ __launch_bounds__(128) void embed_stack_kernel(int stack, EmbedTables
     const int t = (int)((row / SS) % w.T);
     const int b = (int)(row / ((long)SS * w.T));
     const int E = tb.E;
-    const long fr = (long)b * w.T + t;
+    const long frl = (long)b * w.T + t;                                        // frame index inside this pass (mapfeat rows)
+    const long fr = (long)b * (w.Tfull ? w.Tfull : w.T) + w.t0 + t;            // frame index in the token arrays
     float* xr = X + row * E;
     const float* spe = tb.spe + (long)s * E;
-    const float* tpe = tb.tpe + (long)t * E;
+    const float* tpe = tb.tpe + (long)(w.t0 + t) * E;
     const int aux = fixed_aux_id(s);
     if (aux >= 0) {
         const float* a = tb.axe + (long)aux * E;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(128) void embed_stack_kernel(int stack, EmbedTables
         if (stack == STACK_EGO) {
             for (int c = threadIdx.x; c < E; c += 128) xr[c] = (gm[c] + spe[c]) + tpe[c];
         } else {
-            float* mf = mapfeat + (fr * kNMap + k) * E;
+            float* mf = mapfeat + (frl * kNMap + k) * E;
             if (stack == STACK_TAR) {   // grid-centre positional embedding only in forward_tar_net (UMGen.py:722-726)
                 const bf16_t* gp = tb.grid_posi + (long)k * E;
                 for (int c = threadIdx.x; c < E; c += 128) mf[c] = gm[c] + bf16_to_f32(gp[c]);
@@ -84,16 +85,17 @@ __device__ inline float base_coord(int i) {   // at::linspace(-1, 1, 32) * 31 / 
 
 __global__ __launch_bounds__(128) void warp_map_kernel(int stack, EmbedTables tb, int T, const float* __restrict__ mapfeat,
                                                        const float* __restrict__ pose_diff, float* __restrict__ X,
-                                                       float* __restrict__ warped_last) {
+                                                       float* __restrict__ warped_last, int Tfull, int t0) {
     const int SS = stack_len(stack);
-    const long cell = blockIdx.x;            // (b*T + t)*1024 + k
+    const long cell = blockIdx.x;            // (b*T + t_local)*1024 + k
     const int k = (int)(cell % kNMap);
-    const long fr = cell / kNMap;
-    const int t = (int)(fr % T);
+    const long fr = cell / kNMap;            // frame index inside this pass
     const int b = (int)(fr / T);
+    const int t = t0 + (int)(fr % T);        // history slot
+    const long frg = (long)b * Tfull + t;    // frame index in pose_diff
     const int E = tb.E;
     const int hy = k >> 5, wx = k & 31;
-    const float dxm = pose_diff[fr * 3 + 0], dym = pose_diff[fr * 3 + 1], th = pose_diff[fr * 3 + 2];
+    const float dxm = pose_diff[frg * 3 + 0], dym = pose_diff[frg * 3 + 1], th = pose_diff[frg * 3 + 2];
     const float dx = 2.0f * (dxm / 4.0f) / 32.0f, dy = 2.0f * (dym / 4.0f) / 32.0f;
     const float cs = cosf(-th), sn = sinf(-th);
     const float bx = base_coord(wx), by = base_coord(hy);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(128) void warp_map_kernel(int stack, EmbedTables tb
     float* xr = X + ((fr * SS) + s) * E;
     const float* spe = tb.spe + (long)s * E;
     const float* tpe = tb.tpe + (long)t * E;
-    float* wl = (warped_last && t == T - 1) ? warped_last + ((long)b * kNMap + k) * E : nullptr;
+    float* wl = (warped_last && t == Tfull - 1) ? warped_last + ((long)b * kNMap + k) * E : nullptr;
     for (int c = threadIdx.x; c < E; c += 128) {
         float o = 0.f;
         if (in_nw) o += pnw[c] * nw;
@@ -130,9 +132,9 @@ __global__ __launch_bounds__(128) void warp_map_kernel(int stack, EmbedTables tb
 }
 
 void launch_warp_map(hipStream_t s, int stack, const EmbedTables& tb, int B, int T, const float* mapfeat, const float* pose_diff,
-                     float* X, float* warped_last) {
+                     float* X, float* warped_last, int Tfull, int t0) {
     hipLaunchKernelGGL(warp_map_kernel, dim3((unsigned)((long)B * T * kNMap)), dim3(128), 0, s, stack, tb, T, mapfeat, pose_diff, X,
-                       warped_last);
+                       warped_last, Tfull ? Tfull : T, t0);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -46,7 +46,11 @@ template <typename T> void launch_layernorm(hipStream_t s, const float* x, long 
 void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int S_pad, int H);
 template <typename T> void launch_attn_spatial_valu(hipStream_t s, const T* qk, const T* vt, T* y, int F, int S, int S_pad, int H);
 // temporal causal attention over T frames per spatial position: qkv [B*T*S][3E] row-major, y [B*T*S][E]
-template <typename T> void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int T_, int S, int H);
+// Temporal attention over history slots [t0, t0 + Tn) held in the qkv rows; k | v of slots [0, t0) are read from `cache`
+// ([B][Tcap][S][2E], dtype T) and, when write != 0, the k | v rows of the new slots are appended to it (attn.hip).
+struct TemporalRange { int t0; void* cache; int Tcap; int write; };
+template <typename T> void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int Tn, int S, int H,
+                                                TemporalRange tr = TemporalRange{0, nullptr, 0, 0});
 
 // few-query attention over a key/value stream (OAR decode, ego decoder): partial pass, NSPLIT splits of the keys.
 //   q   [NQ][E] fp32;  K row of (scene sc, head h, key k) = kv_base + sc*scene_stride + h*head_stride + k*key_stride (48 values),
