@@ -80,6 +80,8 @@ struct umgen_engine {
     bool overlap = false, overlap_suspended = false;
     int overlap_mode = 1;                // UMGEN_OVERLAP: 0 off, 1 on for one scene per GPU (default), 2 always
     hipStream_t bg_stream = nullptr;
+    hipStream_t full_stream = nullptr;   // unmasked: whole-window passes, profiling frames and rollouts that do not overlap use all CUs
+    hipEvent_t ev_pre_done = nullptr;
     hipEvent_t ev_tar_done = nullptr, ev_bg_done = nullptr, ev_bg0 = nullptr;
     bool bg_pending = false;
     std::vector<void*> tcache[4];        // per stack, per BlockTAR: [max_batch][max_cond_frames][S_stack][2E] of T
@@ -567,7 +569,9 @@ int launch_prefix(umgen_engine* e, const FrameIO& io, const std::vector<int>& eg
 template <typename T>
 int run_frame(umgen_engine* e, const FrameIO& io) {
     const int E = e->E, B = io.B, Tn = io.T;
-    hipStream_t st = e->stream;
+    hipStream_t const fg = e->stream;   // the decode stream of overlapped rollouts (6 of the 8 XCDs when the overlap exists)
+    struct RestoreStream { umgen_engine* e; hipStream_t s; ~RestoreStream() { e->stream = s; } } restore{e, fg};
+    hipStream_t st = fg;
     SamplerParams sp{io.smp->method, io.smp->top_k, io.smp->top_k_map, io.smp->topk_image, io.smp->p, io.smp->p_map, io.smp->temperature,
                      io.smp->rule_constrain, io.smp->merge_ar_tar, io.smp->only_ar};
     const umgen_trace* tr = io.trace;
@@ -585,6 +589,15 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         e->tm.bg_ms += bms;
         e->bg_pending = false;
     }
+    // overlapped TAR pass: when the previous frame's background pass covered slots 0..Tn-2 of this very window, only the last slot
+    // is pushed through the stacks now (against the per-layer slot caches)
+    const bool use_px = prefix_matches(e, io);
+    const bool ov_active = e->overlap && !e->overlap_suspended && !e->profiling && !tr && (B == 1 || e->overlap_mode == 2);
+    // whole-window passes run on all CUs; the decode loop leaves the background stream's XCDs alone only when a pass can follow
+    hipStream_t const pre = (e->full_stream && !use_px) ? e->full_stream : fg;
+    hipStream_t const dec = (e->full_stream && !ov_active) ? e->full_stream : fg;
+    st = pre;
+    e->stream = pre;
     HIPCHK(e, hipMemcpyAsync(e->d_pose, io.pose, (size_t)B * Tn * 3 * 4, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->d_map, io.map, (size_t)B * Tn * kNMap * 4, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->d_box, io.box, (size_t)B * Tn * kNBox * 4, hipMemcpyHostToDevice, st));
@@ -604,9 +617,6 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     HIPCHK(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int), st));
     HIPCHK(e, hipMemsetAsync(e->d_nboxes, 0, (size_t)B * sizeof(int), st));
 
-    // overlapped TAR pass: when the previous frame's background pass covered slots 0..Tn-2 of this very window, only the last slot
-    // is pushed through the stacks now (against the per-layer slot caches)
-    const bool use_px = prefix_matches(e, io);
     const int t0 = use_px ? Tn - 1 : 0, Tc = use_px ? 1 : Tn, cmode = use_px ? 2 : 0;
     e->px.valid = false;
     WindowTokens w{e->d_pose, e->d_map, e->d_box, e->d_img, B, Tc, Tn, t0};
@@ -661,8 +671,14 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     // emits scene token j; j = 0..4 replays the given pose prefix, bos/eos are fixed, everything else is sampled.
     // A step is a fixed kernel sequence with fixed arguments (all per-step state is device resident), replayed from a
     // hipGraph per step kind; trace mode launches directly so the logits can be copied out between kernels.
+    if (dec != pre) {
+        HIPCHK(e, hipEventRecord(e->ev_pre_done, pre));
+        HIPCHK(e, hipStreamWaitEvent(dec, e->ev_pre_done, 0));
+    }
+    st = dec;
+    e->stream = dec;
     launch_first_input(st, B, E, e->tb.tske + (long)e->cfg.task_id * E, e->cond, e->xdec);
-    if (e->overlap && !e->overlap_suspended && io.next_follows && !tr && !e->profiling && (B == 1 || e->overlap_mode == 2)) {
+    if (ov_active && io.next_follows) {
         const auto tp0 = std::chrono::steady_clock::now();
         if (int rc = launch_prefix<T>(e, io, ego)) return rc;
         if (getenv("UMGEN_DEBUG_TIMING"))
@@ -823,6 +839,8 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
             for (int cu = 0; cu < ncu; ++cu) (cu < bg_cus ? mbg : mfg)[cu / 32] |= 1u << (cu % 32);
             HIPCHK(e, hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mfg.size(), mfg.data()));
             HIPCHK(e, hipExtStreamCreateWithCUMask(&e->bg_stream, (uint32_t)mbg.size(), mbg.data()));
+            HIPCHK(e, hipStreamCreateWithFlags(&e->full_stream, hipStreamNonBlocking));
+            HIPCHK(e, hipEventCreate(&e->ev_pre_done));
             HIPCHK(e, hipEventCreate(&e->ev_tar_done));
             HIPCHK(e, hipEventCreate(&e->ev_bg_done));
             HIPCHK(e, hipEventCreate(&e->ev_bg0));
@@ -1200,7 +1218,8 @@ int umgen_destroy(umgen_engine* e) {
     for (auto& pr : e->attn_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (e->tb.gmap) {}   // tables are in allocs
     if (e->bg_stream) { hipStreamSynchronize(e->bg_stream); hipStreamDestroy(e->bg_stream); }
-    for (hipEvent_t ev : {e->ev_tar_done, e->ev_bg_done, e->ev_bg0}) if (ev) hipEventDestroy(ev);
+    if (e->full_stream) hipStreamDestroy(e->full_stream);
+    for (hipEvent_t ev : {e->ev_tar_done, e->ev_bg_done, e->ev_bg0, e->ev_pre_done}) if (ev) hipEventDestroy(ev);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return UMGEN_OK;
