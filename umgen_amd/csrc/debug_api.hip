@@ -165,7 +165,17 @@ int umgen_dbg_gemv(int bf16, const float* x, const float* ln_w, const void* W, c
     a.N = N; a.K = K; a.M = M; a.out_mode = gelu ? GEMV_OUT_GELU : GEMV_OUT_F32; a.out = (float*)dO.p; a.ldo = N; a.E = K;
     if (bf16) launch_gemv<bf16_t>(nullptr, a); else launch_gemv<float>(nullptr, a);
     if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
-    return down(out, dO.p, (size_t)M * N * 4);
+    if (int rc = down(out, dO.p, (size_t)M * N * 4)) return rc;
+    if (M > 1) {   // the one-row-per-workgroup form (what the engine launches for several scenes) must give the same bits
+        std::vector<float> alt((size_t)M * N);
+        (void)hipMemset(dO.p, 0, (size_t)M * N * 4);
+        a.rows_per_block = 1;
+        if (bf16) launch_gemv<bf16_t>(nullptr, a); else launch_gemv<float>(nullptr, a);
+        if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
+        if (int rc = down(alt.data(), dO.p, (size_t)M * N * 4)) return rc;
+        if (memcmp(alt.data(), out, (size_t)M * N * 4) != 0) return UMGEN_E_STATE;
+    }
+    return UMGEN_OK;
 }
 
 }  // extern "C"

@@ -97,6 +97,7 @@ struct umgen_engine {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     umgen_timings tm{};
     bool profiling = false;
+    int rows_per_block = -1;              // few-row launches: rows per workgroup; -1 = by row count (1 up to 6 rows, else 2), 0 = row loop
     bool dbg_same_layer = false;          // UMGEN_DEBUG_SAME_LAYER=1: timing experiment, every decode layer reads layer 0's weights
     bool fused_decode = false;            // UMGEN_FUSED_DECODE=1 (experiment, see oar_layers)
     // decode step graphs per (kind: fixed / map / bbox3d / image, number of attention key splits 1..8)
@@ -340,11 +341,17 @@ void run_stack(umgen_engine* e, int stack, const WindowTokens& w, int cache_mode
     }
 }
 
+// Few-row launches with several rows (scenes, ego queries): one row per workgroup keeps the single-row dependency chain (4 scenes:
+// 2.58 vs 3.12 s of decode per frame) but re-reads the weights from L2 once per row; from 7 rows on, 2 rows per workgroup win
+// (8 scenes: 3.53 vs 3.77 s).  UMGEN_ROWS_PER_BLOCK overrides (0 = every workgroup loops over all rows).
+inline int rows_per_block_for(const umgen_engine* e, int M) { return e->rows_per_block >= 0 ? e->rows_per_block : (M <= 6 ? 1 : 2); }
+
 // GemvArgs helpers
 template <typename T>
 void gemv(umgen_engine* e, const float* x, long ldx, const float* ln_w, const void* W, const float* bias, int N, int K, int M,
           int mode, float* out, long ldo) {
     GemvArgs a{};
+    a.rows_per_block = rows_per_block_for(e, M);
     a.x = x; a.ldx = ldx; a.ln_w = ln_w; a.W = W; a.bias = bias; a.N = N; a.K = K; a.M = M; a.out_mode = mode; a.out = out; a.ldo = ldo;
     a.E = e->E;
     launch_gemv<T>(e->stream, a);
@@ -353,6 +360,7 @@ template <typename T>
 void gemv_resid(umgen_engine* e, const float* a_in, long lda, const float* part, const void* W, const float* bias, int N, int K, int M,
                 float* x, long ldx, int ns = 1) {
     GemvResidArgs a{};
+    a.rows_per_block = rows_per_block_for(e, M);
     a.a = a_in; a.lda = lda; a.part = part; a.H = e->H; a.ns = ns; a.W = W; a.bias = bias; a.N = N; a.K = K; a.M = M; a.x = x; a.ldx = ldx;
     launch_gemv_resid<T>(e->stream, a);
 }
@@ -422,7 +430,7 @@ void oar_layers(umgen_engine* e, int B, int ns, int ns_cached) {
             GemvArgs a{};
             a.x = e->xdec; a.ldx = E; a.ln_w = w.ln_a; a.W = w.attn.Wqkv; a.bias = w.attn.bqkv; a.N = 3 * E; a.K = E; a.M = B;
             a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len;
-            a.Lmax = e->Lmax; a.E = E;
+            a.Lmax = e->Lmax; a.E = E; a.rows_per_block = rows_per_block_for(e, B);
             launch_gemv<T>(e->stream, a);
             launch_attn_partial<T>(e->stream, e->qdec, cache, e->kv_scene_stride, (long)e->Lmax * kHeadDim, kHeadDim,
                                    (long)H * e->Lmax * kHeadDim, B, 1, H, d_len, 1, ns, e->part);
@@ -496,6 +504,7 @@ int enqueue_step(umgen_engine* e, int B, int mod, int ns, int ns_cached, const u
             GemvArgs a{};
             a.x = e->cond; a.ldx = (long)kSeq * E; a.d_xoff = &e->d_state->step; a.xoff_mul = E; a.W = e->head_tar_box;
             a.N = V; a.K = E; a.M = B; a.out_mode = GEMV_OUT_F32; a.out = e->logits_tar; a.ldo = sa.ld_logits; a.E = E;
+            a.rows_per_block = rows_per_block_for(e, B);
             launch_gemv<T>(st, a);
         }
         if (tr) {
@@ -852,6 +861,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     e->H = cfg->n_head;
     if (const char* fd = getenv("UMGEN_FUSED_DECODE")) e->fused_decode = fd[0] == '1';
     if (const char* sl = getenv("UMGEN_DEBUG_SAME_LAYER")) e->dbg_same_layer = sl[0] == '1';
+    if (const char* rb = getenv("UMGEN_ROWS_PER_BLOCK")) e->rows_per_block = rb[0] - '0';
     e->tsz = cfg->precision == UMGEN_PREC_BF16 ? 2 : 4;
     const int64_t E = e->E;
     const std::string t = "transformer.";

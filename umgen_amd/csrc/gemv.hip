@@ -20,25 +20,41 @@ template <> struct WChunk<float> { float4 a, b; };
 // weights are streamed exactly once per launch: non-temporal loads (MI355X_MICROARCH.md "nt-weights": issue->landed -18 %)
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+// (NT = false when several workgroups of one XCD read the same rows: one scene per workgroup, the others hit the L2)
+template <bool NT = true>
 __device__ inline void wload(WChunk<bf16_t>& w, const bf16_t* p) {
 #ifndef UMGEN_NO_NT
-    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
-    w.v = make_uint4(t.x, t.y, t.z, t.w);
-#else
-    w.v = *reinterpret_cast<const uint4*>(p);
+    if (NT) {
+        const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        w.v = make_uint4(t.x, t.y, t.z, t.w);
+        return;
+    }
 #endif
+    w.v = *reinterpret_cast<const uint4*>(p);
 }
+template <bool NT = true>
 __device__ inline void wload(WChunk<float>& w, const float* p) {
 #ifndef UMGEN_NO_NT
-    const f32x4v_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4v_t*>(p));
-    const f32x4v_t b = __builtin_nontemporal_load(reinterpret_cast<const f32x4v_t*>(p + 4));
-    w.a = make_float4(a.x, a.y, a.z, a.w);
-    w.b = make_float4(b.x, b.y, b.z, b.w);
-#else
+    if (NT) {
+        const f32x4v_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4v_t*>(p));
+        const f32x4v_t b = __builtin_nontemporal_load(reinterpret_cast<const f32x4v_t*>(p + 4));
+        w.a = make_float4(a.x, a.y, a.z, a.w);
+        w.b = make_float4(b.x, b.y, b.z, b.w);
+        return;
+    }
+#endif
     w.a = *reinterpret_cast<const float4*>(p);
     w.b = *reinterpret_cast<const float4*>(p + 4);
-#endif
 }
+
+// One (feature tile, row) per workgroup with XCD affinity: workgroup b runs on XCD b % 8 (observed), so the rows of one tile are
+// given to workgroups b, b + 8, b + 16, ... -- the tile's weights are fetched from HBM into ONE L2 and hit there for the other rows.
+__device__ inline void tile_row_of_block(int bid, int rows, int& tile, int& row) {
+    const int q = bid >> 3;
+    row = q % rows;
+    tile = (q / rows) * 8 + (bid & 7);
+}
+inline int tile_row_grid(int tiles, int rows) { return ((tiles + 7) / 8) * 8 * rows; }
 __device__ inline void wzero(WChunk<bf16_t>& w) { w.v = make_uint4(0, 0, 0, 0); }
 __device__ inline void wzero(WChunk<float>& w) { w.a = make_float4(0, 0, 0, 0); w.b = w.a; }
 __device__ inline void wunpack(const WChunk<bf16_t>& w, float (&o)[8]) {
@@ -54,12 +70,15 @@ __device__ inline void wunpack(const WChunk<float>& w, float (&o)[8]) {
 // ---------------------------------------------------------------------------------------------------------
 // out[m][n] = LN(x[m]) . W[n] + bias[n]     K = n_embd (<= 1536): NCH = ceil(K / 512) chunks of 8 per lane
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int MB, int NCH, int RPW>
+template <typename T, int MB, int NCH, int RPW, bool PERROW = false>
 __device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
-    const int n0 = (bid * 4 + wave) * RPW;
+    int tile = bid, mb = 0;                       // mb: first input row of this workgroup
+    if (PERROW) { tile_row_of_block(bid, (a.M + MB - 1) / MB, tile, mb); mb *= MB; }
+    const int Mloc = PERROW ? min(MB, a.M - mb) : a.M;
+    const int n0 = (tile * 4 + wave) * RPW;
     if (n0 >= a.N) return;
     WChunk<T> w[RPW][NCH];
 #pragma unroll
@@ -68,7 +87,7 @@ __device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane * 8 + 512 * i;
-            if (c < K) wload(w[r][i], wr + c); else wzero(w[r][i]);
+            if (c < K) wload<!PERROW>(w[r][i], wr + c); else wzero(w[r][i]);
         }
     }
     float bias[RPW];
@@ -84,11 +103,11 @@ __device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
             if (c < K) load8(a.ln_w + c, lw[i]);
         }
     }
-    for (int m0 = 0; m0 < a.M; m0 += MB) {
+    for (int m0 = 0; m0 < Mloc; m0 += MB) {
         float xv[MB][NCH][8];
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            const float* xr = xbase + (long)min(m0 + m, a.M - 1) * a.ldx;
+            const float* xr = xbase + (long)(mb + min(m0 + m, Mloc - 1)) * a.ldx;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int c = lane * 8 + 512 * i;
@@ -146,8 +165,8 @@ __device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
             if (lane == 0 && n < a.N) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
-                    const int mm = m0 + m;
-                    if (mm < a.M) {
+                    const int mm = mb + m0 + m;
+                    if (m0 + m < Mloc) {
                         const float v = acc[m] + bias[r];
                         if (a.out_mode == GEMV_OUT_QKV) {
                             if (n < a.E) __builtin_nontemporal_store(v, &a.out[(long)mm * a.ldo + n]);
@@ -168,19 +187,25 @@ __device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
     }
 }
 
-template <typename T, int MB, int NCH, int RPW>
+template <typename T, int MB, int NCH, int RPW, bool PERROW = false>
 __global__ __launch_bounds__(256) void gemv_ln_kernel(GemvArgs a) {
 #ifdef UMGEN_DRY_DECODE
     return;   // launch-floor experiment: same graph, no work
 #endif
-    gemv_ln_body<T, MB, NCH, RPW>(a, blockIdx.x);
+    gemv_ln_body<T, MB, NCH, RPW, PERROW>(a, blockIdx.x);
 }
 
 template <typename T, int NCH>
 static void launch_gemv_nch(hipStream_t s, const GemvArgs& a) {
     constexpr int RPW = 2;   // measured: 2 rows per wave (288 workgroups for N=2304) beats 1 and 4
     const int grid = (a.N + 4 * RPW - 1) / (4 * RPW);
-    if (a.M == 1) hipLaunchKernelGGL((gemv_ln_kernel<T, 1, NCH, RPW>), dim3(grid), dim3(256), 0, s, a);
+    // several rows (scenes): one row per workgroup keeps every launch on the single-row dependency chain (measured at 4 scenes:
+    // 8.3 us for the row-looping form vs 4.8 us for one row) at the price of L2 re-reads of the weights
+    if (a.M > 1 && a.rows_per_block == 1)
+        hipLaunchKernelGGL((gemv_ln_kernel<T, 1, NCH, RPW, true>), dim3(tile_row_grid(grid, a.M)), dim3(256), 0, s, a);
+    else if (a.M > 2 && a.rows_per_block == 2)
+        hipLaunchKernelGGL((gemv_ln_kernel<T, 2, NCH, RPW, true>), dim3(tile_row_grid(grid, (a.M + 1) / 2)), dim3(256), 0, s, a);
+    else if (a.M == 1) hipLaunchKernelGGL((gemv_ln_kernel<T, 1, NCH, RPW>), dim3(grid), dim3(256), 0, s, a);
     else if (a.M == 2) hipLaunchKernelGGL((gemv_ln_kernel<T, 2, NCH, RPW>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemv_ln_kernel<T, 4, NCH, RPW>), dim3(grid), dim3(256), 0, s, a);
 }
@@ -199,16 +224,28 @@ template void launch_gemv<bf16_t>(hipStream_t, const GemvArgs&);
 // COMBINE: a[m][:] is first merged from the attention partials (K == H*48) into LDS, after the weight loads are in flight
 // ---------------------------------------------------------------------------------------------------------
 
-template <typename T, int MB, int NCH, bool COMBINE>
-__global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
+template <typename T, int MB, int NCH, bool COMBINE, bool PERROW = false>
+__global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a_in) {
 #ifdef UMGEN_DRY_DECODE
     return;
 #endif
     extern __shared__ __attribute__((aligned(16))) float as[];   // [M][K] when COMBINE
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    GemvResidArgs a = a_in;
+    int tile = blockIdx.x;
+    if (PERROW) {   // this workgroup: one (feature tile, row); everything below sees a one-row problem
+        int mb;
+        tile_row_of_block(blockIdx.x, (a_in.M + MB - 1) / MB, tile, mb);
+        mb *= MB;
+        a.M = min(MB, a_in.M - mb);
+        a.x += (long)mb * a.ldx;
+        if (a.a) a.a += (long)mb * a.lda;
+        if (a.part) a.part += (long)mb * a.H * kAttnRec;
+        if (a.self_q) { a.self_q += (long)mb * a.K; a.self_kv += (long)mb * 2 * a.K; }
+    }
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
-    const int n = blockIdx.x * 4 + wave;
+    const int n = tile * 4 + wave;
     const bool active = n < a.N;
     WChunk<T> w[NCH];
     {
@@ -216,7 +253,7 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane * 8 + 512 * i;
-            if (c < K) wload(w[i], wr + c); else wzero(w[i]);
+            if (c < K) wload<!PERROW>(w[i], wr + c); else wzero(w[i]);
         }
     }
     const float bias = (a.bias && active) ? a.bias[n] : 0.f;
@@ -357,6 +394,16 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a) {
 template <typename T, int NCH, bool COMBINE>
 static void launch_resid_nch(hipStream_t s, const GemvResidArgs& a) {
     const int grid = (a.N + 3) / 4;
+    if (a.M > 1 && a.rows_per_block == 1) {   // one (feature tile, row) per workgroup, see launch_gemv_nch
+        const size_t shm1 = COMBINE ? ((size_t)a.K + (size_t)a.H * kAttnPad) * sizeof(float) : 0;
+        hipLaunchKernelGGL((gemv_resid_kernel<T, 1, NCH, COMBINE, true>), dim3(tile_row_grid(grid, a.M)), dim3(256), shm1, s, a);
+        return;
+    }
+    if (a.M > 2 && a.rows_per_block == 2 && NCH <= 6) {
+        const size_t shm2 = COMBINE ? 2 * ((size_t)a.K + (size_t)a.H * kAttnPad) * sizeof(float) : 0;
+        hipLaunchKernelGGL((gemv_resid_kernel<T, 2, NCH, COMBINE, true>), dim3(tile_row_grid(grid, (a.M + 1) / 2)), dim3(256), shm2, s, a);
+        return;
+    }
     const size_t shm = COMBINE ? ((size_t)a.M * a.K + (size_t)a.M * a.H * kAttnPad) * sizeof(float) : 0;
     constexpr int MBmax = (NCH <= 3) ? 4 : (NCH <= 6 ? 2 : 1);
     if (a.M == 1 || MBmax == 1) hipLaunchKernelGGL((gemv_resid_kernel<T, 1, NCH, COMBINE>), dim3(grid), dim3(256), shm, s, a);
@@ -368,7 +415,7 @@ template <typename T>
 void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a0) {
     GemvResidArgs a = a0;
     const int nch = (a.K + 511) / 512;
-    if (a.part && a.M > 8) {   // the merged attention rows are staged in LDS: at most 8 rows per launch
+    if (a.part && a.M > 8 && a.rows_per_block != 1) {   // the merged attention rows are staged in LDS: at most 8 rows per launch
         for (int m = 0; m < a0.M; m += 8) {
             GemvResidArgs b = a0;
             b.M = min(8, a0.M - m);

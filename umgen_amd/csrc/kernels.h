@@ -84,6 +84,7 @@ struct GemvArgs {
     int out_mode;
     float* out; long ldo;
     void* cache; long scene_stride; const int* d_len; int Lmax;   // GEMV_OUT_QKV
+    int rows_per_block;            // 0: a workgroup loops over all M rows; 1: one (feature tile, row) per workgroup (set by the launcher)
     float* kv_f32;                 // GEMV_OUT_QKV, optional: fp32 copy [M][2E] of the new k | v rows (self term of the fused decode attention)
     int E;
 };
@@ -98,6 +99,7 @@ struct GemvResidArgs {
     const float* self_kv;            // more softmax term (the fused decode attention only covers the cached keys)  [M][2E]
     const void* W; const float* bias; int N, K, M;
     float* x; long ldx;
+    int rows_per_block;              // as in GemvArgs
 };
 template <typename T> void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a);
 
