@@ -602,8 +602,8 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     // is pushed through the stacks now (against the per-layer slot caches)
     const bool use_px = prefix_matches(e, io);
     const bool ov_active = e->overlap && !e->overlap_suspended && !e->profiling && !tr && (B == 1 || e->overlap_mode == 2);
-    // whole-window passes run on all CUs; the decode loop leaves the background stream's XCDs alone only when a pass can follow
-    hipStream_t const pre = (e->full_stream && !use_px) ? e->full_stream : fg;
+    // the ego / TAR phase runs on all CUs; the decode loop leaves the background stream's XCDs alone only when a pass can follow
+    hipStream_t const pre = e->full_stream ? e->full_stream : fg;   // (the background stream is idle until this phase is over)
     hipStream_t const dec = (e->full_stream && !ov_active) ? e->full_stream : fg;
     st = pre;
     e->stream = pre;
