@@ -98,9 +98,14 @@ def install_stubs():
     _mod("cv2")
 
     class _T:
-        class Compose:
+        class Compose:      # torchvision.transforms.Compose: apply the transforms in order
             def __init__(self, ts):
                 self.ts = ts
+
+            def __call__(self, x):
+                for t in self.ts:
+                    x = t(x)
+                return x
 
         class ToTensor:
             def __call__(self, x):

@@ -1,0 +1,113 @@
+"""Scene pickle reader / token writer against vectors recorded from the reference's own
+dataset class and transforms (tests/golden/make_scene_golden.py), plus the pieces in isolation."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from umgen_amd import scene_io
+from umgen_amd.config import BBOX_PAD, MOD_ORDER
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "scene_reader.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def test_reader_reproduces_the_reference_dataset_tokens(gold, tmp_path):
+    for seed, n_frames, block, n_tracks in gold["cases"].tolist():
+        path = tmp_path / f"scene_{seed}_synthetic_clip_000.pkl"
+        with open(path, "wb") as f:
+            pickle.dump(scene_io.synthetic_raw_scene(seed, n_frames, n_tracks), f)
+        item = scene_io.SceneReader(str(path), block_size=block)[0]
+        for m in MOD_ORDER:
+            np.testing.assert_array_equal(item[m], gold[f"s{seed}_{m}"].astype(np.int64), err_msg=f"seed {seed} {m}")
+            assert item[m].dtype == np.int64
+        assert item["file_name"].endswith(str(path))
+
+
+def test_goldens_cover_the_edge_cases(gold):
+    """The recorded scenes exercise: a clip shorter than the block, >60 tracks (60 slots full, later tracks dropped), frames
+    without any agent, agents filtered for range / category."""
+    cases = {c[0]: c for c in gold["cases"].tolist()}
+    assert gold["s2_pose"].shape[0] == (60 - 4 - 1) // 4 < cases[2][2]
+    slots3 = gold["s3_bbox3d"].reshape(-1, 60, 11)
+    assert (slots3[..., 10] != BBOX_PAD).any(0).all()                      # all 60 slots taken
+    assert any((gold[f"s{s}_bbox3d"] == BBOX_PAD).all(1).any() for s in cases)   # a frame with no agents
+    for s in cases:
+        b = gold[f"s{s}_bbox3d"].reshape(-1, 60, 11)
+        full = b[..., 10] != BBOX_PAD
+        assert ((b[full][:, :10] >= 0) & (b[full][:, :10] <= 1023)).all() and ((b[full][:, 10] >= 1024) & (b[full][:, 10] <= 1026)).all()
+        assert (b[~full] == BBOX_PAD).all()
+
+
+def test_frame_indices_inference_rule():
+    # long clip: start at 10, stride 4 (UMGen_nuplan_dataset.py:145-175)
+    assert scene_io.frame_indices(200, 22, 4, 10) == [10 + 4 * i for i in range(22)]
+    # the start moves back when the block would run past the clip
+    assert scene_io.frame_indices(100, 22, 4, 10)[0] == 100 - 22 * 4 - 4
+    # clip shorter than the block: start = sampling_gap, as many frames as fit
+    assert scene_io.frame_indices(60, 22, 4, 10) == [4 + 4 * i for i in range(13)]
+
+
+def test_bin_encoding_edges():
+    bins = np.linspace(0.0, 1.0, 1024)
+    v = np.array([-5.0, 0.0, 1e-9, 0.5, 1.0, 7.0])
+    t = scene_io.encode_bins(v, bins)
+    assert t.tolist() == [0, 1, 1, 512, 1023, 1023]      # below range -> 0, above -> clipped to the last bin
+    # ego: (v - 0) * float32(1 / std) over linspace(-1, 1): zero motion sits in the centre bin
+    assert scene_io.encode_ego(np.zeros((1, 3))).tolist() == [[512, 512, 512]]
+    assert scene_io.encode_ego(np.array([[100.0, -100.0, 0.999]])).tolist() == [[1023, 0, 1023]]
+
+
+def test_slotting_by_first_appearance_and_track_id_zero_quirk():
+    box = lambda x: np.array([[x, 0, 0, 4, 2, 1.5, 0, 0, 0, 0]], dtype=np.float32)   # noqa: E731
+    boxes = [box(1.0), np.concatenate([box(2.0), box(3.0)]), box(4.0), np.zeros((0, 10), np.float32)]
+    cats = [["vehicle"], ["pedestrian", "vehicle"], ["bicycle"], []]
+    tids = [np.array([7]), np.array([9, 7]), np.array([0]), np.array([], dtype=np.int64)]
+    tok = scene_io.encode_boxes(boxes, cats, tids).reshape(4, 60, 11)
+    assert tok[0, 0, 10] == 1024 and (tok[0, 1:] == BBOX_PAD).all()          # track 7 -> slot 0
+    assert tok[1, 0, 10] == 1024 and tok[1, 1, 10] == 1026                    # track 9 appears second -> slot 1
+    assert (tok[2] == BBOX_PAD).all()      # a frame whose only track id is 0 counts as empty (np.any, tokenizer.py:880-886)
+    assert (tok[3] == BBOX_PAD).all()
+
+
+def test_token_pickle_writer_skips_existing(tmp_path):
+    out = {m: np.zeros((1, 3, 4), np.int64) for m in MOD_ORDER}
+    p = scene_io.save_tokens(out, str(tmp_path), "clip_a")
+    assert p == str(tmp_path / "saved_token" / "clip_a_tokens.pkl")
+    with open(p, "rb") as f:
+        back = pickle.load(f)
+    assert set(back) == set(MOD_ORDER) and back["pose"].dtype == np.int64
+    assert scene_io.save_tokens(out, str(tmp_path), "clip_a") is None          # model_pl.py:215-216
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/projects"), reason="reference checkout not present")
+def test_live_against_reference_dataset_on_a_fresh_seed(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_scene_golden
+    ref = make_scene_golden.reference_tokens(11, 150, 30, 120)
+    path = tmp_path / "scene_11_synthetic_clip_000.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(scene_io.synthetic_raw_scene(11, 150, 120), f)
+    item = scene_io.SceneReader(str(path), block_size=30)[0]
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(item[m], ref[m], err_msg=m)
+
+
+def test_evaluate_loads_raw_clips_through_the_reader(tmp_path, gold):
+    """`python -m umgen_amd.evaluate --data_test_root <dir of raw clips>`: load_scene tokenises a raw clip on the fly with the
+    block size evaluate.py derives (set_num_new_frames + 20)."""
+    from umgen_amd.evaluate import load_scene
+    seed, n_frames, block, n_tracks = gold["cases"].tolist()[0]
+    path = tmp_path / "clip.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(scene_io.synthetic_raw_scene(seed, n_frames, n_tracks), f)
+    sc, ctl = load_scene(str(path), block_size=block)
+    assert ctl is None
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(sc[m][0], gold[f"s{seed}_{m}"].astype(np.int64))

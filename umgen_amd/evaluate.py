@@ -10,9 +10,10 @@ one parity is judged on: ``<output_path>/saved_token/<name>_tokens.pkl`` = pickl
 [1, T_out, S_mod] (model_pl.py:350-355), skipped when it already exists (model_pl.py:215-216).
 VAE decoding / video rendering (model_pl.py:254ff) stay on the reference side.
 
-Scenes are read from ``*.npz`` / ``*.pkl`` files holding the token dict the dataset hands to ``inference``
-(pose [T,3] / map [T,1024] / bbox3d [T,660] / image [T,512], optional control_pose / control_bbox3d), or generated
-with ``--synthetic N``.  Under ``torchrun`` the scenes are sharded over ranks (umgen_amd/shard.py).
+Scenes are read from ``*.pkl`` clips in the reference's raw ``tokenized_origin_scenes`` schema (tokenised on the fly exactly as
+``NuPlanTokenDataset`` + ``transforms_val`` do, see scene_io.py), from ``*.npz`` / ``*.pkl`` files that already hold the token
+dict handed to ``inference`` (pose [T,3] / map [T,1024] / bbox3d [T,660] / image [T,512], optional control_pose /
+control_bbox3d), or generated with ``--synthetic N``.  Under ``torchrun`` the scenes are sharded over ranks (umgen_amd/shard.py).
 """
 from __future__ import annotations
 
@@ -25,6 +26,7 @@ import sys
 import numpy as np
 
 from .config import MOD_ORDER, large_config, tiny_config
+from .scene_io import is_raw_scene, save_tokens, scene_tokens
 from .synth import synthetic_control, synthetic_scene
 from .weights import expected_keys, synth_tensor
 
@@ -73,8 +75,10 @@ def resolve(args):
     return cfg, new_frames, input_cond
 
 
-def load_scene(path):
+def load_scene(path, block_size=42, sampling_gap=4, start_index=10):
     d = dict(np.load(path)) if path.endswith(".npz") else pickle.load(open(path, "rb"))
+    if is_raw_scene(d):        # a tokenized_origin_scenes clip: what NuPlanTokenDataset + transforms_val turn it into (scene_io.py)
+        d = scene_tokens(d, block_size, sampling_gap, start_index)
     if "dataset_token" in d:   # control pickle layout (model_pl.py:137-171)
         ctl = d.get("control_dict", {})
         d = dict(d["dataset_token"], **{f"control_{k}": v for k, v in ctl.items()})
@@ -104,7 +108,9 @@ def main(argv=None):
         files = sorted(glob.glob(os.path.join(args.data_test_root or "", "*.npz")) + glob.glob(os.path.join(args.data_test_root or "", "*.pkl")))
         if not files:
             sys.exit("no scenes: pass --data_test_root <dir with *.npz|*.pkl token dicts> or --synthetic N")
-        scenes = [(os.path.basename(f)[:-4],) + load_scene(f) for f in files]
+        # dataset_block_size = set_num_new_frames + cond_frames (infer_fun.py:176-186), sampling_gap 4, start_index 10 (evaluate.py:157)
+        block = (args.set_num_new_frames if args.infer_task == "video" else max(new_frames, 0)) + 20
+        scenes = [(os.path.basename(f)[:-4],) + load_scene(f, block_size=block) for f in files]
     eng = Engine(cfg, precision=args.precision, max_batch=args.batch, max_cond_frames=T_hist, device=local_rank)
     if args.debug:
         for key, shape in expected_keys(cfg).items():
@@ -128,9 +134,7 @@ def main(argv=None):
         out = eng.rollout(toks, new_frames if new_frames >= 0 else toks["pose"].shape[1] - icf, cond_frames=T_hist,
                           input_cond_frames=icf, init_tokens=ctl, control_test=control and ctl is not None and "bbox3d" in ctl,
                           seeds=[scene_seed(args.seed, sid)])
-        with open(path, "wb") as f:
-            pickle.dump(out, f)
-        print("saved", path)
+        print("saved", save_tokens(out, args.output_path, name))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
