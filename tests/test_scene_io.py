@@ -111,3 +111,22 @@ def test_evaluate_loads_raw_clips_through_the_reader(tmp_path, gold):
     assert ctl is None
     for m in MOD_ORDER:
         np.testing.assert_array_equal(sc[m][0], gold[f"s{seed}_{m}"].astype(np.int64))
+
+
+def test_decoders_match_the_oracle_helpers_and_round_trip(gold):
+    """decode side of f-1: same numbers as the oracle's helpers (which are pinned on the reference's tokenizer / normaliser in
+    tests/test_oracle_vs_reference.py), and encode(decode(tokens)) == tokens for every recorded in-vocabulary token."""
+    from oracle.umgen_oracle import decode_box_values, decode_pose_values
+    pose = gold["s0_pose"].astype(np.int64)
+    np.testing.assert_array_equal(scene_io.decode_ego(pose), decode_pose_values(pose))
+    frame = gold["s3_bbox3d"][5].astype(np.int64)
+    boxes, cats, slots = scene_io.decode_boxes(frame)
+    assert len(slots) > 0 and set(cats) <= set(scene_io.CATEGORIES)
+    for b, s in zip(boxes, slots):
+        np.testing.assert_array_equal(b, decode_box_values(frame.reshape(60, 11)[s]))
+    # round trip through the encoder (bin mid-points fall back into their own bin; tokens 0 / 1023 are the open-ended bins)
+    re = scene_io.encode_boxes([boxes.astype(np.float32)], [cats], [np.arange(1, len(cats) + 1)]).reshape(60, 11)[:len(cats)]
+    orig = frame.reshape(60, 11)[slots]
+    inner = (orig[:, :10] > 0) & (orig[:, :10] < 1023)
+    np.testing.assert_array_equal(re[:, :10][inner], orig[:, :10][inner])
+    np.testing.assert_array_equal(re[:, 10], orig[:, 10])

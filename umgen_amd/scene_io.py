@@ -76,6 +76,29 @@ def encode_ego(pose_diff: np.ndarray) -> np.ndarray:
     return encode_bins((pose_diff - mean) * inv_std, _EGO_BINS).astype(np.int64)
 
 
+def decode_ego(pose_tokens: np.ndarray) -> np.ndarray:
+    """Tokens [..., 3] -> (dx, dy, dheading) float32: bin mid-points (DigitalBinsTokenizer.decode, tokenizer.py:332-354) divided by
+    the float32 reciprocal std (Normalize_Standard.unnormalize_ego, normalize.py:65-76) -- what UMGen.decode_pose returns."""
+    t = np.asarray(pose_tokens, dtype=np.int64)
+    v = (_EGO_BINS[np.clip(t - 1, 0, 1023)] + _EGO_BINS[np.clip(t, 0, 1023)]) / 2
+    inv_std = 1.0 / np.array(EGO_STD, dtype=np.float32)
+    return (v / inv_std + np.zeros(3, dtype=np.float32)).astype(np.float32)
+
+
+def decode_boxes(bbox3d_tokens: np.ndarray):
+    """Frame tokens [660] -> (boxes float64 [n, 10], categories list[str], slot indices): slots holding any pad token are dropped
+    (BBox3DTokenizer.decode, tokenizer.py:689-806), attributes are bin mid-points mapped back through their min-max ranges
+    (Normalize.unnormalize_bbox3d, normalize.py:189-229)."""
+    t = np.asarray(bbox3d_tokens, dtype=np.int64).reshape(N_SLOTS, SLOT_LEN)
+    keep = np.nonzero(~np.any(t == BBOX_PAD, axis=1))[0]
+    a = t[keep, :10]
+    v = (_BOX_BINS[np.clip(a - 1, 0, 1023)] + _BOX_BINS[np.clip(a, 0, 1023)]) / 2
+    lo = np.array([r[0] for r in BBOX_RANGE], dtype=np.float64)
+    hi = np.array([r[1] for r in BBOX_RANGE], dtype=np.float64)
+    cats = [CATEGORIES[c - 1024] if 1024 <= c < 1024 + len(CATEGORIES) else "none" for c in t[keep, 10].tolist()]
+    return v * (hi - lo) + lo, cats, keep
+
+
 def filter_boxes(boxes: Sequence, cats: Sequence[Sequence[str]], track_ids: Sequence, vocab: Sequence[str] = CATEGORIES):
     """Keep boxes whose category is in the vocabulary and whose centre is within 64 m in x and y
     (categories_fliter + range filter, UMGen_nuplan_dataset.py:317-346)."""
