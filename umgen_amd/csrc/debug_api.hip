@@ -137,7 +137,7 @@ int umgen_dbg_gemm_bench(int R, int N, int K, int mode, int iters, float* ms) {
     (void)hipMemset(dO.p, 0, (size_t)R * N * 4);
     GemmArgs g{};
     g.P = dW.p; g.Q = dA.p; g.Mi = N; g.Nj = R; g.K = K; g.ldp = K; g.ldq = K; g.batch = 1;
-    g.mode = mode; g.out = dO.p; g.ldo = N;
+    g.mode = mode & 15; g.gelu = (mode >> 4) & 1; g.out = dO.p; g.ldo = N;   // mode bit 4: erf-GELU epilogue
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     launch_gemm_bf16_mfma(nullptr, g);
