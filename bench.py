@@ -189,7 +189,11 @@ def main():
                          "frac": oar_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic_per_step(cfg),
                          "kernel": "OAR decode step (gemv_ln_kernel x73, attn_partial_kernel x36, gemv_resid_kernel x72, sample_token_kernel)",
                          "launches": tm["oar_kernels"], "avg_launch_us": tm["oar_ms"] * 1e3 / max(1, tm["oar_kernels"]),
-                         "avg_step_us": step_us, "algorithmic_bytes_per_step": bytes_per_step},
+                         "avg_step_us": step_us, "algorithmic_bytes_per_step": bytes_per_step,
+                         # the timed region runs the next frame's history slots beside the decode loop (2 of the 8 XCDs); the
+                         # same loop alone on the chip, from the extra profiled frame:
+                         "achieved_alone": tp["oar_bytes"] / (tp["oar_ms"] * 1e-3) / 1e9 if tp["oar_ms"] > 0 else None,
+                         "avg_step_us_alone": tp["oar_ms"] * 1e3 / max(1, tp["oar_steps"])},
             "roofline_gemm": {"bound": "mfma", "achieved": gemm_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
                               "frac": gemm_tfs / MFMA_BF16_PEAK_TFS, "kernel": "gemm_bf16_glds_kernel (TAR/ego stacks)",
                               "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(1, tm["gemm_launches"])},
