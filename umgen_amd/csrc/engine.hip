@@ -80,6 +80,12 @@ struct umgen_engine {
     bool overlap = false, overlap_suspended = false;
     int overlap_mode = 1;                // UMGEN_OVERLAP: 0 off, 1 on for one scene per GPU (default), 2 always
     hipStream_t bg_stream = nullptr;
+    // the last-slot passes of the map / box stacks run beside the TAR stack's on their own streams and 1-slot workspaces
+    struct Work { float* X; void *A, *QKV, *VT, *Hb; float* mapfeat; };
+    Work w_main{}, w_side[2] = {};
+    hipStream_t side_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_side_in = nullptr, ev_side_done[2] = {nullptr, nullptr};
+    void set_work(const Work& w) { X = w.X; A = w.A; QKV = w.QKV; VT = w.VT; Hb = w.Hb; mapfeat = w.mapfeat; }
     hipStream_t full_stream = nullptr;   // unmasked: whole-window passes, profiling frames and rollouts that do not overlap use all CUs
     hipEvent_t ev_pre_done = nullptr;
     hipEvent_t ev_tar_done = nullptr, ev_bg_done = nullptr, ev_bg0 = nullptr;
@@ -579,7 +585,7 @@ template <typename T>
 int run_frame(umgen_engine* e, const FrameIO& io) {
     const int E = e->E, B = io.B, Tn = io.T;
     hipStream_t const fg = e->stream;   // the decode stream of overlapped rollouts (6 of the 8 XCDs when the overlap exists)
-    struct RestoreStream { umgen_engine* e; hipStream_t s; ~RestoreStream() { e->stream = s; } } restore{e, fg};
+    struct RestoreStream { umgen_engine* e; hipStream_t s; ~RestoreStream() { e->stream = s; e->set_work(e->w_main); } } restore{e, fg};
     hipStream_t st = fg;
     SamplerParams sp{io.smp->method, io.smp->top_k, io.smp->top_k_map, io.smp->topk_image, io.smp->p, io.smp->p_map, io.smp->temperature,
                      io.smp->rule_constrain, io.smp->merge_ar_tar, io.smp->only_ar};
@@ -667,12 +673,33 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
 
     // Step 2: the three TAR stacks (UMGen.py:1484-1494) and the conditioning rows (1496-1511)
     WindowTokens ws{e->d_pose_shift, e->d_map, e->d_box, e->d_img, B, Tc, Tn, t0};
-    run_stack<T>(e, STACK_MAP, ws, cmode);
-    launch_cond_rows(st, STACK_MAP, B, Tc, E, e->X, e->ln_map_tar, e->warped_last, e->cond);
-    run_stack<T>(e, STACK_BOX, ws, cmode);
-    launch_cond_rows(st, STACK_BOX, B, Tc, E, e->X, e->ln_box_tar, nullptr, e->cond);
-    run_stack<T>(e, STACK_TAR, ws, cmode);
-    launch_cond_rows(st, STACK_TAR, B, Tc, E, e->X, e->ln_tar, nullptr, e->cond);
+    if (use_px && e->side_stream[0]) {
+        // last-slot passes: 2207 rows per scene leave most CUs idle, and the three stacks are independent -- map and box run on
+        // side streams (own 1-slot workspaces) beside the TAR stack
+        HIPCHK(e, hipEventRecord(e->ev_side_in, st));
+        const int side_stack[2] = {STACK_MAP, STACK_BOX};
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(e, hipStreamWaitEvent(e->side_stream[i], e->ev_side_in, 0));
+            e->stream = e->side_stream[i];
+            e->set_work(e->w_side[i]);
+            run_stack<T>(e, side_stack[i], ws, cmode);
+            launch_cond_rows(e->stream, side_stack[i], B, Tc, E, e->X, i == 0 ? e->ln_map_tar : e->ln_box_tar, i == 0 ? e->warped_last : nullptr,
+                             e->cond);
+            HIPCHK(e, hipEventRecord(e->ev_side_done[i], e->side_stream[i]));
+        }
+        e->stream = st;
+        e->set_work(e->w_main);
+        run_stack<T>(e, STACK_TAR, ws, cmode);
+        launch_cond_rows(st, STACK_TAR, B, Tc, E, e->X, e->ln_tar, nullptr, e->cond);
+        for (int i = 0; i < 2; ++i) HIPCHK(e, hipStreamWaitEvent(st, e->ev_side_done[i], 0));
+    } else {
+        run_stack<T>(e, STACK_MAP, ws, cmode);
+        launch_cond_rows(st, STACK_MAP, B, Tc, E, e->X, e->ln_map_tar, e->warped_last, e->cond);
+        run_stack<T>(e, STACK_BOX, ws, cmode);
+        launch_cond_rows(st, STACK_BOX, B, Tc, E, e->X, e->ln_box_tar, nullptr, e->cond);
+        run_stack<T>(e, STACK_TAR, ws, cmode);
+        launch_cond_rows(st, STACK_TAR, B, Tc, E, e->X, e->ln_tar, nullptr, e->cond);
+    }
     if (tr && tr->cond) HIPCHK(e, hipMemcpyAsync(tr->cond, e->cond, (size_t)kSeq * E * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipEventRecord(e->ev[2], st));
 
@@ -949,6 +976,23 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     HIPCHK(e, hipMemset(e->VT, 0, Bm * Tm * E * e->S_pad * e->tsz));   // pad columns stay zero forever
     if (int rc = dev_alloc(e, &e->Hb, R * 4 * E * e->tsz)) return rc;
     if (int rc = dalloc(e, &e->mapfeat, Bm * Tm * kNMap * E)) return rc;
+    e->w_main = umgen_engine::Work{e->X, e->A, e->QKV, e->VT, e->Hb, e->mapfeat};
+    if (e->overlap) {   // 1-slot workspaces + streams for the concurrent last-slot passes
+        const size_t R1 = Bm * kSeq;
+        for (int i = 0; i < 2; ++i) {
+            umgen_engine::Work& w = e->w_side[i];
+            if (int rc = dalloc(e, &w.X, R1 * E)) return rc;
+            if (int rc = dev_alloc(e, &w.A, R1 * E * e->tsz)) return rc;
+            if (int rc = dev_alloc(e, &w.QKV, R1 * 3 * E * e->tsz)) return rc;
+            if (int rc = dev_alloc(e, &w.VT, Bm * E * e->S_pad * e->tsz)) return rc;
+            HIPCHK(e, hipMemset(w.VT, 0, Bm * E * e->S_pad * e->tsz));
+            if (int rc = dev_alloc(e, &w.Hb, R1 * 4 * E * e->tsz)) return rc;
+            if (int rc = dalloc(e, &w.mapfeat, Bm * kNMap * E)) return rc;
+            HIPCHK(e, hipStreamCreateWithFlags(&e->side_stream[i], hipStreamNonBlocking));
+            HIPCHK(e, hipEventCreate(&e->ev_side_done[i]));
+        }
+        HIPCHK(e, hipEventCreate(&e->ev_side_in));
+    }
     if (int rc = dalloc(e, &e->warped_last, Bm * kNMap * E)) return rc;
     if (int rc = dalloc(e, &e->cond, Bm * kSeq * E)) return rc;
     if (int rc = dalloc(e, &e->pego, Bm * kSeq * E)) return rc;
@@ -1229,6 +1273,11 @@ int umgen_destroy(umgen_engine* e) {
     if (e->tb.gmap) {}   // tables are in allocs
     if (e->bg_stream) { hipStreamSynchronize(e->bg_stream); hipStreamDestroy(e->bg_stream); }
     if (e->full_stream) hipStreamDestroy(e->full_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (e->side_stream[i]) hipStreamDestroy(e->side_stream[i]);
+        if (e->ev_side_done[i]) hipEventDestroy(e->ev_side_done[i]);
+    }
+    if (e->ev_side_in) hipEventDestroy(e->ev_side_in);
     for (hipEvent_t ev : {e->ev_tar_done, e->ev_bg_done, e->ev_bg0, e->ev_pre_done}) if (ev) hipEventDestroy(ev);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
