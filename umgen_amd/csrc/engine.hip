@@ -872,7 +872,12 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         if (ncu < 2 * bg_cus) e->overlap = false;
         else {
             std::vector<uint32_t> mbg((ncu + 31) / 32, 0u), mfg((ncu + 31) / 32, 0u);
-            for (int cu = 0; cu < ncu; ++cu) (cu < bg_cus ? mbg : mfg)[cu / 32] |= 1u << (cu % 32);
+            int fg_cus = ncu - bg_cus;   // UMGEN_FG_CUS: experiment, decode loop on fewer XCDs (32 CUs each)
+            if (const char* fc = getenv("UMGEN_FG_CUS")) fg_cus = std::max(32, std::min(ncu - bg_cus, atoi(fc)));
+            for (int cu = 0; cu < ncu; ++cu) {
+                if (cu < bg_cus) mbg[cu / 32] |= 1u << (cu % 32);
+                else if (cu < bg_cus + fg_cus) mfg[cu / 32] |= 1u << (cu % 32);
+            }
             HIPCHK(e, hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mfg.size(), mfg.data()));
             HIPCHK(e, hipExtStreamCreateWithCUMask(&e->bg_stream, (uint32_t)mbg.size(), mbg.data()));
             HIPCHK(e, hipStreamCreateWithFlags(&e->full_stream, hipStreamNonBlocking));
