@@ -18,9 +18,13 @@ constexpr float kLog2e = 1.4426950408889634f;
 // 112 B / 144 B make the ds_read_b128 / ds_read_b64 fragment reads bank-conflict free) and shared by the 4 waves.
 // Blocks of one (frame, head) are mapped to the same XCD (block b runs on XCD b % 8) so its K/V stay in one L2.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kKStride = 112;   // bytes per K row in LDS  (96 used)
-constexpr int kVStride = 144;   // bytes per Vt row in LDS (128 used)
-constexpr int kTileBytes = 64 * kKStride + 48 * kVStride;   // 14080
+// LDS images (SQ_LDS_BANK_CONFLICT was 44 % of the LDS cycles with plain 112 B / 144 B rows and 8-byte fragment reads):
+//   K row (144 B): d 0..31 as four 16 B pieces, then d 32..47 as four 16 B slots of [4 values | 4 zeros] -- the half-filled MFMA's
+//     A operand is one ds_read_b128 (zero halves written once); 36 dwords per row puts the 8 rows of a b128 phase on all 32 banks.
+//   Vt row (128 B): sixteen 8 B key groups, group s stored at s ^ (row & 15): the 16 rows of a b64 phase hit 16 distinct bank pairs.
+constexpr int kKStride = 144;
+constexpr int kVStride = 128;
+constexpr int kTileBytes = 64 * kKStride + 48 * kVStride;   // 15360
 
 template <int QT>
 __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
@@ -41,38 +45,53 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
     const bf16_t* kbase = qbase + E;
     const bf16_t* vbase = vt + ((long)f * H + h) * kHeadDim * S_pad;
 
-    // staging assignment: 768 16-byte chunks per tile (K: 64 rows x 6, Vt: 48 rows x 8), 3 per thread
-    const bf16_t* gsrc[3];
-    int ldst[3];
-    bool is_k[3];
-    int krow[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int c = tid + 256 * i;
-        if (c < 384) {
-            const int r = c / 6, p = c % 6;
-            is_k[i] = true; krow[i] = r;
-            gsrc[i] = kbase + p * 8;                    // + row*ld per tile
-            ldst[i] = r * kKStride + p * 16;
-        } else {
-            const int cc = c - 384, r = cc >> 3, p = cc & 7;
-            is_k[i] = false; krow[i] = 0;
-            gsrc[i] = vbase + (long)r * S_pad + p * 8;  // + k0 per tile
-            ldst[i] = 64 * kKStride + r * kVStride + p * 16;
-        }
-    }
-    uint4 stage[3];
+    // staging assignment: 768 16-byte chunks per tile (K: 64 rows x 6, Vt: 48 rows x 8), 3 per thread.  Chunks 0..383 are K,
+    // 384..767 are Vt, so thread tid's chunks tid / tid+256 / tid+512 are K / (K if tid < 128 else Vt) / Vt: the three staging
+    // registers are named scalars (an indexed array ended up in scratch memory).
+    const bool mid_is_k = tid < 128;
+    const int r0 = tid / 6, p0 = tid % 6;                                   // chunk tid: K row r0, piece p0
+    const int c1 = tid + 256;
+    const int r1 = mid_is_k ? c1 / 6 : (c1 - 384) >> 3, p1 = mid_is_k ? c1 % 6 : (c1 - 384) & 7;
+    const int c2 = tid + 512 - 384, r2 = c2 >> 3, p2 = c2 & 7;             // chunk tid+512: Vt row r2, piece p2
+    const bf16_t* g0 = kbase + p0 * 8;
+    const bf16_t* g1 = mid_is_k ? kbase + p1 * 8 : vbase + (long)r1 * S_pad + p1 * 8;
+    const bf16_t* g2 = vbase + (long)r2 * S_pad + p2 * 8;
+    // LDS byte offsets: K piece p < 4 -> p*16; p = 4, 5 (d 32..47) -> slots 2(p-4), 2(p-4)+1 behind byte 64 (8 B each, see above);
+    // Vt piece p (key groups 2p, 2p+1) -> the aligned 16 B pair (2p ^ row) & ~1, halves swapped when the row is odd
+    auto koff = [&](int r, int pp) { return r * kKStride + (pp < 4 ? pp * 16 : 64 + (pp - 4) * 32); };
+    auto voff = [&](int r, int pp) { return 64 * kKStride + r * kVStride + (((2 * pp) ^ (r & 15)) & ~1) * 8; };
+    const int l0 = koff(r0, p0);
+    const int l1 = mid_is_k ? koff(r1, p1) : voff(r1, p1);
+    const int l2 = voff(r2, p2);
+    const bool hi0 = p0 >= 4, hi1 = mid_is_k && p1 >= 4, swap1 = !mid_is_k && (r1 & 1), swap2 = r2 & 1;
+    uint4 sg0, sg1, sg2;
     auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (is_k[i]) stage[i] = *reinterpret_cast<const uint4*>(gsrc[i] + (long)min(k0 + krow[i], S - 1) * ld);
-            else stage[i] = *reinterpret_cast<const uint4*>(gsrc[i] + k0);
+        sg0 = *reinterpret_cast<const uint4*>(g0 + (long)min(k0 + r0, S - 1) * ld);
+        sg1 = *reinterpret_cast<const uint4*>(mid_is_k ? g1 + (long)min(k0 + r1, S - 1) * ld : g1 + k0);
+        sg2 = *reinterpret_cast<const uint4*>(g2 + k0);
+    };
+    auto kstore = [](unsigned char* dst, uint4 v, bool hi) {
+        if (hi) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2*>(dst + 16) = make_uint2(v.z, v.w);
+        } else {
+            *reinterpret_cast<uint4*>(dst) = v;
         }
+    };
+    auto vstore = [](unsigned char* dst, uint4 v, bool sw) {
+        *reinterpret_cast<uint4*>(dst) = sw ? make_uint4(v.z, v.w, v.x, v.y) : v;
     };
     auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) *reinterpret_cast<uint4*>(lds + buf * kTileBytes + ldst[i]) = stage[i];
+        unsigned char* base = lds + buf * kTileBytes;
+        kstore(base + l0, sg0, hi0);
+        if (mid_is_k) kstore(base + l1, sg1, hi1); else vstore(base + l1, sg1, swap1);
+        vstore(base + l2, sg2, swap2);
     };
+    // the zero halves of the K hi slots (both buffers) are written once
+    for (int i = tid; i < 2 * 64 * 4; i += 256) {
+        const int buf = i >> 8, r = (i >> 2) & 63, sl = i & 3;
+        *reinterpret_cast<uint2*>(lds + buf * kTileBytes + r * kKStride + 64 + sl * 16 + 8) = make_uint2(0u, 0u);
+    }
 
     // head_dim 48 = one full K=32 MFMA (d 0..31) + one half-filled K=32 MFMA (d 32..47 in k-slots 8g..8g+3, zeros in 8g+4..8g+7).
     // (The legacy v_mfma_f32_16x16x16_bf16 for the 16-wide remainder gave tile-dependent wrong results under some register
@@ -99,6 +118,7 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
     const float c = kScale * kLog2e;
     const int ntile = (S + 63) / 64;
     gload(0);
+    __syncthreads();   // zero halves in place before the first real halves land next to them
     lstore(0);
     if (ntile > 1) gload(64);
     __syncthreads();
@@ -111,13 +131,11 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
         for (int kt = 0; kt < 4; ++kt) {
             const unsigned char* kr = kt_l + (kt * 16 + c16) * kKStride;
             const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kr + 16 * g);
-            union { bf16x8_t v; uint2 u[2]; } khi;
-            khi.u[0] = *reinterpret_cast<const uint2*>(kr + 64 + 8 * g);
-            khi.u[1] = make_uint2(0u, 0u);
+            const bf16x8_t khi = *reinterpret_cast<const bf16x8_t*>(kr + 64 + 16 * g);   // d 32+4g .. 35+4g | zeros
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(klo, qlo[t], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                st[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(khi.v, qhi[t], a, 0, 0, 0);
+                st[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(khi, qhi[t], a, 0, 0, 0);
             }
         }
         if (k0 + 64 > S) {   // key tail: rows past S are masked out
@@ -167,12 +185,12 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
         }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const unsigned char* vr = vt_l + (d * 16 + c16) * kVStride + 8 * g;
+            const unsigned char* vr = vt_l + (d * 16 + c16) * kVStride;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 union { bf16x8_t v; uint2 u[2]; } a;
-                a.u[0] = *reinterpret_cast<const uint2*>(vr + hh * 64);        // keys k0 + 32hh + 4g .. +3
-                a.u[1] = *reinterpret_cast<const uint2*>(vr + hh * 64 + 32);   // keys k0 + 32hh + 16 + 4g .. +3
+                a.u[0] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g) ^ c16) << 3));       // keys k0 + 32hh + 4g .. +3
+                a.u[1] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g + 4) ^ c16) << 3));   // keys k0 + 32hh + 16 + 4g .. +3
 #pragma unroll
                 for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, pb[t][hh], o[t][d], 0, 0, 0);
             }
