@@ -232,9 +232,129 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
         }
 }
 
+// Persistent form of gemm_bf16_glds_kernel for the large token counts of the TAR / ego stacks: 2 workgroups per CU walk the tile
+// list (same XCD-aware order: ids b, b + G, b + 2G, ... stay on XCD b % 8), and the first k-slab of a workgroup's NEXT tile is
+// requested during the last k-step of the current one, so the epilogue (bias / GELU / residual read-modify-write) overlaps that
+// load instead of being followed by a cold HBM round trip.  At K = 768 a tile is only 12 k-steps, and the cold start was as long
+// as the whole MFMA loop.
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI, int nJ) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * BM * BK * 2];
+    const int z = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 2, wj = wave & 3;
+    const int hI = (nI + 1) >> 1, qJ = (nJ + 3) >> 2;
+    const int total = 8 * hI * qJ;
+    const bf16_t* P = reinterpret_cast<const bf16_t*>(a.P) + (long)z * a.strideP;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q) + (long)z * a.strideQ;
+    auto decode = [&](int b, int& ti, int& tj) {   // false: id b names no tile (padding of the 2 x 4 XCD partition)
+        const int xcd = b & 7, lb = b >> 3;
+        ti = (xcd & 1) * hI + lb % hI;
+        tj = (xcd >> 1) * qJ + lb / hI;
+        return !(ti >= nI || tj >= nJ || ti >= ((xcd & 1) + 1) * hI || tj >= ((xcd >> 1) + 1) * qJ);
+    };
+    auto next_valid = [&](int b) {
+        int ti, tj;
+        while (b < total && !decode(b, ti, tj)) b += gridDim.x;
+        return b;
+    };
+    struct Src { const bf16_t* pp[2]; const bf16_t* qq[2]; };
+    auto sources = [&](int b) {
+        int ti, tj;
+        decode(b, ti, tj);
+        Src s;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r = (wave + 8 * it) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            s.pp[it] = P + (long)min(ti * BM + r, a.Mi - 1) * a.ldp + c * 8;
+            s.qq[it] = Q + (long)min(tj * BN + r, a.Nj - 1) * a.ldq + c * 8;
+        }
+        return s;
+    };
+    auto issue = [&](int buf, const Src& s, int k0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            unsigned char* dp = lds[buf] + (wave + 8 * it) * 1024;
+            __builtin_amdgcn_global_load_lds((const void*)(s.pp[it] + k0), (__attribute__((address_space(3))) void*)dp, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(s.qq[it] + k0), (__attribute__((address_space(3))) void*)(dp + BM * BK * 2), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 15, g = lane >> 4;
+    const int nkt = a.K / BK;
+    int tile = next_valid(blockIdx.x);
+    if (tile >= total) return;
+    Src cur = sources(tile);
+    int gs = 0;                       // global k-slab counter of this workgroup: slab s lives in buffer s & 1
+    issue(0, cur, 0);
+    while (tile < total) {
+        const int nxt = next_valid(tile + gridDim.x);
+        const bool has_next = nxt < total;
+        Src nx = cur;
+        if (has_next) nx = sources(nxt);
+        f32x4_t acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();              // slab gs has landed; every wave is done with the previous tile's LDS reads
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) issue((gs + 1) & 1, cur, (kt + 1) * BK);
+            else if (has_next) issue((gs + 1) & 1, nx, 0);
+            const unsigned char* ldsP = lds[gs & 1];
+            const unsigned char* ldsQ = lds[gs & 1] + BM * BK * 2;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t af[4], bfr[2];
+                const int c = kk * 4 + g;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const bf16x8_t*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const bf16x8_t*>(ldsQ + swz(wj * 32 + n * 16 + frow, c));
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+            }
+            ++gs;
+            if (kt + 1 < nkt) __syncthreads();   // (the last k-step's barrier is the one at the top of the next tile)
+        }
+        int ti, tj;
+        decode(tile, ti, tj);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int i0 = ti * BM + wi * 64 + m * 16 + 4 * g;
+                const int j = tj * BN + wj * 32 + n * 16 + frow;
+                float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+                epilogue4<MODE, bf16_t>(a, z, i0, j, v);
+            }
+        tile = nxt;
+        cur = nx;
+    }
+}
+
 void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a) {
     const int nI = (a.Mi + BM - 1) / BM, nJ = (a.Nj + BN - 1) / BN;
     dim3 grid(((nJ + 7) / 8) * 8 * nI, 1, a.batch), block(256);
+#ifndef UMGEN_NO_PERSISTENT_GEMM
+    if (a.K % BK == 0 && a.batch == 1 && a.mode != GEMM_VT && (long)nI * nJ >= 2048) {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        const dim3 pg(2 * n_cu, 1, 1), block8(512);   // 2 workgroups (64 KB of LDS each) per CU; 2 * n_cu is a multiple of 8
+        switch (a.mode) {
+            case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_pers_kernel<GEMM_STORE>, pg, block8, 0, s, a, nI, nJ); break;
+            case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_pers_kernel<GEMM_RESID>, pg, block8, 0, s, a, nI, nJ); break;
+            default: hipLaunchKernelGGL(gemm_bf16_pers_kernel<GEMM_STORE_F32>, pg, block8, 0, s, a, nI, nJ); break;
+        }
+        return;
+    }
+#endif
     if (a.K % BK == 0) {
         grid = dim3(8 * ((nI + 1) / 2) * ((nJ + 3) / 4), 1, a.batch);
         const dim3 block8(512);
