@@ -339,7 +339,7 @@ void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a) {
     const int nI = (a.Mi + BM - 1) / BM, nJ = (a.Nj + BN - 1) / BN;
     dim3 grid(((nJ + 7) / 8) * 8 * nI, 1, a.batch), block(256);
 #ifndef UMGEN_NO_PERSISTENT_GEMM
-    if (a.K % BK == 0 && a.batch == 1 && a.mode != GEMM_VT && (long)nI * nJ >= 2048) {
+    if (a.K % BK == 0 && a.batch == 1 && a.mode != GEMM_VT && (long)nI * nJ >= 1024) {
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
