@@ -22,8 +22,10 @@ def ref_linear(act, W, bias, gelu, resid):
 
 @pytest.mark.parametrize("R,N,K,gelu,resid", [(300, 2304, 768, 0, 0), (2207, 768, 3072, 0, 1), (513, 3072, 768, 1, 0),
                                                (97, 288, 96, 0, 0), (130, 96, 384, 0, 1),
-                                               # >= 8192 rows and features % 192 == 0: the 192 x 256 tile kernel (ragged last tile)
-                                               (8300, 768, 768, 0, 1), (8448, 2304, 768, 0, 0), (9000, 1536, 3072, 1, 0)])
+                                               # large token counts, ragged last tile
+                                               (8300, 768, 768, 0, 1), (8448, 2304, 768, 0, 0), (9000, 1536, 3072, 1, 0),
+                                               # >= 1024 output tiles: the persistent kernel (ragged last token tile, every epilogue)
+                                               (22001, 768, 768, 0, 1), (12000, 3072, 768, 1, 0), (11003, 768, 3072, 0, 1)])
 @pytest.mark.parametrize("bf16", [0, 1])
 def test_linear(bf16, R, N, K, gelu, resid):
     rng = np.random.default_rng(R + N + K)
