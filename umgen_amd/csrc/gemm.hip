@@ -359,7 +359,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI,
                 uint4 v = *reinterpret_cast<const uint4*>(stg + tl * 256 + pos * 8);
                 if (tl & 1) v = make_uint4(v.z, v.w, v.x, v.y);
                 const int token = tj * BN + tl;
-                if (token < a.Nj) *reinterpret_cast<uint4*>(out + (long)token * a.ldo + 8 * q) = v;
+                if (token < a.Nj) {   // written once, read by a later launch: keep the lines out of the way of the L2-resident weights
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(out + (long)token * a.ldo + 8 * q));
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next tile's barrier lets the ring reuse it
         } else {
