@@ -194,6 +194,10 @@ void launch_ego_queries(hipStream_t s, const EmbedTables& tb, int B, int T, floa
 // Last kernel of a decode step: every block has read st->step before it arrives here; the last block to arrive advances it.
 __device__ inline void finish_step(OarState* st) {
     __syncthreads();
+    if (gridDim.x == 1) {   // one scene: no arrival count needed (saves a returning atomic at the end of every step)
+        if (threadIdx.x == 0) st->step += 1;
+        return;
+    }
     if (threadIdx.x == 0) {
         const int t = atomicAdd(&st->done, 1);
         if (t == (int)gridDim.x - 1) { st->done = 0; st->step += 1; }
@@ -223,11 +227,12 @@ struct SampleShared {
 // register values fetched with v_readlane, not on LDS round trips.
 __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k, float temp, float u, int mask_idx, SampleShared& sh) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float v[32];
+    float v[32], v0[32];   // v is consumed by the arg-max rounds, v0 keeps the logits for the kept-set pass
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const int idx = tid + 256 * i;
         v[i] = (idx < V && idx != mask_idx) ? logits[idx] : -INFINITY;
+        v0[i] = v[i];
     }
     const int kk = min(min(k, V), kMaxK);
     if (tid < 4 * kMaxK) { sh.cand_v[tid] = -INFINITY; sh.cand_i[tid] = 0x7fffffff; }
@@ -265,8 +270,10 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
     }
     __syncthreads();
     const float kth = sh.kth;
-    for (int idx = tid; idx < V; idx += 256) {
-        const float l = (idx != mask_idx) ? logits[idx] : -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int idx = tid + 256 * i;
+        const float l = v0[i];
         if (l >= kth && l > -INFINITY) {
             const int slot = atomicAdd(&sh.n_kept, 1);
             if (slot < kMaxKept) { sh.kept_i[slot] = idx; sh.kept_v[slot] = l; }
