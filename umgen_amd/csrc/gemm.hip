@@ -150,6 +150,53 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a, int nI,
         }
 }
 
+// bf16 epilogue of the 8-wave (2 x 4, 64 x 32 per wave) kernels through LDS: every wave stores whole 256-byte token rows (16 B per
+// lane, 16 lanes per row).  Writing from the MFMA layout directly is 8 B per lane in 32-byte pieces: measured 143 of the fc GEMM's
+// 374 us.  `stg` is a 32 KB slab buffer nobody reads any more ([128 tokens][128 features] bf16); 8-byte granule p of token t sits at
+// p ^ (t & 15): conflict-free for the MFMA-layout writes and for the row reads.  The caller guarantees a barrier before the buffer
+// is reused.
+__device__ __forceinline__ void store_tile_rows_bf16(const GemmArgs& a, int z, int ti, int tj, const f32x4_t (&acc)[4][2], unsigned char* stg,
+                                                     int tid, int wi, int wj, int frow, int g) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // every wave is done reading that buffer
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int i0 = ti * BM + wi * 64 + m * 16 + 4 * g;
+        float bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bb[r] = a.bias ? a.bias[i0 + r] : 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = acc[m][n][r] + bb[r];
+                o[r] = a.gelu ? gelu_erf(t) : t;
+            }
+            const int tl = wj * 32 + n * 16 + frow;
+            const int pg = (wi * 16 + m * 4 + g) ^ frow;
+            store4(reinterpret_cast<bf16_t*>(stg + tl * 256 + pg * 8), o);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + (long)z * a.strideO + (long)ti * BM;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 512 * it;
+        const int tl = idx >> 4, q = idx & 15;
+        const int pos = ((2 * q) ^ (tl & 15)) & ~1;
+        uint4 v = *reinterpret_cast<const uint4*>(stg + tl * 256 + pos * 8);
+        if (tl & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+        const int token = tj * BN + tl;
+        if (token < a.Nj) {   // written once, read by a later launch: keep the lines out of the way of the L2-resident weights
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(out + (long)token * a.ldo + 8 * q));
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before a later barrier lets the buffer be refilled
+}
+
 // Same tile and MFMA schedule, but the operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, 1 KB per wave
 // instruction, no staging VGPRs, no ds_write pass).  The LDS image is lane-linear per wave instruction, so the XOR swizzle is
 // applied to the per-lane SOURCE address (chunk c' of the image holds global chunk c' ^ (row & 7)).  Two LDS buffers: the
@@ -220,6 +267,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
                 for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
         }
         __syncthreads();
+    }
+    if (MODE == GEMM_STORE && a.Mi % BM == 0) {
+        store_tile_rows_bf16(a, z, ti, tj, acc, lds[0], tid, wi, wj, frow, g);   // (the loop's last barrier has retired every slab read)
+        return;
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -322,49 +373,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI,
         int ti, tj;
         decode(tile, ti, tj);
         if (MODE == GEMM_STORE && a.Mi % BM == 0) {
-            // bf16 outputs go through LDS so that every wave stores whole 256-byte token rows (16 B per lane, 16 lanes per row).
-            // Writing them from the MFMA layout directly is 8 B per lane in 32-byte pieces: measured 143 of the fc GEMM's 374 us.
-            // The staging tile [128 tokens][128 features] is the slab buffer the last k-step just finished with (the other one
-            // already receives the next tile's first slab); 8-byte granule p of token t sits at p ^ (t & 15): conflict-free both ways.
-            unsigned char* stg = lds[(gs - 1) & 1];
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();                 // every wave is done reading that buffer
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int i0 = ti * BM + wi * 64 + m * 16 + 4 * g;
-                float bb[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bb[r] = a.bias ? a.bias[i0 + r] : 0.f;
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    float o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float t = acc[m][n][r] + bb[r];
-                        o[r] = a.gelu ? gelu_erf(t) : t;
-                    }
-                    const int tl = wj * 32 + n * 16 + frow;
-                    const int pg = (wi * 16 + m * 4 + g) ^ frow;
-                    store4(reinterpret_cast<bf16_t*>(stg + tl * 256 + pg * 8), o);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + (long)z * a.strideO + (long)ti * BM;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = tid + 512 * it;
-                const int tl = idx >> 4, q = idx & 15;
-                const int pos = ((2 * q) ^ (tl & 15)) & ~1;
-                uint4 v = *reinterpret_cast<const uint4*>(stg + tl * 256 + pos * 8);
-                if (tl & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-                const int token = tj * BN + tl;
-                if (token < a.Nj) {   // written once, read by a later launch: keep the lines out of the way of the L2-resident weights
-                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(out + (long)token * a.ldo + 8 * q));
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next tile's barrier lets the ring reuse it
+            // the staging tile is the slab buffer the last k-step just finished with (the other one already receives the next tile's
+            // first slab)
+            store_tile_rows_bf16(a, z, ti, tj, acc, lds[(gs - 1) & 1], tid, wi, wj, frow, g);
         } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
