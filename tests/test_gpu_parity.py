@@ -205,3 +205,32 @@ def test_edge_cases_single_history_frame_zero_new_frames_and_errors():
         e2.load_tensor("transformer.spe.weight", np.zeros((7, 7), np.float32))                                          # wrong shape
     e2.close()
     e.close()
+
+
+def test_evaluate_cli_end_to_end_on_a_raw_clip(tmp_path):
+    """`python -m umgen_amd.evaluate` (counterpart of evaluate.py + model_pl.test_step): raw tokenized_origin_scenes-schema clip ->
+    scene_io reader -> rollout -> `<output>/saved_token/<name>_tokens.pkl` (model_pl.py:350-355); a second run skips the scene
+    (model_pl.py:215-216)."""
+    import pickle
+
+    from umgen_amd import evaluate, scene_io
+
+    data = tmp_path / "scenes"
+    data.mkdir()
+    with open(data / "clip_0007.pkl", "wb") as f:
+        pickle.dump(scene_io.synthetic_raw_scene(7, 120, 70), f)
+    out = tmp_path / "out"
+    argv = ["--infer_task", "video", "--set_num_new_frames", "1", "--model_scale", "debug", "--debug", "1",
+            "--data_test_root", str(data), "--output_path", str(out), "--precision", "fp32"]
+    evaluate.main(argv)
+    p = out / "saved_token" / "clip_0007_tokens.pkl"
+    assert p.exists()
+    with open(p, "rb") as f:
+        toks = pickle.load(f)
+    ref = scene_io.scene_tokens(scene_io.synthetic_raw_scene(7, 120, 70), block_size=21)
+    for m in MOD_ORDER:   # 20 conditioning frames (video task) + 1 new one; the tiny model's window is the last 7 of them
+        assert toks[m].dtype == np.int64 and toks[m].shape[:2] == (1, 21)
+        np.testing.assert_array_equal(toks[m][0, :20], ref[m][:20], err_msg=m)     # history = what the reader produced
+    mtime = p.stat().st_mtime_ns
+    evaluate.main(argv)                                                             # "... has been processed"
+    assert p.stat().st_mtime_ns == mtime
