@@ -197,6 +197,52 @@ __device__ __forceinline__ void store_tile_rows_bf16(const GemmArgs& a, int z, i
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before a later barrier lets the buffer be refilled
 }
 
+// fp32 residual epilogue (x += acc + bias) of the same kernels through LDS, two 64-token halves of 32 KB: the read-modify-write
+// then touches whole 512-byte token rows (16 B per lane, 32 lanes per row) instead of 64-byte pieces.  16-byte granule p of token
+// t sits at p ^ (t & 7).  Same arithmetic as epilogue4<GEMM_RESID>: x + (acc + bias).
+__device__ __forceinline__ void rmw_tile_rows_f32(const GemmArgs& a, int z, int ti, int tj, const f32x4_t (&acc)[4][2], unsigned char* stg,
+                                                  int tid, int wi, int wj, int frow, int g) {
+    float* xbase = reinterpret_cast<float*>(a.out) + (long)z * a.strideO + (long)ti * BM;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // slab reads (hf = 0) / the other half's row reads (hf = 1) are done
+        if ((wj >> 1) == hf) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int i0 = ti * BM + wi * 64 + m * 16 + 4 * g;
+                float bb[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bb[r] = a.bias ? a.bias[i0 + r] : 0.f;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int tl = (wj & 1) * 32 + n * 16 + frow;               // token inside the half
+                    const int pg = (wi * 16 + m * 4 + g) ^ (tl & 7);
+                    *reinterpret_cast<float4*>(stg + tl * 512 + pg * 16) =
+                        make_float4(acc[m][n][0] + bb[0], acc[m][n][1] + bb[1], acc[m][n][2] + bb[2], acc[m][n][3] + bb[3]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 512 * it;
+            const int tl = idx >> 5, q = idx & 31;
+            const float4 v = *reinterpret_cast<const float4*>(stg + tl * 512 + ((q ^ (tl & 7)) << 4));
+            const int token = tj * BN + hf * 64 + tl;
+            if (token < a.Nj) {
+                float* x = xbase + (long)token * a.ldo + 4 * q;
+                float c[4];
+                load4(x, c);
+                c[0] += v.x; c[1] += v.y; c[2] += v.z; c[3] += v.w;
+                store4(x, c);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // Same tile and MFMA schedule, but the operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, 1 KB per wave
 // instruction, no staging VGPRs, no ds_write pass).  The LDS image is lane-linear per wave instruction, so the XOR swizzle is
 // applied to the per-lane SOURCE address (chunk c' of the image holds global chunk c' ^ (row & 7)).  Two LDS buffers: the
@@ -270,6 +316,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
     }
     if (MODE == GEMM_STORE && a.Mi % BM == 0) {
         store_tile_rows_bf16(a, z, ti, tj, acc, lds[0], tid, wi, wj, frow, g);   // (the loop's last barrier has retired every slab read)
+        return;
+    }
+    if (MODE == GEMM_RESID && a.Mi % BM == 0) {
+        rmw_tile_rows_f32(a, z, ti, tj, acc, lds[0], tid, wi, wj, frow, g);
         return;
     }
 #pragma unroll
@@ -376,6 +426,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI,
             // the staging tile is the slab buffer the last k-step just finished with (the other one already receives the next tile's
             // first slab)
             store_tile_rows_bf16(a, z, ti, tj, acc, lds[(gs - 1) & 1], tid, wi, wj, frow, g);
+        } else if (MODE == GEMM_RESID && a.Mi % BM == 0) {
+            rmw_tile_rows_f32(a, z, ti, tj, acc, lds[(gs - 1) & 1], tid, wi, wj, frow, g);
         } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
