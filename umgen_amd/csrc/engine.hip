@@ -878,13 +878,20 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
                 if (cu < bg_cus) mbg[cu / 32] |= 1u << (cu % 32);
                 else if (cu < bg_cus + fg_cus) mfg[cu / 32] |= 1u << (cu % 32);
             }
-            HIPCHK(e, hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mfg.size(), mfg.data()));
-            HIPCHK(e, hipExtStreamCreateWithCUMask(&e->bg_stream, (uint32_t)mbg.size(), mbg.data()));
-            HIPCHK(e, hipStreamCreateWithFlags(&e->full_stream, hipStreamNonBlocking));
-            HIPCHK(e, hipEventCreate(&e->ev_pre_done));
-            HIPCHK(e, hipEventCreate(&e->ev_tar_done));
-            HIPCHK(e, hipEventCreate(&e->ev_bg_done));
-            HIPCHK(e, hipEventCreate(&e->ev_bg0));
+            // a device that refuses CU masks (e.g. a partitioned GPU) simply runs the plain one-stream path: same HIP kernels, same tokens
+            if (hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mfg.size(), mfg.data()) != hipSuccess ||
+                hipExtStreamCreateWithCUMask(&e->bg_stream, (uint32_t)mbg.size(), mbg.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                if (e->stream) { hipStreamDestroy(e->stream); e->stream = nullptr; }
+                if (e->bg_stream) { hipStreamDestroy(e->bg_stream); e->bg_stream = nullptr; }
+                e->overlap = false;
+            } else {
+                HIPCHK(e, hipStreamCreateWithFlags(&e->full_stream, hipStreamNonBlocking));
+                HIPCHK(e, hipEventCreate(&e->ev_pre_done));
+                HIPCHK(e, hipEventCreate(&e->ev_tar_done));
+                HIPCHK(e, hipEventCreate(&e->ev_bg_done));
+                HIPCHK(e, hipEventCreate(&e->ev_bg0));
+            }
         }
     }
     if (!e->overlap) HIPCHK(e, hipStreamCreate(&e->stream));
