@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="scenes per GPU (configs[1] is batch=1)")
     ap.add_argument("--config", default="large", choices=["large", "tiny", "wide2x"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--history", type=int, default=20, help="history frames T (configs[4]: 40 = doubled context)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     args = ap.parse_args()
@@ -122,7 +123,7 @@ def main():
     cfg = {"large": large_config, "tiny": tiny_config, "wide2x": wide2x_config}[args.config]()
     if os.environ.get("UMGEN_BENCH_OAR_LAYERS"):      # experiment knob (not a bench configuration)
         cfg.n_oar_layer = int(os.environ["UMGEN_BENCH_OAR_LAYERS"])
-    T = min(20, cfg.max_frame_len - 1)
+    T = min(args.history, cfg.max_frame_len - 1)
     B = args.batch
     eng = Engine(cfg, precision=args.precision, max_batch=B, max_cond_frames=T, device=local_rank, use_graphs=not args.no_graphs)
     t_load = time.perf_counter()

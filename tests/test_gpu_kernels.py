@@ -80,7 +80,7 @@ def test_attn_spatial(bf16, F, S, H):
     np.testing.assert_allclose(got, ref, atol=(2e-2 if bf16 else 2e-5), rtol=0)
 
 
-@pytest.mark.parametrize("B,T,S,H", [(1, 20, 333, 16), (2, 3, 100, 2)])
+@pytest.mark.parametrize("B,T,S,H", [(1, 20, 333, 16), (2, 3, 100, 2), (1, 40, 77, 4), (1, 64, 31, 2)])
 @pytest.mark.parametrize("bf16", [0, 1])
 def test_attn_temporal(bf16, B, T, S, H):
     E = H * 48

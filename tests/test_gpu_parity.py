@@ -234,3 +234,19 @@ def test_evaluate_cli_end_to_end_on_a_raw_clip(tmp_path):
     mtime = p.stat().st_mtime_ns
     evaluate.main(argv)                                                             # "... has been processed"
     assert p.stat().st_mtime_ns == mtime
+
+
+def test_long_history_window_of_39_frames_matches_oracle():
+    """BASELINE.json config #5 doubles the context: history windows above 32 slots take the 64-slot temporal-attention form
+    (2 heads per workgroup).  fp32 greedy, 39 history frames -> the new frame is token-exact against the oracle."""
+    cfg = tiny_config(max_frame_len=48).greedy()
+    sd = synthetic_state_dict(cfg, seed=5)
+    scene = synthetic_scene(77, n_frames=39)
+    ref = OracleUMGen(cfg, sd).inference(1, 40, scene, input_cond_frames=39, seed=0)
+    e = Engine(cfg, precision="fp32", max_batch=1, max_cond_frames=40)
+    e.load_state_dict(sd)
+    e.finalize()
+    out = e.rollout(scene, 1, cond_frames=40, input_cond_frames=39, seeds=[0])
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(out[m], ref[m], err_msg=m)
+    e.close()

@@ -316,12 +316,12 @@ constexpr int kTmax = 32;
 // the k | v rows of the t0 earlier slots come from the layer's persistent cache [B][Tcap][S][2E] (written by an earlier launch with
 // write = 1).  Every query runs the same sequential online softmax over keys 0 .. tq whichever launch its keys came from, so a
 // split pass (slots 0..P-1 ahead of time, slot P later) is bit-identical to one pass over all P + 1 slots.
-template <typename T, int HG>
-__global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* __restrict__ qkv, T* __restrict__ y, int Tn, int S, int H,
-                                                                       TemporalRange tr) {
+template <typename T, int HG, int TMAX = kTmax>
+__global__ __launch_bounds__(HG * TMAX * 4) void attn_temporal_kernel(const T* __restrict__ qkv, T* __restrict__ y, int Tn, int S, int H,
+                                                                      TemporalRange tr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [T][3][HG*48]
     constexpr int W = HG * kHeadDim;
-    constexpr int NT = HG * kTmax * 4;
+    constexpr int NT = HG * TMAX * 4;
     const int hg = blockIdx.x % (H / HG);
     const long bs = blockIdx.x / (H / HG);          // b*S + s
     const int s = (int)(bs % S);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* 
     T* cache = reinterpret_cast<T*>(tr.cache);
     constexpr int chunks_per_seg = W / 8;
     const int n_chunks = T_ * 3 * chunks_per_seg;
-    constexpr int kIter = (kTmax * 3 * chunks_per_seg + NT - 1) / NT;
+    constexpr int kIter = (TMAX * 3 * chunks_per_seg + NT - 1) / NT;
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {   // all 16-byte loads of the thread are in flight together
         const int c = tid + NT * it;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* 
     }
     __syncthreads();
     // 4 lanes per (head, query frame): lane part p owns head-dim slice [12p, 12p+12)
-    const int part = tid & 3, tq = (tid >> 2) % kTmax, hl = tid / (4 * kTmax);
+    const int part = tid & 3, tq = (tid >> 2) % TMAX, hl = tid / (4 * TMAX);
     const bool active = tq >= t0 && tq < T_;
     float q[12], o[12];
     const float* qp = sm + ((active ? tq : t0) * 3 + 0) * W + hl * kHeadDim + part * 12;
@@ -406,8 +406,17 @@ __global__ __launch_bounds__(HG * kTmax * 4) void attn_temporal_kernel(const T* 
 
 template <typename T>
 void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int Tn, int S, int H, TemporalRange tr) {
-    // t0 + Tn <= kTmax (checked at engine creation); 4 heads per workgroup when H allows
+    // up to 32 history slots: 4 heads per workgroup when H allows; 33..64 slots (the 2x-context stress configuration): 64 query slots
+    // per head, 2 heads per workgroup
     const int T_ = tr.t0 + Tn;
+    if (T_ > kTmax) {
+        const size_t shm = (size_t)T_ * 3 * 2 * kHeadDim * sizeof(float);
+        if (H % 2 == 0)
+            hipLaunchKernelGGL((attn_temporal_kernel<T, 2, 64>), dim3((unsigned)((long)B * S * (H / 2))), dim3(2 * 64 * 4), shm, s, qkv, y, Tn, S, H, tr);
+        else
+            hipLaunchKernelGGL((attn_temporal_kernel<T, 1, 64>), dim3((unsigned)((long)B * S * H)), dim3(64 * 4), shm / 2, s, qkv, y, Tn, S, H, tr);
+        return;
+    }
     if (H % 4 == 0) {
         const size_t shm = (size_t)T_ * 3 * 4 * kHeadDim * sizeof(float);
         hipLaunchKernelGGL((attn_temporal_kernel<T, 4>), dim3((unsigned)((long)B * S * (H / 4))), dim3(4 * kTmax * 4), shm, s, qkv, y, Tn, S, H, tr);

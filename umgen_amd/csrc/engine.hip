@@ -850,7 +850,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (cfg->n_embd > 1536) return e->fail(UMGEN_E_UNSUPPORTED, "n_embd <= 1536 supported");
     if (cfg->map_vocab > 8192 || cfg->img_vocab > 8192 || cfg->bbox3d_vocab != 1028 || cfg->pose_vocab > 8192)
         return e->fail(UMGEN_E_UNSUPPORTED, "vocab sizes out of range");
-    if (cfg->max_cond_frames > 32) return e->fail(UMGEN_E_UNSUPPORTED, "max_cond_frames <= 32 supported (temporal attention tile)");
+    if (cfg->max_cond_frames > 64) return e->fail(UMGEN_E_UNSUPPORTED, "max_cond_frames <= 64 supported (temporal attention tile)");
     if (cfg->max_batch < 1 || cfg->max_cond_frames < 1 || cfg->max_cond_frames > cfg->max_frame_len)
         return e->fail(UMGEN_E_INVALID, "max_batch / max_cond_frames invalid");
     if (cfg->precision != UMGEN_PREC_FP32 && cfg->precision != UMGEN_PREC_BF16) return e->fail(UMGEN_E_INVALID, "precision");
