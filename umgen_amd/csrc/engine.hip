@@ -78,6 +78,8 @@ struct umgen_engine {
     // the ego / map / box / TAR stacks on `bg_stream` (a CU-masked stream) while the latency-bound decode loop runs on the
     // other CUs; their temporal k | v rows are kept per layer in `tcache`.  The next frame then only computes its last slot.
     bool overlap = false, overlap_suspended = false;
+    int last_B = 0;
+    float last_full_pre_ms = 0.f, last_oar_ms = 0.f;   // ego + TAR phase of the last whole-window frame / decode loop of the last frame
     int overlap_mode = 1;                // UMGEN_OVERLAP: 0 off, 1 on for one scene per GPU (default), 2 always
     hipStream_t bg_stream = nullptr;
     // the last-slot passes of the map / box stacks run beside the TAR stack's on their own streams and 1-slot workspaces
@@ -607,7 +609,11 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     // overlapped TAR pass: when the previous frame's background pass covered slots 0..Tn-2 of this very window, only the last slot
     // is pushed through the stacks now (against the per-layer slot caches)
     const bool use_px = prefix_matches(e, io);
-    const bool ov_active = e->overlap && !e->overlap_suspended && !e->profiling && !tr && (B == 1 || e->overlap_mode == 2);
+    // the background pass runs on a quarter of the CUs (measured 3.1x the whole-window time of the same stacks on all CUs): only
+    // worth launching when that is expected to hide behind the decode loop (numbers of the previous frames of this engine)
+    if (e->last_B != B) { e->last_B = B; e->last_full_pre_ms = 0.f; }
+    const bool hides = e->overlap_mode == 2 || e->last_full_pre_ms <= 0.f || 3.3f * e->last_full_pre_ms < 0.95f * e->last_oar_ms;
+    const bool ov_active = e->overlap && !e->overlap_suspended && hides && !e->profiling && !tr && (B == 1 || e->overlap_mode == 2);
     // the ego / TAR phase runs on all CUs; the decode loop leaves the background stream's XCDs alone only when a pass can follow
     hipStream_t const pre = e->full_stream ? e->full_stream : fg;   // (the background stream is idle until this phase is over)
     hipStream_t const dec = (e->full_stream && !ov_active) ? e->full_stream : fg;
@@ -761,6 +767,12 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->tm.ego_ms += ms;
     hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->tm.tar_ms += ms;
     hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->tm.oar_ms += ms;
+    e->last_oar_ms = ms;
+    if (!use_px) {
+        float pre = 0.f;
+        hipEventElapsedTime(&pre, e->ev[0], e->ev[2]);
+        e->last_full_pre_ms = pre;
+    }
     hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->tm.total_ms += ms;
     e->tm.frames += 1;
     if (use_px) e->tm.overlapped_frames += 1;
