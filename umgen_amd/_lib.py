@@ -14,10 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # UMGEN_LIB_PATH selects an alternative build of the SAME library (kernel experiments with extra -D flags); never a fallback
 LIB_PATH = os.environ.get("UMGEN_LIB_PATH") or os.path.join(HERE, "libumgen_hip.so")
-SOURCES = ["engine.hip", "gemm.hip", "attn.hip", "gemv.hip", "rowops.hip", "frame.hip", "debug_api.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "rowops.hip", "frame.hip", "debug_api.hip"]
 EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen_rollout", "umgen_frame",
            "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",
-           "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench"]
+           "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench", "umgen_dbg_oar_step"]
 
 PREC_FP32, PREC_BF16 = 0, 1
 DT_F32, DT_BF16, DT_F16, DT_F64 = 0, 1, 2, 3
@@ -112,6 +112,7 @@ def load_library() -> C.CDLL:
     lib.umgen_dbg_attn_decode.argtypes = [i32, fp, vp, i32, i32, i32, fp]
     lib.umgen_dbg_gemv.argtypes = [i32, fp, fp, vp, fp, i32, i32, i32, i32, fp]
     lib.umgen_dbg_gemm_bench.argtypes = [i32, i32, i32, i32, i32, fp]
+    lib.umgen_dbg_oar_step.argtypes = [vp, i32, i32, fp, fp, i32, i32]
     for name in EXPORTS:
         if name not in ("umgen_last_error", "umgen_version"):
             getattr(lib, name).restype = C.c_int

@@ -113,6 +113,23 @@ struct umgen_engine {
     int step_graph_B = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev, attn_ev;
     size_t gemm_ev_used = 0, attn_ev_used = 0;
+    // XCD-resident decode engine (oar_engine.hip): one launch per decode step instead of five per layer
+    struct EngStream { bool ok = false; int NG = 0; unsigned char map[16]; };
+    bool eng_enabled = false;
+    EngStream eng_fg, eng_full;          // census of the decode stream (CU-masked when the overlap exists) and of the unmasked stream
+    OarLayerDev* d_layers = nullptr;
+    unsigned long long *eng_gx = nullptr, *eng_gloc = nullptr;
+    unsigned int *eng_ticket = nullptr, *eng_err = nullptr;
+    unsigned long long* eng_stamps = nullptr;   // UMGEN_DEBUG_TIMING: per-phase ticks of the engine (printed at destroy)
+    size_t eng_gloc_bytes = 0;
+    int fg_xcds = 8;
+    unsigned eng_epoch = 16u;             // first hand-off tag of the next frame (see run_frame)
+    int step_graph_NG = -1;
+    const EngStream* eng_for(hipStream_t s) const {
+        if (!eng_enabled) return nullptr;
+        const EngStream* es = (full_stream && s == full_stream) ? &eng_full : &eng_fg;
+        return es->ok ? es : nullptr;
+    }
     double gemm_flops_pending = 0, attn_flops_pending = 0;
 
     int fail(int code, const char* fmt, ...) {
@@ -414,6 +431,25 @@ template <typename T>
 void oar_layers(umgen_engine* e, int B, int ns, int ns_cached) {
     const int E = e->E, H = e->H;
     const int* d_len = &e->d_state->step;
+    if (const umgen_engine::EngStream* es = sizeof(T) == 2 ? e->eng_for(e->stream) : nullptr) {
+        OarEngineArgs a{};
+        a.layers = e->d_layers; a.n_layers = (int)e->oar.size();
+        a.kvcache = reinterpret_cast<bf16_t*>(e->kvcache); a.kv_layer_stride = e->kv_layer_stride; a.kv_scene_stride = e->kv_scene_stride; a.Lmax = e->Lmax;
+        a.xdec = e->xdec; a.st = e->d_state; a.gx = e->eng_gx; a.gloc = e->eng_gloc; a.ticket = e->eng_ticket; a.err = e->eng_err;
+        a.B = B; a.NG = es->NG;
+        a.R = es->NG;
+        for (int r = 1; r <= es->NG; ++r)
+            if (es->NG % r == 0 && r >= std::min(B, es->NG)) { a.R = r; break; }
+        if (const char* dd = getenv("UMGEN_DEBUG_ENGINE_D")) {   // debugging: fewer groups per scene than the batch size asks for
+            const int want = atoi(dd);
+            if (want >= 1 && es->NG % want == 0 && es->NG / want >= std::min(B, es->NG)) a.R = es->NG / want;
+        }
+        a.D = es->NG / a.R;
+        memcpy(a.xcc_group, es->map, 16);
+        a.stamps = e->eng_stamps;
+        (void)launch_oar_engine(e->stream, a);
+        return;
+    }
     for (size_t li = 0; li < e->oar.size(); ++li) {
         const SubW& w = e->oar[e->dbg_same_layer ? 0 : li];
         T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
@@ -498,6 +534,14 @@ int enqueue_step(umgen_engine* e, int B, int mod, int ns, int ns_cached, const u
     const int E = e->E;
     hipStream_t st = e->stream;
     oar_layers<T>(e, B, ns, ns_cached);
+    static FILE* dump = getenv("UMGEN_DEBUG_DUMP_X") ? fopen(getenv("UMGEN_DEBUG_DUMP_X"), "wb") : nullptr;   // debugging only (eager launches)
+    if (dump && tr == nullptr && !e->cfg.use_graphs) {
+        std::vector<float> hx((size_t)E);
+        hipMemcpyAsync(hx.data(), e->xdec, (size_t)E * 4, hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+        fwrite(hx.data(), 4, E, dump);
+        fflush(dump);
+    }
     SampleArgs sa{};
     sa.st = e->d_state; sa.tb = e->tb; sa.logits = e->logits; sa.logits_tar = e->logits_tar; sa.ld_logits = 8192;
     sa.cond = e->cond; sa.x_next = e->xdec; sa.tokens = e->d_tokens; sa.prev_box = e->d_prev_box; sa.control_slot = e->d_control;
@@ -674,7 +718,17 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         int a0 = 0, b0 = kImgEos;
         if (sscanf(dbg, "%d:%d", &a0, &b0) == 2 && a0 >= 0 && b0 <= kImgEos && a0 < b0) { j_begin = a0; j_end = b0; }
     }
-    OarState s0{j_begin, io.frame_idx, forced ? 1 : 0, io.control_slot ? 1 : 0, 0, sp};
+    // Hand-off tags of the decode engine never repeat while a copy of an old granule can survive anywhere (a group's L2 keeps its
+    // plain-stored granules across launches): the epoch runs on monotonically over the engine's lifetime.  Before the 32-bit
+    // counter would wrap (~470 frames) everything is drained and the granule buffers are cleared.
+    if (e->eng_enabled && e->eng_epoch > 0xE0000000u) {
+        HIPCHK(e, hipDeviceSynchronize());
+        HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
+        HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
+        e->eng_epoch = 16u;
+    }
+    OarState s0{j_begin, io.frame_idx, forced ? 1 : 0, io.control_slot ? 1 : 0, 0, e->eng_epoch, sp};
+    e->eng_epoch += (unsigned)(kImgEos + 1) * kEpochPerStep;
     HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
 
     // Step 2: the three TAR stacks (UMGen.py:1484-1494) and the conditioning rows (1496-1511)
@@ -728,11 +782,14 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
     }
     const bool graphs = e->cfg.use_graphs && !tr;
-    if (graphs && e->step_graph_B != B) {
+    const umgen_engine::EngStream* eng = sizeof(T) == 2 ? e->eng_for(st) : nullptr;
+    const int eng_ng = eng ? eng->NG : 0;     // the engine's grid depends on the stream's XCDs: graphs are per (B, NG)
+    if (graphs && (e->step_graph_B != B || e->step_graph_NG != eng_ng)) {
         for (auto& row : e->step_graph)
             for (auto& g : row)
                 if (g) { hipGraphExecDestroy(g); g = nullptr; }
         e->step_graph_B = B;
+        e->step_graph_NG = eng_ng;
     }
     for (int j = j_begin; j < j_end; ++j) {   // the img-eos step (j = 2206) produces nothing that is consumed
         int mod = 0;
@@ -741,7 +798,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         else if (j >= kImgC0 && j < kImgEos) mod = 3;
         const int ns = attn_nsplit(j + 1);          // key splits over the j cached keys + the new one
         const int ns_cached = attn_nsplit(j);       // fused-decode experiment: splits over the cached keys only
-        const int gkey = e->fused_decode ? ns_cached : ns;
+        const int gkey = eng ? 0 : (e->fused_decode ? ns_cached : ns);   // the engine derives its key geometry from the device-side step
         if (graphs) {
             hipGraphExec_t& ge = e->step_graph[mod][gkey];
             if (!ge) {
@@ -756,13 +813,19 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         } else if (int rc = enqueue_step<T>(e, B, mod, ns, ns_cached, tr, j)) {
             return rc;
         }
-        e->tm.oar_kernels += (e->fused_decode ? 4 : 5) * (int64_t)e->oar.size() + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
+        e->tm.oar_kernels += (eng ? 1 : (e->fused_decode ? 4 : 5) * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
     }
     e->tm.oar_steps += kImgEos;
     HIPCHK(e, hipEventRecord(e->ev[3], st));
     HIPCHK(e, hipMemcpyAsync(io.out_tokens, e->d_tokens, (size_t)B * kTokPerFrame * 4, hipMemcpyDeviceToHost, st));
     if (tr && tr->counters) HIPCHK(e, hipMemcpyAsync(tr->counters, e->d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    unsigned eng_err = 0;
+    if (eng) HIPCHK(e, hipMemcpyAsync(&eng_err, e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
+    if (eng_err) {   // a hand-off of the decode engine timed out (e.g. two engines sharing one GPU): never return tokens from such a frame
+        (void)hipMemset(e->eng_err, 0, sizeof(unsigned));
+        return e->fail(UMGEN_E_HIP, "decode engine gave up waiting for hand-off tag 0x%08x (is another persistent kernel using this GPU?)", eng_err);
+    }
     float ms;
     hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->tm.ego_ms += ms;
     hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->tm.tar_ms += ms;
@@ -873,9 +936,16 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     // overlapped TAR pass (UMGEN_OVERLAP=0 disables it): the decode stream and the background stream get disjoint CU masks --
     // measured on MI355X, a decode loop sharing CUs with a concurrent GEMM stream runs at a quarter of its speed, with disjoint
     // masks (64 background CUs) it loses 8 %
-    e->overlap = cfg->max_cond_frames >= 2;
-    if (const char* ov = getenv("UMGEN_OVERLAP")) { e->overlap_mode = ov[0] - '0'; e->overlap = e->overlap && ov[0] != '0'; }
-    int bg_cus = 64;   // the mask takes effect in whole XCDs (32 CUs) on MI355X: 64 = 2 of the 8 XCDs for the background stream
+    // The decode engine (oar_engine.hip) needs whole XCDs: 32 workgroups, one per CU, on each of them.  A CU mask cannot give
+    // that -- measured with the engine's census: the mask bits are striped over the XCDs (64 background CUs = 8 CUs of EVERY
+    // XCD), so a masked decode stream has 24 CUs per XCD.  The engine halves the decode loop, which is worth more than hiding the
+    // TAR pass behind a launch-bound loop: when the engine can be used the overlap is off unless UMGEN_OVERLAP asks for it
+    // (then the decode step is the five-launch form again).
+    const char* de_env = getenv("UMGEN_DECODE_ENGINE");
+    const bool engine_wanted = cfg->precision == UMGEN_PREC_BF16 && cfg->n_embd == kEngE && cfg->n_head == kEngH && !(de_env && de_env[0] == '0');
+    e->overlap = cfg->max_cond_frames >= 2 && !engine_wanted;
+    if (const char* ov = getenv("UMGEN_OVERLAP")) { e->overlap_mode = ov[0] - '0'; e->overlap = cfg->max_cond_frames >= 2 && ov[0] != '0'; }
+    int bg_cus = 64;   // mask bits are striped over the 8 XCDs: 64 = 8 CUs of each XCD for the background stream
     if (const char* bc = getenv("UMGEN_BG_CUS")) bg_cus = std::max(32, std::min(128, atoi(bc)));
     if (e->overlap) {
         hipDeviceProp_t prop;
@@ -886,6 +956,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
             std::vector<uint32_t> mbg((ncu + 31) / 32, 0u), mfg((ncu + 31) / 32, 0u);
             int fg_cus = ncu - bg_cus;   // UMGEN_FG_CUS: experiment, decode loop on fewer XCDs (32 CUs each)
             if (const char* fc = getenv("UMGEN_FG_CUS")) fg_cus = std::max(32, std::min(ncu - bg_cus, atoi(fc)));
+            e->fg_xcds = fg_cus / 32;
             for (int cu = 0; cu < ncu; ++cu) {
                 if (cu < bg_cus) mbg[cu / 32] |= 1u << (cu % 32);
                 else if (cu < bg_cus + fg_cus) mfg[cu / 32] |= 1u << (cu % 32);
@@ -1063,6 +1134,70 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (int rc = dalloc(e, &e->d_boxes, Bm * 64 * 10)) return rc;
     if (int rc = dalloc(e, &e->d_seeds, Bm)) return rc;
     if (int rc = dalloc(e, &e->d_state, (size_t)1)) return rc;
+    // ---- XCD-resident decode engine (UMGEN_DECODE_ENGINE=0 keeps the five-launch decode layer) ----
+    if (engine_wanted) {
+        if (int rc = dalloc(e, &e->d_layers, (size_t)cfg->n_oar_layer)) return rc;
+        std::vector<OarLayerDev> hl(cfg->n_oar_layer);
+        for (int i = 0; i < cfg->n_oar_layer; ++i) {
+            const SubW& w = e->oar[i];
+            hl[i] = OarLayerDev{reinterpret_cast<const bf16_t*>(w.attn.Wqkv), reinterpret_cast<const bf16_t*>(w.attn.Wo),
+                                reinterpret_cast<const bf16_t*>(w.mlp.Wfc), reinterpret_cast<const bf16_t*>(w.mlp.Wproj),
+                                w.attn.bqkv, w.attn.bo, w.ln_a, w.ln_b};
+        }
+        HIPCHK(e, hipMemcpy(e->d_layers, hl.data(), hl.size() * sizeof(OarLayerDev), hipMemcpyHostToDevice));
+        e->eng_gloc_bytes = (size_t)16 * kEngLocStride * 8;
+        if (int rc = dalloc(e, &e->eng_gx, Bm * kEngE)) return rc;
+        if (int rc = dev_alloc(e, reinterpret_cast<void**>(&e->eng_gloc), e->eng_gloc_bytes)) return rc;
+        if (int rc = dalloc(e, &e->eng_ticket, (size_t)16)) return rc;
+        if (int rc = dalloc(e, &e->eng_err, (size_t)4)) return rc;
+        HIPCHK(e, hipMemset(e->eng_ticket, 0, 64));
+        if (getenv("UMGEN_DEBUG_TIMING")) {
+            if (int rc = dalloc(e, &e->eng_stamps, (size_t)16)) return rc;
+            HIPCHK(e, hipMemset(e->eng_stamps, 0, 128));
+        }
+        HIPCHK(e, hipMemset(e->eng_gx, 0, Bm * kEngE * 8));
+        HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
+        HIPCHK(e, hipMemset(e->eng_err, 0, 16));
+        // census: an engine-shaped launch (one 512-thread workgroup per CU) must put exactly 32 workgroups on each of NG XCDs
+        auto census = [&](hipStream_t s, int NG, umgen_engine::EngStream& es) -> int {
+            unsigned* d_cnt;
+            if (int rc = dalloc(e, &d_cnt, (size_t)16)) return rc;
+            es.ok = false;
+            for (int rep = 0; rep < 2; ++rep) {      // twice: the placement must be reproducible
+                HIPCHK(e, hipMemsetAsync(d_cnt, 0, 64, s));
+                HIPCHK(e, launch_oar_engine_census(s, NG, d_cnt));
+                unsigned cnt[16];
+                HIPCHK(e, hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, s));
+                HIPCHK(e, hipStreamSynchronize(s));
+                if (getenv("UMGEN_DEBUG_TIMING")) {
+                    fprintf(stderr, "[umgen] engine census (%d groups asked):", NG);
+                    for (int x = 0; x < 16; ++x) fprintf(stderr, " %u", cnt[x]);
+                    fprintf(stderr, "\n");
+                }
+                int groups = 0;
+                unsigned char map[16];
+                bool good = true;
+                for (int x = 0; x < 16; ++x) {
+                    map[x] = 0xff;
+                    if (cnt[x] == (unsigned)kEngGroup) map[x] = (unsigned char)groups++;
+                    else if (cnt[x] != 0) good = false;
+                }
+                if (!good || groups != NG) return 0;
+                if (rep == 1 && memcmp(map, es.map, 16)) return 0;
+                memcpy(es.map, map, 16);
+            }
+            es.NG = NG;
+            es.ok = true;
+            return 0;
+        };
+        // (a CU-masked decode stream never passes: its CUs are spread over all XCDs)
+        if (!e->overlap) { if (int rc = census(e->stream, 8, e->eng_fg)) return rc; }
+        if (e->full_stream) { if (int rc = census(e->full_stream, 8, e->eng_full)) return rc; }
+        e->eng_enabled = e->eng_fg.ok || e->eng_full.ok;
+        if (getenv("UMGEN_DEBUG_TIMING"))
+            fprintf(stderr, "[umgen] decode engine: decode stream %s (%d XCDs), unmasked stream %s\n", e->eng_fg.ok ? "ok" : "off", e->eng_fg.NG,
+                    e->eng_full.ok ? "ok" : "off");
+    }
     return UMGEN_OK;
 }
 
@@ -1284,9 +1419,51 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
     return UMGEN_OK;
 }
 
+// Test hook: ONE decode step through the BlockOAR layers (no head, no sampler) on caller-provided inputs, either as the five-launch
+// layer form or through the decode engine.  The K/V rows of position L are appended to the cache, so a test drives L = 0, 1, 2, ...
+int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in, float* x_out, int32_t use_engine, int32_t unmasked) {
+    if (!e || !x_in || !x_out) return UMGEN_E_INVALID;
+    if (!e->finalized) return e->fail(UMGEN_E_STATE, "umgen_finalize_weights has not been called");
+    if (e->cfg.precision != UMGEN_PREC_BF16) return e->fail(UMGEN_E_UNSUPPORTED, "bf16 engines only");
+    if (B < 1 || B > e->cfg.max_batch || L < 0 || L >= e->Lmax) return e->fail(UMGEN_E_INVALID, "B=%d L=%d", B, L);
+    if (use_engine && !e->eng_enabled) return e->fail(UMGEN_E_UNSUPPORTED, "decode engine not available on this engine");
+    const unsigned epoch = e->eng_epoch;   // tags never repeat across calls
+    e->eng_epoch += kEpochPerStep;
+    hipStream_t const keep = e->stream;
+    hipStream_t const st = (unmasked && e->full_stream) ? e->full_stream : e->stream;
+    OarState s0{L, 0, 0, 0, 0, epoch, SamplerParams{}};
+    HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(e->xdec, x_in, (size_t)B * e->E * 4, hipMemcpyHostToDevice, st));
+    const bool en = e->eng_enabled;
+    e->eng_enabled = en && use_engine;
+    e->stream = st;
+    oar_layers<bf16_t>(e, B, attn_nsplit(L + 1), attn_nsplit(L));
+    e->stream = keep;
+    e->eng_enabled = en;
+    HIPCHK(e, hipMemcpyAsync(x_out, e->xdec, (size_t)B * e->E * 4, hipMemcpyDeviceToHost, st));
+    unsigned eng_err = 0;
+    if (use_engine) HIPCHK(e, hipMemcpyAsync(&eng_err, e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (eng_err) {
+        (void)hipMemset(e->eng_err, 0, sizeof(unsigned));
+        return e->fail(UMGEN_E_HIP, "decode engine gave up waiting for hand-off tag 0x%08x", eng_err);
+    }
+    return UMGEN_OK;
+}
+
 int umgen_destroy(umgen_engine* e) {
     if (!e) return UMGEN_OK;
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->eng_stamps) {
+        unsigned long long st[16];
+        if (hipMemcpy(st, e->eng_stamps, 128, hipMemcpyDeviceToHost) == hipSuccess && st[10]) {
+            const char* nm[10] = {"wait x", "qkv rows", "wait qkv", "attention", "wait partials", "c_proj", "wait x'", "c_fc", "wait h", "mlp proj"};
+            fprintf(stderr, "[umgen] decode engine, group 0 rank 0, us per item over %llu items:", st[10]);
+            double tot = 0;
+            for (int p = 0; p < 10; ++p) { fprintf(stderr, " %s %.2f", nm[p], (double)st[p] / 100.0 / (double)st[10]); tot += (double)st[p] / 100.0 / (double)st[10]; }
+            fprintf(stderr, " | total %.2f\n", tot);
+        }
+    }
     for (auto& row : e->step_graph)
         for (auto& g : row)
             if (g) hipGraphExecDestroy(g);

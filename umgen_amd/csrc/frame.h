@@ -34,6 +34,8 @@ struct WindowTokens {
     int t0 = 0;        // first slot of the pass: tokens and tpe are indexed with t0 + t_local
 };
 
+constexpr unsigned kEpochPerStep = 4096;   // hand-off tags one decode step may use (rounds x layers x edges)
+
 struct SamplerParams {
     int method, top_k, top_k_map, topk_image;
     float p, p_map, temperature;
@@ -48,6 +50,7 @@ struct OarState {
     int use_forced;  // teacher forcing: take tokens from SampleArgs::forced
     int use_control; // control_test: SampleArgs::control_slot is valid
     int done;        // blocks of the step's last kernel that have finished (the last one advances `step`)
+    unsigned epoch;  // base of the decode engine's hand-off tags for this step (advanced with `step`, oar_engine.hip)
     SamplerParams sp;
 };
 

@@ -195,12 +195,12 @@ void launch_ego_queries(hipStream_t s, const EmbedTables& tb, int B, int T, floa
 __device__ inline void finish_step(OarState* st) {
     __syncthreads();
     if (gridDim.x == 1) {   // one scene: no arrival count needed (saves a returning atomic at the end of every step)
-        if (threadIdx.x == 0) st->step += 1;
+        if (threadIdx.x == 0) { st->step += 1; st->epoch += kEpochPerStep; }
         return;
     }
     if (threadIdx.x == 0) {
         const int t = atomicAdd(&st->done, 1);
-        if (t == (int)gridDim.x - 1) { st->done = 0; st->step += 1; }
+        if (t == (int)gridDim.x - 1) { st->done = 0; st->step += 1; st->epoch += kEpochPerStep; }
     }
 }
 

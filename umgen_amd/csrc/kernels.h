@@ -115,4 +115,33 @@ struct QkvAttnArgs {
 };
 template <typename T> void launch_qkv_attn(hipStream_t s, const QkvAttnArgs& a);
 
+// ------------------------------------------------------------------------------------------------
+// XCD-resident decode engine (oar_engine.hip): all BlockOAR layers of one decode step in one launch, bf16 weights, n_embd 768
+// ------------------------------------------------------------------------------------------------
+constexpr int kEngE = 768, kEngH = 16;         // the width the engine is built for (UMGen_Large); other widths use the launches above
+constexpr int kEngThreads = 512;               // one workgroup per CU
+constexpr int kEngGroup = 32;                  // workgroups per group == CUs per XCD
+constexpr int kEngLocStride = 3 * kEngE + 2 * kEngH * 50 + kEngE + 4 * kEngE + kEngE;   // granules per group: q|k|v, half partials, x', h, x
+struct OarLayerDev {                           // one BlockOAR's parameters (module.py:378-400)
+    const bf16_t *Wqkv, *Wo, *Wfc, *Wproj;
+    const float *bqkv, *bo, *ln_a, *ln_b;
+};
+struct OarState;
+struct OarEngineArgs {
+    const OarLayerDev* layers; int n_layers;
+    bf16_t* kvcache; long kv_layer_stride, kv_scene_stride; int Lmax;   // [layer][scene][2][H][Lmax][48]
+    float* xdec;                               // [B][E]: in = input of layer 0, out = output of the last layer
+    const OarState* st;                        // step (cached keys) and epoch of the hand-off tags
+    unsigned long long* gx;                    // [max_batch][E] cross-group x granules
+    unsigned long long* gloc;                  // [NG][kEngLocStride] group-private granules
+    unsigned int* ticket;                      // [16] monotonic arrival counters per group (rank = ticket % 32)
+    unsigned int* err;                         // give-up word (0 = ok)
+    int B, NG, R, D;                           // scenes; groups; scenes per round; groups per scene (NG == R * D)
+    unsigned char xcc_group[16];               // physical XCC id -> group index (0xff: not taking part)
+    unsigned long long* stamps;                // optional [8]: 100 MHz ticks per phase + item count, accumulated by rank 0 of group 0
+};
+size_t oar_engine_lds_bytes();
+hipError_t launch_oar_engine(hipStream_t s, const OarEngineArgs& a);
+hipError_t launch_oar_engine_census(hipStream_t s, int n_groups, unsigned int* d_counts16);
+
 }  // namespace umgen

@@ -1,0 +1,550 @@
+// XCD-resident OAR decode engine: the 36 BlockOAR layers of one decode step (module.py:378-428) in ONE launch.
+//
+// Why this shape (measured on MI355X, profiles/r02_seam_bench_*.txt): a decode layer at one scene is 14 MB of weights and five
+// all-to-all hand-offs (x -> q|k|v -> attention -> x' -> h -> x'').  As five launches the layer costs 22 us, of which ~9 us are
+// kernel boundaries; as one chip-wide persistent kernel the hand-offs alone cost 12-17 us per layer, because every hop between
+// XCDs pays the fabric twice (write-through store, L2-missing load).  Inside ONE XCD the L2 is coherent for its 32 CUs: a plain
+// 8-byte {tag, value} store lands in the L2 and an sc1 load (L1 bypass) reads it back in 0.8-1.7 us per edge.  So:
+//   * a GROUP = the 32 workgroups (one per CU, 512 threads) that landed on one XCD; a work item = (scene, layer); all five
+//     hand-offs of an item stay inside the group, in group-private granule buffers;
+//   * layers are dealt round-robin over the D groups that serve a scene (layer l -> group l % D): only the 768-float x vector
+//     crosses the fabric between layers (sc1 store + sc1 load, ~2.8 us), and while the other D-1 groups work, a group's loads
+//     for its next layer are already in flight (weights are requested one phase ahead into registers, the first phase's right
+//     after the previous item);
+//   * several scenes: scene s of a round owns groups [s*D, s*D + D) -- with 8 scenes every XCD runs a whole scene.
+// Workgroups find their XCD with s_getreg HW_REG_XCC_ID and take a rank from a per-group ticket; the host has checked with a
+// census launch (oar_engine_census) that the stream's CUs give exactly 32 workgroups on each of NG XCDs -- otherwise the engine
+// is not used and the decode step runs as the five-launch form (gemv.hip).  Every poll is bounded; a give-up is reported
+// through OarEngineArgs::err and fails the frame loudly.
+//
+// Arithmetic (fixed, independent of B / D / group placement, so scenes are batch-invariant): fp32 activations, bf16 weights and
+// bf16 K/V cache, fp32 accumulation.  Row dot products: lane l owns k = 8l..8l+7 (+512 i), 8 sequential FMAs per chunk, DPP
+// wave sum.  Attention of a head: its keys are split in two halves (two CUs), each half in 8 wave spans, each span in groups
+// of 8 lanes per key with an online softmax per lane group; the 64 group partials of a half, then the two halves, are merged in
+// a fixed order.
+#include "frame.h"
+#include "kernels.h"
+
+namespace umgen {
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int E = kEngE, H = kEngH, F = 4 * kEngE;
+constexpr int NT = kEngThreads, NW = kEngThreads / 64, CU = kEngGroup;
+constexpr int RQ = 3 * E / CU / NW;   // 9 q|k|v rows per wave
+constexpr int RO = E / CU / NW;       // 3 c_proj rows per wave
+constexpr int RF = F / CU / NW;       // 12 c_fc rows per wave
+constexpr int RP = E / CU / NW;       // 3 mlp c_proj rows per wave
+static_assert(RQ * NW * CU == 3 * E && RO * NW * CU == E && RF * NW * CU == F, "row partition");
+constexpr u32 kSpinLimit = 2000000;   // bounded polls: ~1 s worst case, then the give-up code is published
+constexpr float kScaleQK = 0.14433756729740643f;   // float32(1/sqrt(48)), module.py:196-198
+
+// LDS carve (floats)
+constexpr int L_XS = 0;                    // x of the item (kept until the attention projection's residual)   [768]
+constexpr int L_XB = L_XS + E;             // x' (kept until the MLP projection's residual)                    [768]
+constexpr int L_AS = L_XB + E;             // merged attention output                                            [768]
+constexpr int L_HS = L_AS + E;             // gelu(c_fc) vector                                                 [3072]
+constexpr int L_QKV = L_HS + F;            // q_h | k_h | v_h of this CU's head                                  [144 -> 160]
+constexpr int L_GP = L_QKV + 160;          // gathered half partials [32][50]                                   [1600]
+constexpr int L_SM = L_GP + 2 * H * 50;    // per lane-group m [64], l [64], weights [64]                        [192]
+constexpr int L_SO = L_SM + 192;           // per lane-group o [64][48]                                          [3072]
+constexpr int L_MISC = L_SO + 64 * 48;     // rank / scratch                                                      [16]
+constexpr int L_LN = L_MISC + 16;          // ln_1 | ln_2 weights of the item                                     [1536]
+constexpr int L_W2 = L_LN + 2 * E;         // parked mlp c_proj rows 0, 1 of every wave: [8][2][6][64] x 16 B      [24576]
+constexpr int L_TOTAL = L_W2 + NW * 2 * 6 * 64 * 4;
+
+__device__ inline u32 xcc_id() {
+    u32 x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 15u;
+}
+__device__ inline u64 gran(u32 tag, float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); }
+// in-group edge: plain store, stays in the XCD's L2 (readers bypass their L1 with sc1 loads)
+__device__ inline void put_local(u64* g, u32 tag, float v) { __hip_atomic_store(g, gran(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// cross-group edge: write-through
+__device__ inline void put_far(u64* g, u32 tag, float v) { __hip_atomic_store(g, gran(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline u64 get(const u64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct Ctx {
+    u32* err;
+    bool failed;
+};
+
+// the workgroup gathers granules [0, n) of g into dst[0, n)
+template <int PER>
+__device__ inline void gather(Ctx& c, int tid, const u64* g, int n, u32 tag, float* dst) {
+    u32 got = 0, need = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (tid + k * NT < n) need |= 1u << k;
+    if (!c.failed) {
+        for (u32 spins = 0;;) {
+            u64 v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (((need & ~got) >> k) & 1u) v[k] = get(g + tid + k * NT);
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (((need & ~got) >> k) & 1u) {
+                    if ((u32)(v[k] >> 32) == tag) { dst[tid + k * NT] = __uint_as_float((u32)v[k]); got |= 1u << k; }
+                }
+            if (!__any(got != need)) break;
+            if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, tag | 0x80000000u); c.failed = true; break; }
+            if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
+        }
+    }
+    __syncthreads();
+}
+
+// Pointers read out of the layer table are generic to the compiler (flat loads): cast them to the global address space.
+#define UMGEN_GLOBAL __attribute__((address_space(1)))
+// wave-uniform base + 32-bit per-lane element offset (global_load ... saddr form: one VGPR of address per load)
+__device__ inline u32x4_t ldwu(const bf16_t* ubase, u32 off) {
+    return __builtin_nontemporal_load((const UMGEN_GLOBAL u32x4_t*)(ubase + off));
+}
+__device__ inline float ldg(const float* p) { return *(const UMGEN_GLOBAL float*)p; }
+__device__ inline void ldg8(const float* p, float (&o)[8]) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v x = *(const UMGEN_GLOBAL f4v*)p;
+    const f4v y = *(const UMGEN_GLOBAL f4v*)(p + 4);
+    o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w; o[4] = y.x; o[5] = y.y; o[6] = y.z; o[7] = y.w;
+}
+__device__ inline void unpack8(const u32x4_t& w, float (&o)[8]) {
+    o[0] = __uint_as_float(w.x << 16); o[1] = __uint_as_float(w.x & 0xffff0000u);
+    o[2] = __uint_as_float(w.y << 16); o[3] = __uint_as_float(w.y & 0xffff0000u);
+    o[4] = __uint_as_float(w.z << 16); o[5] = __uint_as_float(w.z & 0xffff0000u);
+    o[6] = __uint_as_float(w.w << 16); o[7] = __uint_as_float(w.w & 0xffff0000u);
+}
+__device__ inline float dot8(const u32x4_t& w, const float (&x)[8], float acc) {
+    float w8[8];
+    unpack8(w, w8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = fmaf(w8[e], x[e], acc);
+    return acc;
+}
+
+// R rows of a [N][768] matrix held by one wave: chunk a[r] = k 8l..8l+7 of row r; the 256 tail columns of rows (2j, 2j+1) are
+// shared by the two half-waves: lanes 0-31 hold row 2j's, lanes 32-63 row 2j+1's, k = 512 + 8 (l & 31)
+template <int R>
+struct Rows768 {
+    u32x4_t a[R];
+    u32x4_t b[(R + 1) / 2];
+};
+template <int R>
+__device__ inline void req768(Rows768<R>& w, const bf16_t* W, int row0, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) w.a[r] = ldwu(W + (long)(row0 + r) * E, (u32)lane * 8u);
+#pragma unroll
+    for (int j = 0; j < (R + 1) / 2; ++j) {
+        const bool both = 2 * j + 1 < R;   // odd R: the upper half-wave re-reads the last row's tail, its copy is ignored
+        w.b[j] = ldwu(W + (long)(row0 + 2 * j) * E + 512, (u32)(lane & 31) * 8u + (both ? (u32)(lane >> 5) * (u32)E : 0u));
+    }
+}
+template <int R>
+__device__ inline void dot768(const Rows768<R>& w, const float (&x1)[8], const float (&x2)[8], int lane, float (&out)[R]) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = dot8(w.a[r], x1, 0.f);
+#pragma unroll
+    for (int j = 0; j < (R + 1) / 2; ++j) {
+        const float p = dot8(w.b[j], x2, 0.f);
+        acc[2 * j] += (lane < 32) ? p : 0.f;
+        if (2 * j + 1 < R) acc[2 * j + 1] += (lane >= 32) ? p : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = wave_sum(acc[r]);
+}
+
+// LayerNorm (weight only, eps 1e-5, module.py:26-37) of the 768-vector in LDS, in the lane's dot-product layout
+__device__ inline void ln768(const float* xs, const float* lnw, int lane, float (&x1)[8], float (&x2)[8]) {
+    float l1[8], l2[8];
+    load8(lnw + lane * 8, l1);
+    load8(lnw + 512 + (lane & 31) * 8, l2);
+    load8(xs + lane * 8, x1);
+    load8(xs + 512 + (lane & 31) * 8, x2);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += x1[e];
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s2 += x2[e];
+    s += (lane < 32) ? s2 : 0.f;
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = x1[e] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = x2[e] - mean; q2 = fmaf(d, d, q2); }
+    q += (lane < 32) ? q2 : 0.f;
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { x1[e] = (x1[e] - mean) * rstd * l1[e]; x2[e] = (x2[e] - mean) * rstd * l2[e]; }
+}
+
+__device__ inline float bf16_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+}  // namespace
+
+__global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid0 = threadIdx.x;
+    // ---- who am I: group (XCD) and rank inside it ----
+    const u32 xcc = xcc_id();
+    const int g = a.xcc_group[xcc];
+    if (g >= a.NG) return;   // (the census guarantees this never happens)
+    if (tid0 == 0) reinterpret_cast<u32*>(lds + L_MISC)[0] = atomicAdd(a.ticket + g, 1u) & (u32)(CU - 1);
+    __syncthreads();
+    const int w0 = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<u32*>(lds + L_MISC)[0]);
+    Ctx c{a.err, false};
+    const bool timer = a.stamps != nullptr && g == 0 && w0 == 0 && tid0 == 0;
+    unsigned long long t_prev = 0;
+    auto stamp = [&](int p) {
+        if (timer) { const unsigned long long t = wall_clock64(); if (p >= 0) a.stamps[p] += t - t_prev; t_prev = t; }
+    };
+    const int Lk = a.st->step;              // cached keys before this step == position of the new token
+    const u32 ep = a.st->epoch;
+    const int R = a.R, D = a.D;
+    const int rounds = (a.B + R - 1) / R;
+    const int pipe = g / D, q = g % D;      // pipeline (scene slot of the round) and position in it
+    float* xs = lds + L_XS;
+    float* xb = lds + L_XB;
+    float* as = lds + L_AS;
+    float* hs = lds + L_HS;
+
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int s = rd * R + pipe;
+        if (s >= a.B) continue;
+        for (int l = q; l < a.n_layers; l += D) {
+            // Everything below is derived from these four values INSIDE the item: laundering them keeps the compiler from hoisting
+            // ~100 VGPRs / SGPRs of loop-invariant addresses out of the layer loop (they spilled to scratch, on the critical path)
+            int tid = tid0, w = w0, gl = g;
+            asm volatile("" : "+v"(tid));
+            asm volatile("" : "+s"(w), "+s"(gl));
+            const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: row addresses stay in SGPRs)
+            u64* gqkv = a.gloc + (long)gl * kEngLocStride;
+            u64* gpart = gqkv + 3 * E;
+            u64* gxb = gpart + 2 * H * 50;
+            u64* gh = gxb + E;
+            u64* gxl = gh + F;                       // in-group x edge (D == 1)
+            Rows768<RQ> wq;
+            Rows768<RO> wo;
+            Rows768<RF> wf;
+            u32x4_t w2[RP][6];
+            const int rowq = (w * NW + wave) * RQ, rowo = (w * NW + wave) * RO, rowf = (w * NW + wave) * RF;
+            const OarLayerDev lw = a.layers[l];
+            const u32 tg = ep + (u32)((rd * 64 + l) * 8);
+            // q|k|v, attention-projection and c_fc rows of this wave are requested NOW: they are in flight while the group waits
+            // for x (the other D - 1 groups are working); the mlp projection's follow once the attention has freed its registers
+            u32x4_t* w2p = reinterpret_cast<u32x4_t*>(lds + L_W2) + wave * (2 * 6 * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < RP; ++r)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) w2[r][i] = ldwu(lw.Wproj + (long)(rowo + r) * F + 512 * i, (u32)lane * 8u);
+            req768(wq, lw.Wqkv, rowq, lane);
+            req768(wo, lw.Wo, rowo, lane);
+            req768(wf, lw.Wfc, rowf, lane);
+            // two of the three mlp c_proj rows are parked in LDS until P5 (the attention needs the registers); they were requested
+            // first, so this waits for them only -- the rest stays in flight (this wave alone reads its parked rows back)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) w2p[(r * 6 + i) * 64] = w2[r][i];
+            float lnr[3];   // ln_1 | ln_2 weights (1536 floats over 512 threads), staged through LDS once x is here
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lnr[k] = ldg((tid + k * NT < E ? lw.ln_a : lw.ln_b - E) + tid + k * NT);
+            float bq = 0.f, bo = 0.f;
+            if (lane < RQ) bq = ldg(lw.bqkv + rowq + lane);
+            if (lane < RO) bo = ldg(lw.bo + rowo + lane);
+            stamp(-1);
+            // ================= P1: x -> LN -> q | k | v =================
+            float* lnw = lds + L_LN;
+            if (l == 0) {
+                for (int i = tid; i < E; i += NT) xs[i] = a.xdec[(long)s * E + i];
+            } else {
+                gather<2>(c, tid, D == 1 ? gxl : a.gx + (long)s * E, E, tg + 0, xs);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lnw[tid + k * NT] = lnr[k];
+            __syncthreads();
+            stamp(0);   // waited for x
+            // attention geometry of this CU: head hh, half of the L + 1 keys, split in 8 wave spans of 8-key passes
+            const int hh = w >> 1, half = w & 1;
+            const int nk = Lk + 1;
+            const int n0 = min(nk, (((nk + 1) >> 1) + 7) & ~7);
+            const int ka = half ? n0 : 0, kb = half ? nk : n0;
+            const int span = ((((kb - ka) + NW - 1) / NW) + 7) & ~7;
+            const int k_lo = ka + wave * span, k_hi = min(kb, k_lo + span);
+            const int piece = lane & 7, kg = lane >> 3;
+            const bool pact = piece < 6;
+            const bf16_t* kbase = a.kvcache + (long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride + (long)hh * a.Lmax * kHeadDim;
+            const bf16_t* vbase = kbase + (long)H * a.Lmax * kHeadDim;
+            constexpr int KP = 2, NB = 3;              // 8-key passes per register buffer, buffers (NB * KP * 8 keys of a wave in flight)
+            u32x4_t kc[NB][KP], vc[NB][KP];
+            auto kv_req = [&](int buf, int k0) {
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    const u32 off = (u32)min(k0 + 8 * i + kg, a.Lmax - 1) * (u32)kHeadDim + (u32)piece * 8u;
+                    if (pact) { kc[buf][i] = ldwu(kbase, off); vc[buf][i] = ldwu(vbase, off); }
+                    else { kc[buf][i] = u32x4_t{0, 0, 0, 0}; vc[buf][i] = u32x4_t{0, 0, 0, 0}; }
+                }
+            };
+            if (k_lo < k_hi) kv_req(0, k_lo);
+            if (k_lo + 8 * KP < k_hi) kv_req(1, k_lo + 8 * KP);
+            {
+                float x1[8], x2[8], out[RQ];
+                ln768(xs, lnw, lane, x1, x2);
+                dot768<RQ>(wq, x1, x2, lane, out);
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < RQ; ++r) v = (lane == r) ? out[r] : v;
+                v += bq;
+                if (lane < RQ) {
+                    const int n = rowq + lane;
+                    put_local(gqkv + n, tg + 1, v);
+                    if (n >= E) {   // K / V rows of the new token: bf16 into the cache (head-major [2][H][Lmax][48])
+                        const int cc = n - E, kvsel = cc / E, hc = cc % E;
+                        a.kvcache[(long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride +
+                                  ((long)(kvsel * H + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim] = f32_to_bf16(v);
+                    }
+                }
+            }
+            if (k_lo + 16 * KP < k_hi) kv_req(2, k_lo + 16 * KP);   // (the q|k|v rows' registers are free now)
+            stamp(1);   // LN + q|k|v rows
+            // ================= P2: attention of (head hh, half) =================
+            {
+                // q_h | k_h | v_h of the new token
+                float* qs = lds + L_QKV;
+                if (!c.failed) {
+                    const int src = (tid / kHeadDim) * E + hh * kHeadDim + tid % kHeadDim;
+                    for (u32 spins = 0;;) {
+                        bool ok = true;
+                        u64 v = 0;
+                        if (tid < 3 * kHeadDim) { v = get(gqkv + src); ok = (u32)(v >> 32) == tg + 1; }
+                        if (ok && tid < 3 * kHeadDim) qs[tid] = __uint_as_float((u32)v);
+                        if (!__any(!ok)) break;
+                        if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, (tg + 1) | 0x80000000u); c.failed = true; break; }
+                        if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
+                    }
+                }
+                __syncthreads();
+                stamp(2);   // waited for q_h | k_h | v_h
+                float q8[8];   // this lane's piece of q
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q8[e] = pact ? qs[piece * 8 + e] : 0.f;
+                float m_run = -INFINITY, l_run = 0.f, o8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+                auto chunk = [&](const u32x4_t (&kcb)[KP], const u32x4_t (&vcb)[KP], int k0) {
+                    float sc[KP];
+                    float mc = -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) {
+                        const int k = k0 + 8 * i + kg;
+                        float kf[8];
+                        unpack8(kcb[i], kf);
+                        if (k == Lk) {   // the new token's own k, as the cache will hold it (bf16)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) kf[e] = pact ? bf16_round(qs[kHeadDim + piece * 8 + e]) : 0.f;
+                        }
+                        float d = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d = fmaf(q8[e], kf[e], d);
+                        d += dpp_xor1(d);
+                        d += dpp_xor2(d);
+                        d += dpp_half_mirror(d);
+                        d = (k < k_hi) ? d * kScaleQK : -INFINITY;
+                        sc[i] = d;
+                        mc = fmaxf(mc, d);
+                    }
+                    const float m_new = fmaxf(m_run, mc);
+                    if (m_new > -INFINITY) {
+                        const float scale = __expf(m_run - m_new);   // exp(-inf) = 0 on the first chunk
+                        l_run *= scale;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o8[e] *= scale;
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) {
+                            const int k = k0 + 8 * i + kg;
+                            float vf[8];
+                            unpack8(vcb[i], vf);
+                            if (k == Lk) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) vf[e] = pact ? bf16_round(qs[2 * kHeadDim + piece * 8 + e]) : 0.f;
+                            }
+                            const float p = __expf(sc[i] - m_new);
+                            l_run += p;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o8[e] = fmaf(p, vf[e], o8[e]);
+                        }
+                        m_run = m_new;
+                    }
+                };
+                // chunks of 8 KP keys in NB register buffers, all requested before q|k|v were exchanged; a buffer is requested again as
+                // soon as it has been consumed
+                for (int k0 = k_lo; k0 < k_hi; k0 += 8 * KP * NB) {
+                    chunk(kc[0], vc[0], k0);
+                    if (k0 + 8 * KP * NB < k_hi) kv_req(0, k0 + 8 * KP * NB);
+                    if (k0 + 8 * KP < k_hi) {
+                        chunk(kc[1], vc[1], k0 + 8 * KP);
+                        if (k0 + 8 * KP * (NB + 1) < k_hi) kv_req(1, k0 + 8 * KP * (NB + 1));
+                    }
+                    if (k0 + 16 * KP < k_hi) {
+                        chunk(kc[2], vc[2], k0 + 16 * KP);
+                        if (k0 + 8 * KP * (NB + 2) < k_hi) kv_req(2, k0 + 8 * KP * (NB + 2));
+                    }
+                }
+                // 64 lane-group partials of this CU -> LDS -> one half partial (m, l, o[48]) published by wave 0
+                float* sm = lds + L_SM;
+                float* so = lds + L_SO;
+                const int gi = wave * 8 + kg;
+                if (piece == 0) { sm[gi] = m_run; sm[64 + gi] = l_run; }
+                if (pact) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) so[gi * kHeadDim + piece * 8 + e] = o8[e];
+                }
+                __syncthreads();
+                {
+                    // every wave recomputes the 64 merge weights (cheap), then thread (jg, d) folds 8 of the 64 partial rows of
+                    // column d; 48 threads add the 8 folds in a fixed order and publish the half partial (m, l, o[48])
+                    const float mg = sm[lane];
+                    const float M = wave_max(mg);
+                    const float wg = (M > -INFINITY) ? __expf(mg - M) : 0.f;
+                    const float Ls = wave_sum(wg * sm[64 + lane]);
+                    float* fold = lds + L_GP;   // (free until the P3 gather, which starts behind the barrier below)
+                    if (tid < 8 * kHeadDim) {
+                        const int jg = tid / kHeadDim, d = tid % kHeadDim;
+                        float o = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float wj = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (8 * jg + j), __float_as_int(wg)));
+                            o = fmaf(wj, so[(8 * jg + j) * kHeadDim + d], o);
+                        }
+                        fold[jg * kHeadDim + d] = o;
+                    }
+                    __syncthreads();
+                    if (tid < kHeadDim) {
+                        float o = 0.f;
+#pragma unroll
+                        for (int jg = 0; jg < 8; ++jg) o += fold[jg * kHeadDim + tid];
+                        u64* gp = gpart + (hh * 2 + half) * 50;
+                        put_local(gp + tid, tg + 2, o);
+                        if (tid == 0) { put_local(gp + 48, tg + 2, M); put_local(gp + 49, tg + 2, Ls); }
+                    }
+                    __syncthreads();   // fold (the gather buffer) is free again
+                }
+            }
+            stamp(3);   // attention of this CU's half
+            // ================= P3: merge the halves -> c_proj -> x' =================
+            gather<4>(c, tid, gpart, 2 * H * 50, tg + 2, lds + L_GP);
+            stamp(4);   // waited for the half partials
+            {
+                const float* gp = lds + L_GP;
+                for (int col = tid; col < E; col += NT) {
+                    const int h2 = col / kHeadDim, d = col % kHeadDim;
+                    const float* p0 = gp + (h2 * 2) * 50;
+                    const float* p1 = p0 + 50;
+                    const float m0 = p0[48], m1 = p1[48];
+                    const float M = fmaxf(m0, m1);
+                    const float e0 = expf(m0 - M), e1 = (m1 > -INFINITY) ? expf(m1 - M) : 0.f;
+                    const float Ls = fmaf(e1, p1[49], e0 * p0[49]);
+                    as[col] = fmaf(e1, p1[d], e0 * p0[d]) / Ls;
+                }
+                __syncthreads();
+                float x1[8], x2[8], out[RO];
+                load8(as + lane * 8, x1);
+                load8(as + 512 + (lane & 31) * 8, x2);
+                dot768<RO>(wo, x1, x2, lane, out);
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < RO; ++r) v = (lane == r) ? out[r] : v;
+                if (lane < RO) {
+                    const int n = rowo + lane;
+                    put_local(gxb + n, tg + 3, xs[n] + (v + bo));
+                }
+            }
+            stamp(5);   // merge + c_proj rows
+            // ================= P4: x' -> LN -> c_fc -> GELU =================
+            gather<2>(c, tid, gxb, E, tg + 3, xb);
+            stamp(6);   // waited for x'
+            {
+                float x1[8], x2[8], out[RF];
+                ln768(xb, lnw + E, lane, x1, x2);
+                dot768<RF>(wf, x1, x2, lane, out);
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < RF; ++r) v = (lane == r) ? out[r] : v;
+                if (lane < RF) put_local(gh + rowf + lane, tg + 4, gelu_erf(v));
+            }
+            stamp(7);   // LN + c_fc rows
+            // ================= P5: h -> mlp c_proj -> x'' (next layer's x) =================
+            gather<6>(c, tid, gh, F, tg + 4, hs);
+            stamp(8);   // waited for h
+            {
+                float out[RP];
+#pragma unroll
+                for (int r = 0; r < RP; ++r) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        float xv[8];
+                        load8(hs + lane * 8 + 512 * i, xv);
+                        acc = dot8(r < 2 ? w2p[(r * 6 + i) * 64] : w2[r][i], xv, acc);
+                    }
+                    out[r] = wave_sum(acc);
+                }
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < RP; ++r) v = (lane == r) ? out[r] : v;
+                if (lane < RP) {
+                    const int n = rowo + lane;
+                    const float xn = xb[n] + v;
+                    if (l + 1 == a.n_layers) a.xdec[(long)s * E + n] = xn;
+                    else if (D == 1) put_local(gxl + n, tg + 8, xn);
+                    else put_far(a.gx + (long)s * E + n, tg + 8, xn);
+                }
+            }
+            stamp(9);   // mlp c_proj rows
+            if (timer) a.stamps[10] += 1;
+        }
+    }
+}
+
+// census: which XCD did each workgroup of an engine-shaped launch land on?
+__global__ __launch_bounds__(kEngThreads) void oar_engine_census_kernel(u32* counts) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (threadIdx.x == 0) {
+        lds[0] = 0.f;
+        atomicAdd(counts + xcc_id(), 1u);
+    }
+}
+
+size_t oar_engine_lds_bytes() {
+    const size_t need = (size_t)L_TOTAL * sizeof(float);
+    return need > (size_t)(96 << 10) ? need : (size_t)(96 << 10);   // > 80 KB: never two engine workgroups on one CU
+}
+
+hipError_t launch_oar_engine_census(hipStream_t s, int n_groups, unsigned int* d_counts16) {
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(oar_engine_census_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)oar_engine_lds_bytes());
+    if (rc != hipSuccess) return rc;
+    hipLaunchKernelGGL(oar_engine_census_kernel, dim3(n_groups * kEngGroup), dim3(kEngThreads), oar_engine_lds_bytes(), s, d_counts16);
+    return hipGetLastError();
+}
+
+hipError_t launch_oar_engine(hipStream_t s, const OarEngineArgs& a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(oar_engine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)oar_engine_lds_bytes());
+        if (rc != hipSuccess) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(oar_engine_kernel, dim3(a.NG * kEngGroup), dim3(kEngThreads), oar_engine_lds_bytes(), s, a);
+    return hipGetLastError();
+}
+
+}  // namespace umgen

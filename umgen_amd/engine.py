@@ -178,6 +178,14 @@ class Engine:
                                          "sampled_ne_forced"), counters[:6].tolist()))
         return outs, tbuf
 
+    def dbg_oar_step(self, x: np.ndarray, L: int, use_engine: bool, unmasked: bool = True) -> np.ndarray:
+        """Test hook: one decode step through the BlockOAR layers for x [B, n_embd] at KV length L (appends K/V row L)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        self._check(self.lib.umgen_dbg_oar_step(self._h, x.shape[0], L, fp(x), fp(out), int(use_engine), int(unmasked)), "dbg_oar_step")
+        return out
+
     # -- measurement ---------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self._check(self.lib.umgen_set_profiling(self._h, int(on)), "set_profiling")
