@@ -22,9 +22,18 @@ How it is pinned
 
 Modes
   * ``weight_dtype="fp32"`` : the reference's CPU fp32 semantics (what the import produces).
-  * ``weight_dtype="bf16"`` : identical math with every >=2-D weight rounded to bf16 first -- the comparison
-    target for the engine's bf16 mode (which additionally rounds GEMM/attention operands; tolerance is
-    stated in the tests).
+  * ``weight_dtype="bf16"`` : identical math with every >=2-D weight rounded to bf16 first.
+  * ``weight_dtype="bf16_engine"`` : the rounding-aware restatement of the engine's production (bf16) mode: bf16
+    weights AND a round-to-bf16 at every point where libumgen_hip stores or feeds a bf16 value --
+      TAR / ego-TAR sub-blocks (gemm.hip / attn.hip): the LayerNorm output that becomes the GEMM A operand, the q | k | v rows,
+      the softmax probabilities that feed the P.V MFMA of the SPATIAL attention (the row sum keeps the unrounded fp32
+      values), the attention output, the GELU output; accumulation and the residual stream stay fp32;
+      ego decoder (engine.hip run_ego): ln_3(p) and the cross-attention k | v rows;
+      OAR decode (gemv.hip / oar_engine.hip): only the K/V cache rows (incl. the new token's); activations stay fp32.
+    Everything else (embeddings, LayerNorm statistics, softmax, heads, samplers) is fp32 like the reference (module.py:34-37
+    keeps LayerNorm in fp32 inside the autocast region of UMGen.py:1604-1605).  What this mode cannot reproduce is the ORDER
+    of fp32 accumulation inside the MFMA tiles and the online-softmax rescaling, so the comparison is a tolerance, stated in
+    the tests, not bit equality.  The fp32 mode is untouched by it (pinned by tests/test_oracle.py on the reference goldens).
 """
 from __future__ import annotations
 
@@ -42,7 +51,7 @@ MASK64 = (1 << 64) - 1
 
 # --------------------------------------------------------------------------------------------------
 # build-owned counter-based RNG (replaces torch.multinomial's stream; mirrored bit-for-bit in
-# umgen_amd/csrc/sampler.hip: umgen_rng_u24)
+# umgen_amd/csrc/common.h: rng_u24)
 # --------------------------------------------------------------------------------------------------
 DRAW_MAIN, DRAW_PAD_AVOID, DRAW_CONTROL = 0, 1, 2
 EGO_POS_BASE = SEQ_LEN  # ego-net draws use positions SEQ_LEN + {0,1,2}
@@ -61,6 +70,26 @@ def rng_u24(seed: int, frame: int, pos: int, draw: int) -> int:
 
 def rng_uniform(seed: int, frame: int, pos: int, draw: int) -> np.float32:
     return np.float32(rng_u24(seed, frame, pos, draw)) * np.float32(2.0 ** -24)
+
+
+_EXP_C = [np.float32(v) for v in (1.0, 0.693147180559945, 0.240226506959101, 0.0555041086648216, 0.00961812910762848,
+                                  0.00133335581464284, 1.54035303933816e-4, 1.52527338040598e-5, 1.32154867901443e-6,
+                                  1.01780860092397e-7)]
+
+
+def exp_det(x: np.ndarray) -> np.ndarray:
+    """exp(x), x <= 0, bit-identical to the device's exp_det (umgen_amd/csrc/common.h): 2^n * P(f) with separately rounded
+    fp32 multiplies and adds.  The samplers' softmax uses it on both sides so that the inverse-CDF walk sees the same bits."""
+    x = np.asarray(x, dtype=np.float32)
+    ok = x > np.float32(-87.0)
+    xs = np.where(ok, x, np.float32(0.0)).astype(np.float32)
+    t = xs * np.float32(1.44269504088896341)
+    n = np.floor(t)
+    f = (t - n).astype(np.float32)
+    p = np.full_like(f, _EXP_C[9])
+    for k in range(8, -1, -1):
+        p = (p * f).astype(np.float32) + _EXP_C[k]
+    return np.where(ok, np.ldexp(p, n.astype(np.int32)), np.float32(0.0)).astype(np.float32)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -181,8 +210,13 @@ def check_collision(decoded: List[np.ndarray]) -> bool:
 # --------------------------------------------------------------------------------------------------
 # the model
 # --------------------------------------------------------------------------------------------------
-def _attention(q, k, v, n_head: int, causal: bool) -> torch.Tensor:
-    """flash_attn_func as called at module.py:218-225 / 497-504 (third-party; semantics fixed in the header)."""
+def _bf16(x: torch.Tensor) -> torch.Tensor:
+    return x.bfloat16().float()
+
+
+def _attention(q, k, v, n_head: int, causal: bool, round_p: bool = False) -> torch.Tensor:
+    """flash_attn_func as called at module.py:218-225 / 497-504 (third-party; semantics fixed in the header).
+    round_p: the engine's spatial attention feeds bf16 probabilities to the P.V MFMA and divides by the fp32 row sum."""
     B, Tq, C = q.shape
     Tk = k.shape[1]
     D = C // n_head
@@ -195,6 +229,9 @@ def _attention(q, k, v, n_head: int, causal: bool) -> torch.Tensor:
         i = torch.arange(Tq).view(-1, 1)
         j = torch.arange(Tk).view(1, -1)
         att = att.masked_fill(j > i + (Tk - Tq), float("-inf"))
+    if round_p:
+        e = torch.exp(att - att.amax(dim=-1, keepdim=True))
+        return ((_bf16(e) @ vh) / e.sum(dim=-1, keepdim=True)).permute(0, 2, 1, 3).reshape(B, Tq, C)
     att = torch.softmax(att, dim=-1)
     return (att @ vh).permute(0, 2, 1, 3).reshape(B, Tq, C)
 
@@ -207,9 +244,10 @@ class OracleUMGen:
             t = torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v
             if t.dtype != torch.bfloat16:
                 t = t.float()
-                if weight_dtype == "bf16" and t.dim() >= 2:
+                if weight_dtype in ("bf16", "bf16_engine") and t.dim() >= 2:
                     t = t.bfloat16().float()
             self.w[k] = t
+        self.engine_rounding = weight_dtype == "bf16_engine"
         E = cfg.n_embd
         # UMGen.py:137-153 (tables may be overridden by checkpoint entries, UMGen.py:257-261)
         self.fouier_pe = self.w.get("fouier_pe", position_encoding_init(1024, E)).bfloat16()
@@ -226,6 +264,10 @@ class OracleUMGen:
         self.counters[what] = self.counters.get(what, 0) + 1
 
     # ---- primitives (module.py) -------------------------------------------------------------
+    def _r(self, x):
+        """bf16 round trip at the engine's bf16 storage points (bf16_engine mode only)."""
+        return _bf16(x) if self.engine_rounding else x
+
     def _ln(self, x, key):  # module.py:26-37: weight only, eps 1e-5
         w = self.w[key + ".weight"]
         return F.layer_norm(x, w.shape, w, None, 1e-5)
@@ -233,36 +275,45 @@ class OracleUMGen:
     def _lin(self, x, key, bias=True):
         return F.linear(x, self.w[key + ".weight"], self.w.get(key + ".bias") if bias else None)
 
-    def _mlp(self, x, key):  # module.py:233-250 (exact erf GELU, no bias)
-        return self._lin(F.gelu(self._lin(x, key + ".c_fc", bias=False)), key + ".c_proj", bias=False)
+    def _mlp(self, x, key, tar=False):  # module.py:233-250 (exact erf GELU, no bias)
+        h = F.gelu(self._lin(x, key + ".c_fc", bias=False))
+        return self._lin(self._r(h) if tar else h, key + ".c_proj", bias=False)
 
-    def _self_attn(self, x, key, causal, kv=None):
-        """CausalFlashAttention.forward (module.py:201-230)."""
+    def _self_attn(self, x, key, causal, kv=None, site="plain"):
+        """CausalFlashAttention.forward (module.py:201-230).  site: where the engine rounds to bf16 (bf16_engine mode) --
+        "tar_spatial" / "tar_temporal": q | k | v and the output (+ the probabilities of the spatial form); "oar": the K/V rows."""
         E = self.cfg.n_embd
         q, k, v = self._lin(x, key + ".c_attn").split(E, dim=2)
+        if site in ("tar_spatial", "tar_temporal"):
+            q, k, v = self._r(q), self._r(k), self._r(v)
+        elif site == "oar":
+            k, v = self._r(k), self._r(v)
         if kv is not None and kv[0] is not None:
             k = torch.cat([kv[0], k], dim=1)
             v = torch.cat([kv[1], v], dim=1)
-        y = _attention(q, k, v, self.cfg.n_head, causal)
+        y = _attention(q, k, v, self.cfg.n_head, causal, round_p=self.engine_rounding and site == "tar_spatial")
+        if site in ("tar_spatial", "tar_temporal"):
+            y = self._r(y)
         return self._lin(y, key + ".c_proj"), (k, v)
 
     def _block_tar(self, x, key):
         """BlockTAR.forward_func (module.py:332-359); kvcache is always None at inference."""
         B, T, S, C = x.shape
         x = x.reshape(B * T, S, C)
-        x = x + self._self_attn(self._ln(x, key + ".ln_1"), key + ".spatial_attn_1", False)[0]
-        x = x + self._mlp(self._ln(x, key + ".ln_2"), key + ".mlp1")
+        r = self._r
+        x = x + self._self_attn(r(self._ln(x, key + ".ln_1")), key + ".spatial_attn_1", False, site="tar_spatial")[0]
+        x = x + self._mlp(r(self._ln(x, key + ".ln_2")), key + ".mlp1", tar=True)
         x = x.view(B, T, S, C).permute(0, 2, 1, 3).reshape(B * S, T, C)
-        x = x + self._self_attn(self._ln(x, key + ".ln_3"), key + ".temporal_attn", True)[0]
-        x = x + self._mlp(self._ln(x, key + ".ln_4"), key + ".mlp2")
+        x = x + self._self_attn(r(self._ln(x, key + ".ln_3")), key + ".temporal_attn", True, site="tar_temporal")[0]
+        x = x + self._mlp(r(self._ln(x, key + ".ln_4")), key + ".mlp2", tar=True)
         x = x.view(B, S, T, C).permute(0, 2, 1, 3).reshape(B * T, S, C)
-        x = x + self._self_attn(self._ln(x, key + ".ln_5"), key + ".spatial_attn_2", False)[0]
-        x = x + self._mlp(self._ln(x, key + ".ln_6"), key + ".mlp3")
+        x = x + self._self_attn(r(self._ln(x, key + ".ln_5")), key + ".spatial_attn_2", False, site="tar_spatial")[0]
+        x = x + self._mlp(r(self._ln(x, key + ".ln_6")), key + ".mlp3", tar=True)
         return x.view(B, T, S, C)
 
     def _block_oar(self, x, key, kv):
         """BlockOAR.forward_func (module.py:402-416) on x [B, s, C] with the cat-grown KV cache."""
-        a, kv = self._self_attn(self._ln(x, key + ".ln_1"), key + ".temporal_attn", True, kv)
+        a, kv = self._self_attn(self._ln(x, key + ".ln_1"), key + ".temporal_attn", True, kv, site="oar")
         x = x + a
         x = x + self._mlp(self._ln(x, key + ".ln_2"), key + ".mlp")
         return x, kv
@@ -270,10 +321,10 @@ class OracleUMGen:
     def _decoder(self, x, p, key):
         """Decoder.forward_func (module.py:662-683) + FlashCrossAttention.forward (module.py:482-509)."""
         x = x + self._self_attn(self._ln(x, key + ".ln_1"), key + ".self_attn", False)[0]
-        qn, pn = self._ln(x, key + ".ln_2"), self._ln(p, key + ".ln_3")
+        qn, pn = self._ln(x, key + ".ln_2"), self._r(self._ln(p, key + ".ln_3"))
         q = self._lin(qn, key + ".cross_attn.q_attn")
-        k = self._lin(pn, key + ".cross_attn.k_attn")
-        v = self._lin(pn, key + ".cross_attn.v_attn")
+        k = self._r(self._lin(pn, key + ".cross_attn.k_attn"))
+        v = self._r(self._lin(pn, key + ".cross_attn.v_attn"))
         y = _attention(q, k, v, self.cfg.n_head, False)
         x = x + self._lin(y, key + ".cross_attn.c_proj")
         return x + self._mlp(self._ln(x, key + ".ln_4"), key + ".mlp1")
@@ -381,10 +432,10 @@ class OracleUMGen:
             kth = np.partition(l, -kk)[-kk]
             idx = np.nonzero(l >= kth)[0]
             z = l[idx] / temp
-            e = np.exp(z - z.max()).astype(np.float32)
+            e = exp_det(z - z.max())
         else:
             z = l / temp
-            pr = np.exp(z - z.max()).astype(np.float32)
+            pr = exp_det(z - z.max())
             pr = pr / np.cumsum(pr, dtype=np.float32)[-1]      # sequential fp32 sum in index order (mirrored on the device)
             order = np.argsort(-pr, kind="stable")              # ties: ascending index
             ps = pr[order]

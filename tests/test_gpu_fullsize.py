@@ -1,11 +1,19 @@
-"""-m gpu: parity at the production width and at BASELINE.json's full size.
+"""-m gpu: parity at the production width and at BASELINE.json's full sizes (configs #2-#5).
 
-* full WIDTH (E=768, H=16, all vocabularies at their production size, S=2207) with one layer per stack: small enough
-  for the CPU oracle to finish in seconds, so logits are compared directly under teacher forcing;
-* full SIZE (UMGen_Large, 2.44 B parameters, 20 history frames): the oracle needs ~15 min per frame on CPU, so parity is
-  carried by size-independent properties of the path: scenes never interact (a B=2 batch == the two B=1 rollouts), a
-  hipGraph replay == eager launches, `umgen_frame` == the first frame of `umgen_rollout`, a frame teacher-forced with
-  its own output samples exactly that output again, the history is returned untouched and every token is in range.
+* full WIDTH (E=768, H=16, all vocabularies at their production size, S=2207) and the 2x width of config #5 (E=1536, H=32), one
+  layer per stack: the CPU oracle's teacher-forced outputs are committed as golden vectors (tests/golden/make_full_width_golden.py)
+  so that no GPU-box time is spent re-running it.  fp32 parity mode is held to the north-star's 1e-3 on logits; the production
+  bf16 mode is compared with the ROUNDING-AWARE oracle (weight_dtype="bf16_engine": a bf16 round trip wherever the engine stores
+  bf16).  What is left between the two are 1-ulp-bf16 flips at those storage points (a value that differs by fp32 summation
+  noise lands on the other side of a rounding boundary), measured at 1.7e-3 relative rms = one bf16 epsilon: the bars are
+  4e-3 relative rms and 1.5e-2 absolute on logits of magnitude ~2.5 (6e-2 / 8e-2 before), and EVERY arg-max flip must be a
+  near-tie of the oracle (top-2 gap below twice the absolute bar).
+* full SIZE (UMGen_Large, 2.44 B parameters): the oracle needs ~15 min per frame on CPU, so parity is carried by
+  size-independent properties of the path: scenes never interact (a batch of B scenes == the B one-scene rollouts, for the
+  decode engine's three schedules: 8 / 2 / 1 XCDs per scene), a hipGraph replay == eager launches, the decode engine == the
+  five-launch decode layer up to near-ties, `umgen_frame` == the first frame of `umgen_rollout`, a frame teacher-forced with
+  its own output samples exactly that output again, control pose tokens are copied verbatim, the history is returned untouched
+  and every token is in range.
 """
 import dataclasses
 import os
@@ -13,76 +21,130 @@ import os
 import numpy as np
 import pytest
 
-from oracle.umgen_oracle import OracleUMGen
-from umgen_amd.config import BBOX_PAD, CONTENT_LEN, MOD_ORDER, N_SLOTS, SLOT_LEN, large_config, tiny_config
+from tests.golden.make_full_width_golden import COND_ROWS, LOGIT_POS, SCENE_ID, WEIGHT_SEED, config as width_config
+from umgen_amd.config import BBOX_PAD, CONTENT_LEN, MOD_ORDER, N_SLOTS, SLOT_LEN, large_config
 from umgen_amd.engine import Engine
 from umgen_amd.synth import synthetic_control, synthetic_scene
 from umgen_amd.weights import synthetic_items, synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def full_width_cfg(**over):
-    return tiny_config(n_embd=768, n_head=16, **over)
+class env:
+    """Engine-creation switches are read from the environment at umgen_create."""
+
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
-@pytest.fixture(scope="module")
-def full_width():
-    # rule_constrain off: a blanked slot leaves stale K/V rows behind in the unforced run (UMGen.py:1116-1123), which a
-    # teacher-forced replay of the OUTPUT tokens cannot reproduce; the rule path has its own tests in test_gpu_parity.py
-    cfg = full_width_cfg(rule_constrain=False).greedy()
-    sd = synthetic_state_dict(cfg, seed=21)
-    scene = synthetic_scene(31, n_frames=2)
-    o = OracleUMGen(cfg, sd)
-    ref = o.inference(1, 3, scene, input_cond_frames=2, trace=True, seed=0)
-    return cfg, sd, scene, ref, o.trace
+def rel_rms(a, b):
+    return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b.astype(np.float64) ** 2).mean()))
 
 
-def test_full_width_fp32_teacher_forced_logits_vs_oracle(full_width):
-    """Production width and vocabularies, fp32 parity mode: every OAR logit row of the frame within the north-star's 1e-3
-    of the oracle under teacher forcing, and the engine samples the oracle's greedy tokens back."""
-    cfg, sd, scene, ref, otr = full_width
-    forced = {m: ref[m][0, 2] for m in MOD_ORDER}
-    e = Engine(cfg, precision="fp32", max_cond_frames=4)
-    e.load_state_dict(sd)
+def run_forced_frame(width, precision):
+    g = np.load(os.path.join(GOLD, f"{width}_{'fp32' if precision == 'fp32' else 'bf16_engine'}.npz"))
+    assert [int(x) for x in g["meta"]] == [WEIGHT_SEED, SCENE_ID]
+    cfg = width_config(width)
+    scene = synthetic_scene(SCENE_ID, n_frames=2)
+    forced = {m: g[f"tok_{m}"].astype(np.int64) for m in MOD_ORDER}
+    e = Engine(cfg, precision=precision, max_cond_frames=4)
+    e.load_state_dict(synthetic_state_dict(cfg, seed=WEIGHT_SEED))
     e.finalize()
     toks, tr = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, trace=True, forced=forced)
-    np.testing.assert_allclose(tr["cond"], otr["cond"][0], atol=5e-4, rtol=0)
-    np.testing.assert_allclose(tr["ego_logits"], otr["ego_logits"][0], atol=1e-3, rtol=0)
-    for m in ("map", "bbox3d", "image"):
-        np.testing.assert_allclose(tr[f"logits_{m}"], otr["logits"][0][m], atol=1e-3, rtol=0)
-    # greedy arg-max of near-tied logits may legitimately differ by summation order; everything else must be identical
-    assert tr["counters"]["sampled_ne_forced"] <= 2, tr["counters"]
     e.close()
+    return g, tr
 
 
-def test_full_width_bf16_teacher_forced_logits_vs_oracle(full_width):
-    """bf16 production mode at production width against the fp32 oracle on the same bf16-rounded weights (tolerances of
-    tests/test_gpu_parity.py::test_bf16_teacher_forced_logits_vs_oracle: bf16 operands in the TAR GEMMs / attention and a
-    bf16 KV cache)."""
-    cfg, sd, scene, _, _ = full_width
-    o = OracleUMGen(cfg, sd, weight_dtype="bf16")
-    ref = o.inference(1, 3, scene, input_cond_frames=2, trace=True, seed=0)
-    forced = {m: ref[m][0, 2] for m in MOD_ORDER}
-    e = Engine(cfg, precision="bf16", max_cond_frames=4)
+def check_argmax_flips(g, tr, near_tie):
+    """Every position where the engine's arg-max differs from the oracle's must be a near-tie of the oracle."""
+    report = {}
+    for m in ("map", "bbox3d", "image"):
+        am = tr[f"logits_{m}"].argmax(-1)
+        flips = np.nonzero(am != g[f"argmax_{m}"].astype(np.int64))[0]
+        worst = float(g[f"gap_{m}"][flips].max()) if len(flips) else 0.0
+        report[m] = (len(flips), int(flips[0]) if len(flips) else -1, worst)
+        assert worst < near_tie, f"{m}: arg-max flip at position {flips[np.argmax(g[f'gap_{m}'][flips])]} with oracle top-2 gap {worst}"
+    return report
+
+
+@pytest.mark.parametrize("width", ["full_width", "wide2x"])
+def test_fp32_teacher_forced_logits_vs_oracle_golden(width):
+    """fp32 parity mode at production width / at config #5's doubled width: conditioning rows, ego logits and OAR logit rows
+    within the north-star's 1e-3 of the oracle; arg-max flips only at oracle near-ties (< 2e-3)."""
+    g, tr = run_forced_frame(width, "fp32")
+    np.testing.assert_allclose(tr["cond"][COND_ROWS], g["cond_rows"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(tr["ego_logits"], g["ego_logits"], atol=1e-3, rtol=0)
+    for m, pos in LOGIT_POS.items():
+        np.testing.assert_allclose(tr[f"logits_{m}"][pos], g[f"logits_{m}"], atol=1e-3, rtol=0, err_msg=m)
+    rep = check_argmax_flips(g, tr, near_tie=2e-3)
+    assert sum(v[0] for v in rep.values()) <= 3, rep
+    assert tr["counters"]["sampled_ne_forced"] <= 3, tr["counters"]
+
+
+@pytest.mark.parametrize("width", ["full_width", "wide2x"])
+def test_bf16_teacher_forced_logits_vs_rounding_aware_oracle_golden(width):
+    """Production bf16 mode (full_width: the decode engine; wide2x: the five-launch decode layer) against the rounding-aware
+    oracle: 1.5e-2 absolute / 4e-3 relative rms on logits, every arg-max flip a near-tie."""
+    g, tr = run_forced_frame(width, "bf16")
+    np.testing.assert_allclose(tr["cond"][COND_ROWS], g["cond_rows"], atol=2.5e-2, rtol=0)
+    assert rel_rms(tr["cond"][COND_ROWS], g["cond_rows"]) < 4e-3
+    np.testing.assert_allclose(tr["ego_logits"], g["ego_logits"], atol=1e-2, rtol=0)
+    for m, pos in LOGIT_POS.items():
+        np.testing.assert_allclose(tr[f"logits_{m}"][pos], g[f"logits_{m}"], atol=1.5e-2, rtol=0, err_msg=m)
+        assert rel_rms(tr[f"logits_{m}"][pos], g[f"logits_{m}"]) < 4e-3, m
+    rep = check_argmax_flips(g, tr, near_tie=3e-2)
+    n_flip = sum(v[0] for v in rep.values())
+    print(f"{width} bf16: arg-max flips (count, first position, largest oracle gap) {rep}")
+    assert n_flip <= 0.015 * 2196, rep
+
+
+def test_wide2x_doubled_context_rollout_properties():
+    """BASELINE.json config #5 (2x width, doubled context): 39 history frames -> the window grows to 40 slots (the 64-slot temporal
+    attention form).  The oracle cannot run this in test time, so: two scenes in one batch == the two one-scene rollouts, the
+    graph-replayed path == plain eager launches, structure checks."""
+    cfg = dataclasses.replace(width_config("wide2x", max_frame_len=48), top_k=5, top_k_map=5, topk_image=16)
+    sd = synthetic_state_dict(cfg, seed=5)
+    scenes = [synthetic_scene(70 + i, n_frames=39) for i in range(2)]
+    e = Engine(cfg, precision="bf16", max_batch=2, max_cond_frames=40)
     e.load_state_dict(sd)
     e.finalize()
-    toks, tr = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, trace=True, forced=forced)
-    np.testing.assert_allclose(tr["cond"], o.trace["cond"][0], atol=6e-2, rtol=0)
-    for m in ("map", "bbox3d", "image"):
-        np.testing.assert_allclose(tr[f"logits_{m}"], o.trace["logits"][0][m], atol=8e-2, rtol=0)
-        agree = (tr[f"logits_{m}"].argmax(-1) == o.trace["logits"][0][m].argmax(-1)).mean()
-        assert agree > 0.95, (m, agree)
+    single = [e.rollout(scenes[i], 1, cond_frames=40, input_cond_frames=39, seeds=[11 + i]) for i in range(2)]
+    both_in = {m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}
+    both = e.rollout(both_in, 1, cond_frames=40, input_cond_frames=39, seeds=[11, 12])
     e.close()
+    check_structure(cfg, both_in, both, 39, 1)
+    for i in range(2):
+        for m in MOD_ORDER:
+            np.testing.assert_array_equal(both[m][i:i + 1], single[i][m], err_msg=f"scene {i} {m}")
+    with env(UMGEN_OVERLAP=0):
+        eager = Engine(cfg, precision="bf16", max_batch=1, max_cond_frames=40, use_graphs=False)
+    eager.load_state_dict(sd)
+    eager.finalize()
+    out = eager.rollout(scenes[0], 1, cond_frames=40, input_cond_frames=39, seeds=[11])
+    eager.close()
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(out[m], single[0][m], err_msg=m)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# UMGen_Large, configs[1] / configs[2] of BASELINE.json at full size
+# UMGen_Large: configs[1] / [2] / [3] of BASELINE.json at full size
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def large():
     cfg = large_config()
-    e = Engine(cfg, precision="bf16", max_batch=2, max_cond_frames=20)
+    e = Engine(cfg, precision="bf16", max_batch=8, max_cond_frames=20)
     e.load_state_dict(synthetic_items(cfg, seed=0))
     e.finalize()
     yield cfg, e
@@ -101,28 +163,52 @@ def check_structure(cfg, scene, out, t_in, new_frames):
     assert np.all(box[blank] == BBOX_PAD)
 
 
-def test_large_batch_of_two_equals_two_single_rollouts(large):
-    """configs[1] shape (video, 20 history frames) with the default k = 5/5/16 sampler: scenes are independent units, so the
-    B=2 batch must reproduce the two B=1 rollouts token for token (per-scene counter RNG; batch-invariant kernels)."""
+def cat(scenes):
+    return {m: np.concatenate([s[m] for s in scenes]) for m in scenes[0]}
+
+
+def test_large_config4_eight_scenes_per_gpu_equal_eight_single_rollouts(large):
+    """configs[3]'s per-GPU shape (video, 20 history frames, 8 scenes per GPU) with the default k = 5/5/16 sampler: scenes are
+    independent units, so the 8-scene batch (decode engine: one XCD per scene) must reproduce the 8 one-scene rollouts (8 XCDs
+    per scene) token for token -- per-scene counter RNG, batch- and schedule-invariant kernels.  Also: determinism and seed use."""
     cfg, e = large
-    scenes = [synthetic_scene(1000 + i, n_frames=20) for i in range(2)]
-    seeds = [7, 8]
-    single = [e.rollout(scenes[i], 2, cond_frames=20, seeds=[seeds[i]]) for i in range(2)]
-    # frame 2 of a one-scene rollout takes the overlapped path: history slots 0..18 went through the stacks beside frame 1's decode
-    assert e.timings()["overlapped_frames"] == 1
-    both_in = {m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}
+    scenes = [synthetic_scene(1000 + i, n_frames=20) for i in range(8)]
+    seeds = [7 + i for i in range(8)]
+    single = [e.rollout(scenes[i], 2, cond_frames=20, seeds=[seeds[i]]) for i in range(8)]
+    both_in = cat(scenes)
     both = e.rollout(both_in, 2, cond_frames=20, seeds=seeds)
     check_structure(cfg, both_in, both, 20, 2)
-    for i in range(2):
+    for i in range(8):
         for m in MOD_ORDER:
             np.testing.assert_array_equal(both[m][i:i + 1], single[i][m], err_msg=f"scene {i} {m}")
-    # determinism: the same call again gives the same tokens
+    two = e.rollout(cat(scenes[2:4]), 2, cond_frames=20, seeds=seeds[2:4])      # 4 XCDs per scene
+    for i in range(2):
+        for m in MOD_ORDER:
+            np.testing.assert_array_equal(two[m][i:i + 1], single[2 + i][m], err_msg=f"pair scene {i} {m}")
     again = e.rollout(scenes[0], 2, cond_frames=20, seeds=[seeds[0]])
     for m in MOD_ORDER:
         np.testing.assert_array_equal(again[m], single[0][m])
-    # and a different seed does not
-    other = e.rollout(scenes[0], 1, cond_frames=20, seeds=[seeds[0] + 1])
+    other = e.rollout(scenes[0], 1, cond_frames=20, seeds=[seeds[0] + 100])
     assert any(np.any(other[m][:, 20] != single[0][m][:, 20]) for m in ("map", "image"))
+
+
+def test_large_config3_control_four_scenes_equal_four_single_rollouts(large):
+    """configs[2]: --infer_task control, 13 history frames, batch 4, one controlled agent per scene.  The 4-scene batch equals
+    the four one-scene rollouts token for token, and the control pose tokens are copied verbatim into the output
+    (UMGen.py:1640-1651) while the controlled slot is sampled, not copied (UMGen.py:1083-1089)."""
+    cfg, e = large
+    scenes = [synthetic_scene(1100 + i, n_frames=13) for i in range(4)]
+    inits = [synthetic_control(1100 + i, n_frames=2, slot=3 + i) for i in range(4)]
+    seeds = [21 + i for i in range(4)]
+    kw = dict(cond_frames=20, input_cond_frames=13, control_test=True)
+    single = [e.rollout(scenes[i], 2, init_tokens=inits[i], seeds=[seeds[i]], **kw) for i in range(4)]
+    both_in = cat(scenes)
+    both = e.rollout(both_in, 2, init_tokens=cat(inits), seeds=seeds, **kw)
+    check_structure(cfg, both_in, both, 13, 2)
+    np.testing.assert_array_equal(both["pose"][:, 13:15], cat(inits)["pose"][:, :2])
+    for i in range(4):
+        for m in MOD_ORDER:
+            np.testing.assert_array_equal(both[m][i:i + 1], single[i][m], err_msg=f"scene {i} {m}")
 
 
 def test_large_frame_entry_point_and_self_forcing(large):
@@ -145,26 +231,29 @@ def test_large_frame_entry_point_and_self_forcing(large):
         np.testing.assert_array_equal(toks2[m], toks1[m], err_msg=m)
 
 
-def test_large_control_rollout_copies_control_pose_and_overlapped_graph_path_equals_plain_eager(large):
-    """configs[2] shape (control, 13 history frames, one controlled agent): control pose tokens are copied verbatim into the
-    output (UMGen.py:1640-1651); the production path (hipGraph replay of the decode step, next frame's history slots pushed
-    through the stacks on the background stream) gives the same tokens as the plain path (eager launches, one pass)."""
+def test_large_overlapped_launch_path_equals_plain_eager_and_the_engine_up_to_near_ties(large):
+    """The round-1 production path (five-launch decode layer replayed from a hipGraph + the next frame's history slots pushed
+    through the stacks on the CU-masked background stream, UMGEN_OVERLAP=1) gives exactly the tokens of the plain path (eager
+    launches, one pass, UMGEN_OVERLAP=0 / UMGEN_DECODE_ENGINE=0) in a control rollout with a growing window (13 -> 15 slots).
+    The decode engine has the same rounding points but another fp32 summation order in the attention: its rollout may only
+    differ from them after a near-tie, so the first frame's tokens agree to >= 99 %."""
     cfg, e = large
     scene = synthetic_scene(1005, n_frames=13)
     init = synthetic_control(1005, n_frames=2)
-    out = e.rollout(scene, 2, cond_frames=20, input_cond_frames=13, init_tokens=init, control_test=True, seeds=[9])
-    check_structure(cfg, scene, out, 13, 2)
-    np.testing.assert_array_equal(out["pose"][:, 13:15], init["pose"][:, :2])
-    assert e.timings()["overlapped_frames"] == 1       # growing window (13 -> 14 slots), pose given: ego prefix skipped
-    os.environ["UMGEN_OVERLAP"] = "0"                  # plain path: whole window in one foreground pass, eager launches
-    try:
-        eager = Engine(cfg, precision="bf16", max_batch=1, max_cond_frames=20, use_graphs=False)
-    finally:
-        del os.environ["UMGEN_OVERLAP"]
-    eager.load_state_dict(synthetic_items(cfg, seed=0))
-    eager.finalize()
-    out2 = eager.rollout(scene, 2, cond_frames=20, input_cond_frames=13, init_tokens=init, control_test=True, seeds=[9])
-    assert eager.timings()["overlapped_frames"] == 0
-    eager.close()
+    kw = dict(cond_frames=20, input_cond_frames=13, init_tokens=init, control_test=True, seeds=[9])
+    out_engine = e.rollout(scene, 2, **kw)
+    assert e.timings()["overlapped_frames"] == 0            # the engine owns every CU: no background pass
+    outs = []
+    for envs, graphs, want_overlapped in ((dict(UMGEN_OVERLAP=1), True, 1), (dict(UMGEN_OVERLAP=0, UMGEN_DECODE_ENGINE=0), False, 0)):
+        with env(**envs):
+            x = Engine(cfg, precision="bf16", max_batch=1, max_cond_frames=20, use_graphs=graphs)
+        x.load_state_dict(synthetic_items(cfg, seed=0))
+        x.finalize()
+        outs.append(x.rollout(scene, 2, **kw))
+        assert x.timings()["overlapped_frames"] == want_overlapped     # growing window (13 -> 14 slots), pose given: ego prefix skipped
+        x.close()
     for m in MOD_ORDER:
-        np.testing.assert_array_equal(out2[m], out[m], err_msg=m)
+        np.testing.assert_array_equal(outs[0][m], outs[1][m], err_msg=m)
+        np.testing.assert_array_equal(outs[0]["pose"][:, 13:15], init["pose"][:, :2])
+    agree = np.mean([np.mean(out_engine[m][:, 13] == outs[0][m][:, 13]) for m in ("map", "bbox3d", "image")])
+    assert agree >= 0.99, agree

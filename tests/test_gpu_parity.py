@@ -60,27 +60,54 @@ def test_fp32_first_frame_activations_match_reference_golden():
     e.close()
 
 
-def test_bf16_teacher_forced_logits_vs_oracle():
-    """bf16 production mode under teacher forcing against the fp32 oracle run on the same bf16-rounded weights.
-    The engine additionally rounds GEMM / attention operands of the TAR stacks and the KV cache to bf16, so the
-    tolerance is the bf16 one: 6e-2 absolute on logits of magnitude ~2.5 (measured ~1.5e-2), cond rows 4e-2."""
+def rel_rms(a, b):
+    return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b.astype(np.float64) ** 2).mean()))
+
+
+def test_bf16_teacher_forced_logits_vs_rounding_aware_oracle():
+    """bf16 production mode under teacher forcing against the ROUNDING-AWARE oracle (weight_dtype="bf16_engine": bf16 weights
+    and a bf16 round trip at every point where the engine stores bf16 -- LN outputs, q|k|v, spatial-attention probabilities,
+    attention / GELU outputs in the TAR stacks, the K/V cache; oracle/umgen_oracle.py header).  What remains are 1-ulp-bf16
+    flips at those storage points (fp32 summation noise pushing a value across a rounding boundary): measured 1.7e-3 relative
+    rms (one bf16 epsilon), 1.0e-2 / 6e-3 absolute on conditioning rows / logits of magnitude ~4 / ~2.5.  Bars: 4e-3 relative
+    rms, 2.5e-2 / 1.5e-2 absolute (6e-2 before), and EVERY arg-max flip must be a near-tie of the oracle (top-2 gap < 3e-2)."""
     g = np.load(os.path.join(GOLD, "tiny_video_greedy.npz"))
     ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
     cfg = tiny_config().greedy()
     sd = synthetic_state_dict(cfg, seed=ws)
     scene = synthetic_scene(sid, n_frames=icf)
     forced = {m: g[f"out_{m}"][0, icf].astype(np.int64) for m in MOD_ORDER}
-    o = OracleUMGen(cfg, sd, weight_dtype="bf16")
+    o = OracleUMGen(cfg, sd, weight_dtype="bf16_engine")
     o.inference(1, cf, scene, input_cond_frames=icf, trace=True, forced={m: forced[m][None] for m in MOD_ORDER})
     e = make_engine(cfg, ws, "bf16")
     toks, tr = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, trace=True, forced=forced)
-    np.testing.assert_allclose(tr["cond"], o.trace["cond"][0], atol=4e-2, rtol=0)
-    np.testing.assert_allclose(tr["ego_logits"], o.trace["ego_logits"][0], atol=6e-2, rtol=0)
+    np.testing.assert_allclose(tr["cond"], o.trace["cond"][0], atol=2.5e-2, rtol=0)
+    assert rel_rms(tr["cond"], o.trace["cond"][0]) < 4e-3
+    np.testing.assert_allclose(tr["ego_logits"], o.trace["ego_logits"][0], atol=1e-2, rtol=0)
+    n_flip = 0
     for m in ("map", "bbox3d", "image"):
-        np.testing.assert_allclose(tr[f"logits_{m}"], o.trace["logits"][0][m], atol=6e-2, rtol=0)
-        agree = (tr[f"logits_{m}"].argmax(-1) == o.trace["logits"][0][m].argmax(-1)).mean()
-        assert agree > 0.97, (m, agree)
+        ref = o.trace["logits"][0][m]
+        np.testing.assert_allclose(tr[f"logits_{m}"], ref, atol=1.5e-2, rtol=0)
+        assert rel_rms(tr[f"logits_{m}"], ref) < 4e-3, m
+        flips = np.nonzero(tr[f"logits_{m}"].argmax(-1) != ref.argmax(-1))[0]
+        srt = np.sort(ref[flips], axis=-1)
+        gaps = srt[:, -1] - srt[:, -2]
+        assert np.all(gaps < 3e-2), (m, flips[np.argmax(gaps)], gaps.max())     # every flip is a near-tie of the oracle
+        n_flip += len(flips)
+    assert n_flip <= 0.015 * 2196, n_flip
+    # free-running greedy rollout: token-exact up to the first near-tie; report where and how close it was
+    out = e.rollout(scene, 1, cond_frames=cf, input_cond_frames=icf, seeds=[0])
     e.close()
+    o2 = OracleUMGen(cfg, sd, weight_dtype="bf16_engine")
+    ref = o2.inference(1, cf, scene, input_cond_frames=icf, trace=True)
+    for m, off in (("map", 0), ("bbox3d", 1), ("image", 2)):
+        d = np.nonzero(out[m][0, icf] != ref[m][0, icf])[0]
+        if len(d):
+            lg = np.sort(o2.trace["logits"][0][m][d[0]])
+            print(f"bf16 greedy rollout: first divergence at {m}[{d[0]}], oracle top-2 gap {lg[-1] - lg[-2]:.2e}")
+            assert lg[-1] - lg[-2] < 3e-2, (m, d[0])
+            break
+        np.testing.assert_array_equal(out[m][0, icf], ref[m][0, icf])
 
 
 def test_fp32_sampled_rollout_matches_oracle_and_is_batch_invariant():
@@ -138,9 +165,10 @@ def test_dropin_model_class_through_registry_matches_golden():
 def test_fp32_top_p_frame_matches_oracle_under_teacher_forcing():
     """sample_method='topp' (UMGen.py:915-965; not the evaluate.py default): nucleus p=0.4 for pose/bbox3d/map and the
     whole distribution for image tokens (UMGen.py:1133).  With random-init weights the nucleus holds thousands of nearly
-    equiprobable codes, so a 1-ulp difference between numpy's and the device's expf can move a draw across a CDF boundary;
-    the comparison is therefore teacher-forced (no error propagation): >= 99 % of the 2199 device draws must equal the
-    oracle's, and the logits must agree to 1e-3."""
+    equiprobable codes, so a 1-ulp difference in exp() moves a draw across a CDF boundary: round 1 allowed 22 such mismatches
+    between numpy's and the device's expf.  Both sides now use the same bit-reproducible exp (common.h exp_det / the oracle's
+    exp_det: separately rounded fp32 Horner steps), so the remaining budget only covers arg-max-level logit noise: the
+    comparison is teacher-forced (no error propagation) and the logits must agree to 1e-3."""
     cfg = tiny_config()
     cfg.sample_method = "topp"
     cfg.rule_constrain = False      # no retro-active blanking: the emitted tokens ARE the sampled stream being forced
@@ -153,7 +181,9 @@ def test_fp32_top_p_frame_matches_oracle_under_teacher_forcing():
     toks, tr = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, seed=77, trace=True, forced=forced, sampling=cfg)
     for m in ("map", "bbox3d", "image"):
         np.testing.assert_allclose(tr[f"logits_{m}"], o.trace["logits"][0][m], atol=1e-3, rtol=0)
-    assert tr["counters"]["sampled_ne_forced"] <= 22, tr["counters"]
+    # the logits themselves still differ by fp32 summation order (<= 1e-3), which can move a CDF boundary across u: a handful
+    print("top-p sampled != forced:", tr["counters"]["sampled_ne_forced"])
+    assert tr["counters"]["sampled_ne_forced"] <= 8, tr["counters"]
     e.close()
 
 

@@ -124,4 +124,21 @@ __host__ __device__ inline float rng_uniform(uint64_t seed, int frame, int pos, 
 }
 enum { DRAW_MAIN = 0, DRAW_PAD_AVOID = 1, DRAW_CONTROL = 2 };
 
+// exp(x) for x <= 0 that is BIT-IDENTICAL on the device and in the numpy oracle (oracle/umgen_oracle.py: exp_det): the samplers'
+// softmax feeds an inverse-CDF walk, where a 1-ulp difference between two libm expf implementations can move a draw across a CDF
+// boundary.  2^n * P(f) with t = x log2(e), n = floor(t), f = t - n in [0, 1), P = degree-9 Taylor polynomial of 2^f evaluated by
+// Horner with SEPARATELY rounded fp32 multiplies and adds (no FMA contraction); the scaling by 2^n is exact.
+__device__ inline float exp_det(float x) {
+    if (!(x > -87.0f)) return 0.f;   // underflow, -inf and NaN
+    const float t = __fmul_rn(x, 1.44269504088896341f);
+    const float n = floorf(t);
+    const float f = __fsub_rn(t, n);
+    const float c[10] = {1.0f, 0.693147180559945f, 0.240226506959101f, 0.0555041086648216f, 0.00961812910762848f,
+                         0.00133335581464284f, 1.54035303933816e-4f, 1.52527338040598e-5f, 1.32154867901443e-6f, 1.01780860092397e-7f};
+    float p = c[9];
+#pragma unroll
+    for (int k = 8; k >= 0; --k) p = __fadd_rn(__fmul_rn(p, f), c[k]);
+    return ldexpf(p, (int)n);
+}
+
 }  // namespace umgen

@@ -292,7 +292,7 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
         const int si = lane < n ? sh.cand_i[lane] : 0;
         const float z = lane < n ? sh.cand_v[lane] / temp : -INFINITY;
         const float zmax = wave_max(z);
-        const float ev = lane < n ? expf(z - zmax) : 0.f;
+        const float ev = lane < n ? exp_det(__fsub_rn(z, zmax)) : 0.f;
         float total = 0.f;
         for (int a = 0; a < n; ++a) total = __fadd_rn(total, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev), a)));
         const float target = __fmul_rn(u, total);
@@ -337,7 +337,7 @@ __device__ int block_sample_topp(const float* __restrict__ logits, int V, float 
     if (lane == 0) sh.red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(sh.red[0], sh.red[1]), fmaxf(sh.red[2], sh.red[3]));
-    for (int i = tid; i < kTopPMax; i += 256) sh.pr[i] = expf(sh.pr[i] - mx);   // exp(-inf) = 0 for padding / masked
+    for (int i = tid; i < kTopPMax; i += 256) sh.pr[i] = exp_det(__fsub_rn(sh.pr[i], mx));   // exp(-inf) = 0 for padding / masked
     __syncthreads();
     if (tid == 0) {
         float t = 0.f;
