@@ -7,7 +7,8 @@
 A "step" is one generated frame of the video rollout for the rank's scene batch: ego net + 3 TAR stacks over the
 20-frame history window + the 2206-step OAR decode loop (one pass of the hot path, UMGen._inference).  The default
 K = 30 steps is BASELINE.json configs[1]: ``UMGen_Large --infer_task video --set_num_new_frames 30, batch=1, bf16``.
-Each rank rolls out its own independent scenes (weak scaling, no data-path collective); the sampled tokens are
+Scene i runs on rank i mod P (umgen_amd/shard.py: the same static partition + one all-gather the evaluate CLI and the tests
+use): every rank rolls out its own independent scenes (weak scaling, no data-path collective) and the sampled tokens are
 all-gathered once at the end (RCCL) inside the timed region.  Weights are random-init (PyTorch-default-like) of the
 UMGen_Large architecture and inputs are synthetic tokenized_origin_scenes-shaped tokens: no checkpoint/dataset offline.
 
@@ -32,27 +33,38 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak
 
 
-def pmc_traffic_per_step(cfg):
-    """HBM bytes per decode step from the committed rocprofv3 PMC pass (profiles/r01_pmc_fetch_size.csv: mean FETCH_SIZE [KB]
-    per launch of each kernel at KV length ~2000; x2 = the gfx950 correction of MI355X_MICROARCH.md for wide streaming reads).
-    PMC serialises every dispatch, so it cannot be collected inside the timed region; null when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.csv")
-    if not os.path.exists(path):
+def pmc_traffic_per_launch(engine_on: bool, cfg):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (mean FETCH_SIZE [KB] per launch at KV
+    length ~2000; x2 = the gfx950 correction of MI355X_MICROARCH.md for wide streaming reads).  PMC serialises every dispatch, so
+    it cannot be collected inside the timed region; null when the file is absent.
+      decode engine : profiles/r02_pmc_fetch_size_engine.csv   (oar_engine_kernel: one launch = all layers of a step)
+      five launches : profiles/r01_pmc_fetch_size.csv          (sum over the 5 x n_oar_layer launches of a step)"""
+    def rows(path):
+        out = {}
+        if not os.path.exists(path):
+            return None
+        for line in open(path).read().splitlines()[1:]:
+            name, _, rest = line.rpartition('",')
+            out[name.strip('"')] = float(rest.split(",")[2])
+        return out
+    if engine_on:
+        r = rows(os.path.join(ROOT, "profiles", "r02_pmc_fetch_size_engine.csv"))
+        if not r:
+            return None
+        for k, v in r.items():
+            if "oar_engine_kernel" in k:
+                return v * 2.0 * 1024.0
         return None
-    per_kernel = {}
-    for line in open(path).read().splitlines()[1:]:
-        name, _, rest = line.rpartition('",')
-        f = rest.split(",")
-        per_kernel[name.strip('"')] = float(f[2])
+    r = rows(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.csv"))
+    if not r:
+        return None
     def mean(sub):
-        for k, v in per_kernel.items():
+        for k, v in r.items():
             if sub in k:
                 return v
         return 0.0
-    L = cfg.n_oar_layer
-    kb = L * (2 * mean("gemv_ln_kernel<unsigned short, 1") + mean("attn_partial_kernel<unsigned short>") +
-              mean("gemv_resid_kernel<unsigned short, 1, 6, false>") + mean("gemv_resid_kernel<unsigned short, 1, 2, true>"))
-    kb += mean("gemv_ln_kernel<unsigned short, 1")      # head GEMV
+    kb = cfg.n_oar_layer * (2 * mean("gemv_ln_kernel<unsigned short, 1") + mean("attn_partial_kernel<unsigned short>") +
+                            mean("gemv_resid_kernel<unsigned short, 1, 6, false>") + mean("gemv_resid_kernel<unsigned short, 1, 2, true>"))
     return kb * 2.0 * 1024.0
 
 
@@ -86,7 +98,12 @@ def cpu_baseline(cfg_name: str, threads: int):
         t_oar = (time.perf_counter() - t0) / 16
     frame_s = (t_blk[2207] * (full.n_ego_tar_layer + full.n_tar_layer) + t_blk[1031] * full.n_map_tar_layer
                + t_blk[1693] * full.n_box_tar_layer + t_oar * full.n_oar_layer * 2206)
-    return {"value": SEQ_LEN / frame_s, "unit": "scene-tokens/s", "cores": threads, "kind": "port",
+    full = None
+    fp = os.path.join(ROOT, "profiles", "r02_cpu_baseline_full.json")
+    if os.path.exists(fp):      # tools/cpu_baseline_full.py: 2 whole frames, median of 3 (SURVEY.md section 8d protocol), run once per round
+        full = json.load(open(fp))
+    return {"value": SEQ_LEN / frame_s, "unit": "scene-tokens/s", "cores": threads, "kind": "port", "extrapolated_from_sample": True,
+            "full_frames_measurement": full,
             "sample": ("oracle/umgen_oracle.py (PyTorch-CPU fp32): 1 BlockTAR at S=1031/1693/2207 x T=20 "
                        f"({t_blk[1031]:.1f}/{t_blk[1693]:.1f}/{t_blk[2207]:.1f} s) + 16 BlockOAR steps at L=1100 "
                        f"({t_oar * 1e3:.2f} ms/step), scaled by UMGen_Large block/step counts -> {frame_s:.0f} s/frame")}
@@ -131,9 +148,16 @@ def main():
         eng.load_tensor(key, synth_tensor(key, shape, seed=0))
     eng.finalize()
     t_load = time.perf_counter() - t_load
-    scenes = [synthetic_scene(rank * B + i, n_frames=T) for i in range(B)]
-    tokens = {m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}
-    seeds = [1000 + rank * B + i for i in range(B)]
+    from umgen_amd.shard import scene_partition, scene_seed, sharded_rollout
+
+    n_scenes = B * world                     # scene i -> rank i mod P (shard.py): B scenes per rank, weak scaling
+    scenes = [synthetic_scene(i, n_frames=T) for i in range(n_scenes)]
+    mine = scene_partition(n_scenes, world, rank)
+    tokens = {m: np.concatenate([scenes[i][m] for i in mine]) for m in MOD_ORDER}
+    seeds = [scene_seed(1000, i) for i in mine]
+
+    def rollout_fn(toks, seeds, new_frames):
+        return eng.rollout(toks, new_frames, cond_frames=T, input_cond_frames=T, seeds=seeds)
 
     def sync():
         torch.cuda.synchronize()
@@ -142,14 +166,12 @@ def main():
             torch.cuda.synchronize()
 
     if args.warmup > 0:
-        eng.rollout(tokens, args.warmup, cond_frames=T, input_cond_frames=T, seeds=seeds)
+        rollout_fn(tokens, seeds, args.warmup)
     sync()
     t0 = time.perf_counter()
-    out = eng.rollout(tokens, args.steps, cond_frames=T, input_cond_frames=T, seeds=seeds)
-    if world > 1:   # the one exchange of the path: all-gather the sampled tokens (north_star)
-        flat = torch.from_numpy(np.concatenate([out[m][:, T:].reshape(B, -1) for m in MOD_ORDER], axis=1).astype(np.int32)).cuda()
-        gathered = [torch.empty_like(flat) for _ in range(world)]
-        dist.all_gather(gathered, flat)
+    # the timed region: every rank's rollouts + the one exchange of the path (all-gather of the sampled tokens, north_star)
+    out = sharded_rollout(rollout_fn, scenes, base_seed=1000, batch=B, device="cuda" if world > 1 else "cpu", new_frames=args.steps)
+    assert out["map"].shape[0] == n_scenes
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -165,7 +187,7 @@ def main():
         eng.rollout(tokens, 1, cond_frames=T, input_cond_frames=T, seeds=seeds)
         tp = eng.timings()
         eng.set_profiling(False)
-        for k in ("gemm_ms", "gemm_flops", "gemm_launches", "attn_ms", "attn_flops", "attn_launches"):
+        for k in ("gemm_ms", "gemm_flops", "gemm_launches", "attn_ms", "attn_flops", "attn_launches", "layers_ms", "layers_launches"):
             tm[k] = tp[k]
         total_scenes = B * world
         value = total_scenes * args.steps * SEQ_LEN / dt
@@ -174,8 +196,19 @@ def main():
         attn_tfs = (tm["attn_flops"] / (tm["attn_ms"] * 1e-3) / 1e12) if tm["attn_ms"] > 0 else 0.0
         steps_total = max(1, tm["oar_steps"])
         step_us = tm["oar_ms"] * 1e3 / steps_total
-        bytes_per_step = tm["oar_bytes"] / steps_total / B        # algorithmic: weights once + KV read/write
+        engine_on = bool(tm["decode_engine"])
+        # dominant kernel: the decode step's layer kernel(s).  Algorithmic bytes per step = the OAR weights once + the KV rows of
+        # every scene (the head / sampler launches of the step are not part of this kernel).  Its duration is
+        # measured per launch with HIP events on the decode stream in the extra profiled frame (eager launches, nothing else runs).
+        wsz = 2 if args.precision == "bf16" else 4
+        head_bytes = (cfg.map_vocab_size * 1024 + 2 * cfg.bbox3d_vocab_size * 660 + cfg.img_vocab_size * 512) * cfg.n_embd * wsz / 2206.0   # per step, frame average
+        bytes_per_step = tm["oar_bytes"] / steps_total        # whole batch
+        layer_bytes = bytes_per_step - head_bytes
+        layers_us = tp["layers_ms"] * 1e3 / max(1, tp["layers_launches"])
+        ach = layer_bytes / (layers_us * 1e-6) / 1e9 if layers_us > 0 else 0.0
         oar_gbs = (tm["oar_bytes"] / (tm["oar_ms"] * 1e-3) / 1e9) if tm["oar_ms"] > 0 else 0.0
+        kname = ("umgen::oar_engine_kernel (XCD-resident decode engine: the 36 BlockOAR layers of a decode step in one launch)" if engine_on else
+                 "OAR decode layers as launches (gemv_ln_kernel x72, attn_partial_kernel x36, gemv_resid_kernel x72 per step)")
         res = {
             "metric": "scene_tokens_per_sec", "value": value, "unit": "scene-tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
@@ -184,25 +217,21 @@ def main():
             "config": {"workload": f"UMGen_{args.config} --infer_task video, {args.steps}-frame rollout, "
                                    f"{B} scene(s)/GPU, T={T} history frames, top-k 5/5/16 sampling, rule_constrain",
                        "scenes_per_gpu": B, "history_frames": T, "sec_per_frame": dt / args.steps},
-            # dominant unit of work (~80 % of the frame): the OAR decode step = 36 x (gemv_ln, attn_partial, gemv_resid,
-            # gemv_ln, gemv_resid) + head + sampler, replayed from a hipGraph; HIP events bracket the decode phase of every frame
-            "roofline": {"bound": "hbm", "achieved": oar_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": oar_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic_per_step(cfg),
-                         "kernel": "OAR decode step (gemv_ln_kernel x73, attn_partial_kernel x36, gemv_resid_kernel x72, sample_token_kernel)",
-                         "launches": tm["oar_kernels"], "avg_launch_us": tm["oar_ms"] * 1e3 / max(1, tm["oar_kernels"]),
-                         "avg_step_us": step_us, "algorithmic_bytes_per_step": bytes_per_step,
-                         # the timed region runs the next frame's history slots beside the decode loop (2 of the 8 XCDs); the
-                         # same loop alone on the chip, from the extra profiled frame:
-                         "achieved_alone": tp["oar_bytes"] / (tp["oar_ms"] * 1e-3) / 1e9 if tp["oar_ms"] > 0 else None,
-                         "avg_step_us_alone": tp["oar_ms"] * 1e3 / max(1, tp["oar_steps"])},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_per_launch(engine_on, cfg), "kernel": kname,
+                         "avg_launch_us": layers_us, "launches_timed": tp["layers_launches"],
+                         "algorithmic_bytes_per_launch": layer_bytes, "scenes_per_launch": B,
+                         # the whole decode step (layer kernel + head GEMV + sampler, replayed from a hipGraph), timed region:
+                         "step": {"avg_step_us": step_us, "algorithmic_bytes_per_step": bytes_per_step, "achieved": oar_gbs,
+                                  "frac": oar_gbs / HBM_PEAK_GBS, "kernels_per_step": tm["oar_kernels"] / steps_total}},
             "roofline_gemm": {"bound": "mfma", "achieved": gemm_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                              "frac": gemm_tfs / MFMA_BF16_PEAK_TFS, "kernel": "gemm_bf16_glds_kernel (TAR/ego stacks)",
+                              "frac": gemm_tfs / MFMA_BF16_PEAK_TFS, "kernel": "gemm_bf16_pers_kernel / gemm_bf16_glds_kernel (TAR / ego stacks)",
                               "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(1, tm["gemm_launches"])},
             "roofline_attn": {"bound": "mfma", "achieved": attn_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
                               "frac": attn_tfs / MFMA_BF16_PEAK_TFS, "kernel": "attn_spatial_mfma_kernel",
                               "launches": tm["attn_launches"], "avg_launch_ms": tm["attn_ms"] / max(1, tm["attn_launches"])},
-            # foreground stream per frame; "background" = the next frame's history slots pushed through the stacks on the
-            # CU-masked second stream while the decode loop runs
+            # foreground stream per frame; "background" = the next frame's history slots pushed through the stacks on the CU-masked
+            # second stream while the decode loop runs (only with UMGEN_OVERLAP=1, i.e. without the engine)
             "phases_ms_per_frame": {"ego": tm["ego_ms"] / frames, "tar": tm["tar_ms"] / frames, "oar": tm["oar_ms"] / frames,
                                     "background_per_pass": tm["bg_ms"] / max(1, tm["overlapped_frames"]),
                                     "overlapped_frames": tm["overlapped_frames"]},
@@ -210,7 +239,8 @@ def main():
             "weight_load_s": t_load,
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.config, threads=min(32, os.cpu_count() or 1))   # 32 threads is the measured optimum on the 2x64-core host (more threads are slower)
+            # 32 threads is the measured optimum on the 2x64-core host (more threads are slower): "cores" = threads actually used
+            res["cpu_baseline"] = cpu_baseline(args.config, threads=min(32, os.cpu_count() or 1))
         print(json.dumps(res))
     eng.close()
     if world > 1:

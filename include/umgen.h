@@ -98,6 +98,11 @@ typedef struct umgen_timings {
     double attn_flops;
     double bg_ms;           // busy time of the background stream (next frame's history slots run beside the decode loop)
     int64_t overlapped_frames; /* frames whose TAR stacks only had to compute their last history slot */
+    double layers_ms;       /* sum over launches of the decode step's layer kernel(s): the decode engine's one launch per step, or the
+                             * 5 x n_oar_layer launches of the five-launch form (when profiling enabled; HIP events on the decode stream) */
+    int64_t layers_launches; /* decode steps timed that way */
+    int32_t decode_engine;  /* 1 when the last frame's decode steps ran on the XCD-resident decode engine */
+    int32_t reserved;
 } umgen_timings;
 
 /* UMGen(config)  -- UMGen.py:53 */
@@ -132,7 +137,8 @@ int umgen_frame(umgen_engine *e, int32_t T, const int64_t *pose, const int64_t *
                 const umgen_sampling *sampling, int32_t frame_idx, const umgen_trace *trace,
                 int64_t *out_pose, int64_t *out_map, int64_t *out_bbox3d, int64_t *out_image);
 
-int umgen_set_profiling(umgen_engine *e, int32_t enable); /* per-launch HIP-event timing of the GEMM kernel */
+int umgen_set_profiling(umgen_engine *e, int32_t enable); /* per-launch HIP-event timing of the GEMM / attention kernels and of the
+                                                            * decode step's layer kernel(s); profiled frames launch eagerly */
 int umgen_get_timings(umgen_engine *e, umgen_timings *out);
 
 const char *umgen_last_error(const umgen_engine *e); /* never NULL */

@@ -228,6 +228,29 @@ def test_edge_cases_single_history_frame_zero_new_frames_and_errors():
         e.rollout({m: np.concatenate([three[m], three[m]]) for m in MOD_ORDER}, 1, cond_frames=2, input_cond_frames=1)   # B = 6 > max_batch
     with pytest.raises(UMGenError):
         e.rollout(scene, 1, cond_frames=99, input_cond_frames=1)                                                       # window > max_cond_frames
+    # malformed scenes fail at the ABI boundary instead of indexing the embedding tables out of bounds
+    bad = {m: scene[m].copy() for m in MOD_ORDER}
+    bad["map"][0, 0, 17] = 8192
+    with pytest.raises(UMGenError, match="map token 8192"):
+        e.rollout(bad, 1, cond_frames=2, input_cond_frames=1)
+    bad = {m: scene[m].copy() for m in MOD_ORDER}
+    bad["bbox3d"][0, 0, 5] = -1
+    with pytest.raises(UMGenError, match="bbox3d token -1"):
+        e.rollout(bad, 1, cond_frames=2, input_cond_frames=1)
+    ctl = synthetic_control(30, n_frames=1)
+    with pytest.raises(UMGenError, match="without init_tokens"):
+        e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"bbox3d": ctl["bbox3d"]}, control_test=True)      # bbox3d-only control
+    with pytest.raises(UMGenError, match="not supported"):
+        e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"pose": ctl["pose"], "map": scene["map"]})
+    with pytest.raises(UMGenError, match="shape"):
+        e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"pose": ctl["pose"], "bbox3d": ctl["bbox3d"][:, :, :600]})
+    ctl_bad = {"pose": ctl["pose"].copy(), "bbox3d": ctl["bbox3d"].copy()}
+    ctl_bad["pose"][0, 0, 1] = 1024
+    with pytest.raises(UMGenError, match="control pose token 1024"):
+        e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens=ctl_bad, control_test=True)
+    out_again = e.rollout(scene, 2, cond_frames=2, input_cond_frames=1, seeds=[0])     # the engine is still usable after the failures
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(out_again[m], ref[m], err_msg=m)
     e2 = Engine(cfg, precision="fp32", max_batch=1, max_cond_frames=2)
     with pytest.raises(UMGenError):
         e2.finalize()                                                                                                   # weights missing

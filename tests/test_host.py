@@ -54,6 +54,29 @@ def test_config_from_reference_namespace_rejects_unsupported_switches():
     assert c.head_dim == 48 and c.top_k_map == 5 and c.topk_image == 16
     with pytest.raises(NotImplementedError):
         RolloutConfig.from_namespace(Namespace(**base, box_transform=True))
+    # switches that would silently change what the engine hard-codes are refused too (UMGen.py:99-172, infer_fun.py:84-139)
+    for bad in (dict(split_image_ar=True), dict(add_posi_embedd=False), dict(add_spatial_pos_embedd_on_map=False),
+                dict(seq_len=1693), dict(token_len={"pose": 5, "map": 1026, "bbox3d": 662}), dict(n_step=2), dict(no_born=True),
+                dict(bos_eos={"pose": [0, 1], "map": [2, 3], "bbox3d": [4, 5]})):
+        with pytest.raises(NotImplementedError):
+            RolloutConfig.from_namespace(Namespace(**base, **bad))
+    ok = RolloutConfig.from_namespace(Namespace(**base, seq_len=2207, token_len=dict(TOKEN_LEN), split_image_ar=False,
+                                                bos_eos={"pose": [0, 1], "map": [2, 3], "bbox3d": [4, 5], "image": [6, 7]}))
+    assert ok.n_oar_layer == 36
+
+
+def test_model_class_tracks_the_device_it_is_moved_to(monkeypatch):
+    """nn.Module surface used by the reference's harness (model_pl.py:366-368, 445-447): .to()/.cuda() select the engine's GPU
+    (default LOCAL_RANK), .cpu() leaves it alone; no engine is created before weights arrive."""
+    from umgen_amd.model import UMGen
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    m = UMGen(tiny_config())
+    assert m._engine_args["device"] == 3 and m._engine is None
+    assert m.to("cuda:5") is m and m._engine_args["device"] == 5
+    assert m.cuda() is m and m._engine_args["device"] == 3
+    assert m.cuda(2)._engine_args["device"] == 2
+    assert m.cpu()._engine_args["device"] == 2 and m.to(torch.float16)._engine_args["device"] == 2
+    assert m.to(device=torch.device("cuda", 1))._engine_args["device"] == 1 and m._engine is None
 
 
 def test_registry_build_from_cfg_with_class_object():

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -59,3 +60,64 @@ def test_two_rank_gloo_sharded_equals_unsharded():
     for m in MOD_ORDER:
         assert got[m].shape == (n, 5, CONTENT_LEN[m])
         np.testing.assert_array_equal(got[m], ref[m])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the same path with the REAL engine (-m gpu): two ranks share cuda:0, each owns its scenes, one all-gather at the end
+# ---------------------------------------------------------------------------------------------------------------------
+def _real_scenes(n):
+    from umgen_amd.synth import synthetic_scene
+    return [synthetic_scene(60 + i, n_frames=2) for i in range(n)]
+
+
+def _real_rollout(n, batch):
+    """umgen_amd.shard.sharded_rollout over Engine.rollout on this process's GPU (what bench.py / the evaluate CLI run per rank)."""
+    from umgen_amd.config import tiny_config
+    from umgen_amd.engine import Engine
+    from umgen_amd.weights import synthetic_state_dict
+
+    cfg = tiny_config()
+    e = Engine(cfg, precision="fp32", max_batch=batch, max_cond_frames=3, device=0)
+    e.load_state_dict(synthetic_state_dict(cfg, seed=4))
+    e.finalize()
+
+    def fn(toks, seeds, new_frames):
+        return e.rollout(toks, new_frames, cond_frames=3, input_cond_frames=2, seeds=seeds)
+
+    res = sharded_rollout(fn, _real_scenes(n), base_seed=500, batch=batch, new_frames=1)
+    e.close()
+    return res
+
+
+def _real_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # two ranks on ONE device: RCCL refuses that, gloo carries the gather
+    res = _real_rollout(n, batch=2)
+    if rank == 0:
+        q.put({m: res[m] for m in MOD_ORDER})
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_real_engine_equal_the_unsharded_rollout():
+    """sharded (P = 2, scene i -> rank i mod 2, per-rank batches of 2) == unsharded (P = 1, one scene at a
+    time), token for token, with the real HIP engine as rollout_fn.  Per-scene seeds are keyed by scene id, so the result does
+    not depend on P or on the batch composition."""
+    n = 5
+    ref = _real_rollout(n, batch=1)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_real_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for m in MOD_ORDER:
+        assert got[m].shape == (n, 3, CONTENT_LEN[m])
+        np.testing.assert_array_equal(got[m], ref[m], err_msg=m)

@@ -52,7 +52,8 @@ class Timings(C.Structure):
                 ("frames", C.c_int64), ("oar_steps", C.c_int64), ("oar_kernels", C.c_int64),
                 ("gemm_ms", C.c_double), ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("oar_bytes", C.c_double),
                 ("attn_ms", C.c_double), ("attn_launches", C.c_int64), ("attn_flops", C.c_double),
-                ("bg_ms", C.c_double), ("overlapped_frames", C.c_int64)]
+                ("bg_ms", C.c_double), ("overlapped_frames", C.c_int64),
+                ("layers_ms", C.c_double), ("layers_launches", C.c_int64), ("decode_engine", C.c_int32), ("reserved", C.c_int32)]
 
 
 def hipcc_path() -> str:
@@ -62,20 +63,38 @@ def hipcc_path() -> str:
     return p
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950: compiles every HIP source into umgen_amd/libumgen_hip.so (in-tree)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "frame.h")] + \
+def source_hash() -> str:
+    """sha256 over every source the library is built from (and the compile flags): the staleness check of build_library."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, x) for x in ("common.h", "kernels.h", "frame.h")] + \
         [os.path.join(os.path.dirname(HERE), "include", "umgen.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified file) instead of AGPRs -- the attention softmax
+# reads every S tile and rescales O in place, which otherwise costs ~150 v_accvgpr moves per key tile (423 -> 572 TFLOP/s)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950: compiles every HIP source into umgen_amd/libumgen_hip.so (in-tree).  The library is rebuilt
+    whenever the hash of its sources differs from the one recorded next to it (and compiled into umgen_version())."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    want = source_hash()
+    stamp = LIB_PATH + ".srchash"
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB_PATH
-    # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified file) instead of AGPRs -- the attention softmax
-    # reads every S tile and rescales O in place, which otherwise costs ~150 v_accvgpr moves per key tile (423 -> 572 TFLOP/s)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-o", LIB_PATH] + srcs
+    cmd = [hipcc_path()] + HIPCC_FLAGS + [f'-DUMGEN_SRC_HASH="{want}"', "-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
     return LIB_PATH
 
 

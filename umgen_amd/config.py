@@ -122,6 +122,24 @@ class RolloutConfig:
             unsupported.append("bias=True")
         if c.no_born:
             unsupported.append("no_born=True")
+        # switches whose non-default value changes what the engine hard-codes (UMGen.py:99-172): refuse them instead of
+        # silently producing other tokens
+        if g("split_image_ar", False):
+            unsupported.append("split_image_ar=True")
+        if not g("add_posi_embedd", True):
+            unsupported.append("add_posi_embedd=False")
+        if not g("add_spatial_pos_embedd_on_map", True):
+            unsupported.append("add_spatial_pos_embedd_on_map=False")
+        if g("pred_task", "pose_map_bbox3d_image") != "pose_map_bbox3d_image":
+            unsupported.append(f"pred_task={g('pred_task', None)!r}")
+        if g("seq_len", SEQ_LEN) != SEQ_LEN:
+            unsupported.append(f"seq_len={g('seq_len', None)} (the scene sequence is {SEQ_LEN} positions)")
+        tl = g("token_len", None)
+        if tl is not None and dict(tl) != TOKEN_LEN:
+            unsupported.append(f"token_len={dict(tl)}")
+        be = g("bos_eos", None)
+        if be is not None and {k: tuple(v) for k, v in dict(be).items()} != BOS_EOS:
+            unsupported.append("bos/eos ids differ from infer_fun.py:99-104")
         if unsupported:
             raise NotImplementedError(
                 "umgen_amd implements the UMGen_Large evaluation configuration only; unsupported: "

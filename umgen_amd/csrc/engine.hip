@@ -111,8 +111,8 @@ struct umgen_engine {
     // decode step graphs per (kind: fixed / map / bbox3d / image, number of attention key splits 1..8)
     hipGraphExec_t step_graph[4][kAttnSplit + 1] = {};
     int step_graph_B = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev, attn_ev;
-    size_t gemm_ev_used = 0, attn_ev_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev, attn_ev, layer_ev;
+    size_t gemm_ev_used = 0, attn_ev_used = 0, layer_ev_used = 0;
     // XCD-resident decode engine (oar_engine.hip): one launch per decode step instead of five per layer
     struct EngStream { bool ok = false; int NG = 0; unsigned char map[16]; };
     bool eng_enabled = false;
@@ -125,6 +125,7 @@ struct umgen_engine {
     int fg_xcds = 8;
     unsigned eng_epoch = 16u;             // first hand-off tag of the next frame (see run_frame)
     int step_graph_NG = -1;
+    bool in_capture = false;
     const EngStream* eng_for(hipStream_t s) const {
         if (!eng_enabled) return nullptr;
         const EngStream* es = (full_stream && s == full_stream) ? &eng_full : &eng_fg;
@@ -533,7 +534,18 @@ template <typename T>
 int enqueue_step(umgen_engine* e, int B, int mod, int ns, int ns_cached, const umgen_trace* tr, int j) {
     const int E = e->E;
     hipStream_t st = e->stream;
+    const bool time_layers = e->profiling && !e->in_capture;
+    if (time_layers) {
+        if (e->layer_ev_used == e->layer_ev.size()) {
+            hipEvent_t a0, a1;
+            hipEventCreate(&a0);
+            hipEventCreate(&a1);
+            e->layer_ev.emplace_back(a0, a1);
+        }
+        hipEventRecord(e->layer_ev[e->layer_ev_used].first, st);
+    }
     oar_layers<T>(e, B, ns, ns_cached);
+    if (time_layers) hipEventRecord(e->layer_ev[e->layer_ev_used++].second, st);
     static FILE* dump = getenv("UMGEN_DEBUG_DUMP_X") ? fopen(getenv("UMGEN_DEBUG_DUMP_X"), "wb") : nullptr;   // debugging only (eager launches)
     if (dump && tr == nullptr && !e->cfg.use_graphs) {
         std::vector<float> hx((size_t)E);
@@ -781,7 +793,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
             fprintf(stderr, "[umgen] host time to enqueue the background pass: %.1f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
     }
-    const bool graphs = e->cfg.use_graphs && !tr;
+    const bool graphs = e->cfg.use_graphs && !tr && !e->profiling;   // profiled frames time every decode step's layer kernel(s) with events
     const umgen_engine::EngStream* eng = sizeof(T) == 2 ? e->eng_for(st) : nullptr;
     const int eng_ng = eng ? eng->NG : 0;     // the engine's grid depends on the stream's XCDs: graphs are per (B, NG)
     if (graphs && (e->step_graph_B != B || e->step_graph_NG != eng_ng)) {
@@ -804,7 +816,9 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
             if (!ge) {
                 hipGraph_t g;
                 HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                e->in_capture = true;
                 enqueue_step<T>(e, B, mod, ns, ns_cached, nullptr, 0);
+                e->in_capture = false;
                 HIPCHK(e, hipStreamEndCapture(st, &g));
                 HIPCHK(e, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
                 HIPCHK(e, hipGraphDestroy(g));
@@ -838,6 +852,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     }
     hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->tm.total_ms += ms;
     e->tm.frames += 1;
+    e->tm.decode_engine = eng ? 1 : 0;
     if (use_px) e->tm.overlapped_frames += 1;
     if (e->profiling) {
         for (size_t i = 0; i < e->gemm_ev_used; ++i) {
@@ -852,6 +867,12 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
             hipEventElapsedTime(&ms, e->attn_ev[i].first, e->attn_ev[i].second);
             e->tm.attn_ms += ms;
         }
+        for (size_t i = 0; i < e->layer_ev_used; ++i) {
+            hipEventElapsedTime(&ms, e->layer_ev[i].first, e->layer_ev[i].second);
+            e->tm.layers_ms += ms;
+        }
+        e->tm.layers_launches += (int64_t)e->layer_ev_used;
+        e->layer_ev_used = 0;
         e->tm.attn_launches += (int64_t)e->attn_ev_used;
         e->tm.attn_flops += e->attn_flops_pending;
         e->attn_ev_used = 0;
@@ -874,7 +895,27 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
 }
 
 int run_frame_any(umgen_engine* e, const FrameIO& io) {
-    return e->cfg.precision == UMGEN_PREC_BF16 ? run_frame<bf16_t>(e, io) : run_frame<float>(e, io);
+    const int rc = e->cfg.precision == UMGEN_PREC_BF16 ? run_frame<bf16_t>(e, io) : run_frame<float>(e, io);
+    if (rc != UMGEN_OK) {
+        // A failed frame may have left a stream capture open, async copies in flight that read this call's host buffers, and a
+        // background pass the next call would wait for: drain everything and forget the pass (the error message is kept).
+        const std::string msg = e->err;
+        for (hipStream_t s : {e->stream, e->full_stream, e->bg_stream, e->side_stream[0], e->side_stream[1]}) {
+            if (!s) continue;
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+                hipGraph_t g = nullptr;
+                (void)hipStreamEndCapture(s, &g);
+                if (g) (void)hipGraphDestroy(g);
+            }
+        }
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        e->bg_pending = false;
+        e->px.valid = false;
+        e->err = msg;
+    }
+    return rc;
 }
 
 template <typename T>
@@ -910,7 +951,10 @@ int build_tables(umgen_engine* e) {
 // =============================================================================================================
 extern "C" {
 
-const char* umgen_version(void) { return "umgen_hip 0.1 (gfx950)"; }
+#ifndef UMGEN_SRC_HASH
+#define UMGEN_SRC_HASH "unknown"
+#endif
+const char* umgen_version(void) { return "umgen_hip 0.2 (gfx950) src " UMGEN_SRC_HASH; }
 const char* umgen_last_error(const umgen_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
 int umgen_create(const umgen_config* cfg, umgen_engine** out) {
@@ -1301,6 +1345,27 @@ static int check_sampling(umgen_engine* e, const umgen_sampling* s) {
     return 0;
 }
 
+// Every token that becomes a gather index is checked at the ABI boundary (history: embed_stack_kernel's table rows; control
+// pose: the fouier_pe rows and decode_pose_value; control bbox3d: -1 = "free", anything else a be / posi row).
+static int check_tokens(umgen_engine* e, const char* what, const int64_t* p, size_t n, int64_t vocab, bool allow_free) {
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t v = p[i];
+        if (v >= 0 && v < vocab) continue;
+        if (allow_free && v == -1) continue;
+        return e->fail(UMGEN_E_INVALID, "%s token %lld at flat index %zu is outside [0, %lld)%s", what, (long long)v, i, (long long)vocab,
+                       allow_free ? " (and is not -1 = free)" : "");
+    }
+    return 0;
+}
+static int check_scene_tokens(umgen_engine* e, size_t frames, const int64_t* pose, const int64_t* map, const int64_t* bbox3d, const int64_t* image) {
+    if (int rc = check_tokens(e, "pose", pose, frames * kNPose, e->cfg.pose_vocab, false)) return rc;
+    if (int rc = check_tokens(e, "map", map, frames * kNMap, e->cfg.map_vocab, false)) return rc;
+    if (int rc = check_tokens(e, "bbox3d", bbox3d, frames * kNBox, e->cfg.bbox3d_vocab, false)) return rc;
+    if (int rc = check_tokens(e, "image", image, frames * kNImg, e->cfg.img_vocab, false)) return rc;
+    // the x / y attribute tokens of a slot index the 1030-row spatial table; attribute tokens are bins (< 1024) or pad
+    return 0;
+}
+
 int umgen_frame(umgen_engine* e, int32_t T, const int64_t* pose, const int64_t* map, const int64_t* bbox3d, const int64_t* image,
                 const int64_t* ctrl_pose, const int64_t* ctrl_bbox3d, int32_t control_test, const umgen_sampling* sampling,
                 int32_t frame_idx, const umgen_trace* trace, int64_t* out_pose, int64_t* out_map, int64_t* out_bbox3d, int64_t* out_image) {
@@ -1308,6 +1373,11 @@ int umgen_frame(umgen_engine* e, int32_t T, const int64_t* pose, const int64_t* 
     if (!e->finalized) return e->fail(UMGEN_E_STATE, "umgen_finalize_weights has not been called");
     if (T < 1 || T > e->cfg.max_cond_frames) return e->fail(UMGEN_E_INVALID, "T=%d out of range [1,%d]", T, e->cfg.max_cond_frames);
     if (int rc = check_sampling(e, sampling)) return rc;
+    if (!pose || !map || !bbox3d || !image || !out_pose || !out_map || !out_bbox3d || !out_image) return e->fail(UMGEN_E_INVALID, "null token buffer");
+    if (int rc = check_scene_tokens(e, (size_t)T, pose, map, bbox3d, image)) return rc;
+    if (ctrl_pose) { if (int rc = check_tokens(e, "control pose", ctrl_pose, 3, e->cfg.pose_vocab, false)) return rc; }
+    if (ctrl_bbox3d) { if (int rc = check_tokens(e, "control bbox3d", ctrl_bbox3d, kNBox, e->cfg.bbox3d_vocab, true)) return rc; }
+    if (ctrl_bbox3d && !ctrl_pose) return e->fail(UMGEN_E_UNSUPPORTED, "control bbox3d tokens without control pose tokens: not a path the reference's callers take (model_pl.py:137-171 passes both)");
     std::vector<int> p((size_t)T * 3), m((size_t)T * kNMap), bx((size_t)T * kNBox), im((size_t)T * kNImg);
     for (size_t i = 0; i < p.size(); ++i) p[i] = (int)pose[i];
     for (size_t i = 0; i < m.size(); ++i) m[i] = (int)map[i];
@@ -1344,6 +1414,12 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
         return e->fail(UMGEN_E_INVALID, "T_in=%d new_frames=%d cond_frames=%d (max %d)", T_in, new_frames, cond_frames, e->cfg.max_cond_frames);
     if (int rc = check_sampling(e, sampling)) return rc;
     if (!pose || !map || !bbox3d || !image || !out_pose || !out_map || !out_bbox3d || !out_image) return e->fail(UMGEN_E_INVALID, "null token buffer");
+    if (int rc = check_scene_tokens(e, (size_t)B * T_in, pose, map, bbox3d, image)) return rc;
+    if ((ctrl_pose || ctrl_bbox3d) && T_ctl < 1) return e->fail(UMGEN_E_INVALID, "control tokens given with T_ctl=%d", T_ctl);
+    if (ctrl_pose) { if (int rc = check_tokens(e, "control pose", ctrl_pose, (size_t)B * T_ctl * 3, e->cfg.pose_vocab, false)) return rc; }
+    if (ctrl_bbox3d) { if (int rc = check_tokens(e, "control bbox3d", ctrl_bbox3d, (size_t)B * T_ctl * kNBox, e->cfg.bbox3d_vocab, true)) return rc; }
+    if (ctrl_bbox3d && !ctrl_pose)   // the reference's loop ends a control rollout on the pose tokens only (UMGen.py:1613-1619)
+        return e->fail(UMGEN_E_UNSUPPORTED, "control bbox3d tokens without control pose tokens: not a path the reference's callers take (model_pl.py:137-171 passes both)");
     e->tm = umgen_timings{};
     e->overlap_suspended = false;
     const int T_out = T_in + new_frames;
@@ -1453,7 +1529,8 @@ int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in,
 
 int umgen_destroy(umgen_engine* e) {
     if (!e) return UMGEN_OK;
-    if (e->stream) hipStreamSynchronize(e->stream);
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();   // every stream of this engine (decode, background, side, unmasked) is idle before anything is freed
     if (e->eng_stamps) {
         unsigned long long st[16];
         if (hipMemcpy(st, e->eng_stamps, 128, hipMemcpyDeviceToHost) == hipSuccess && st[10]) {
@@ -1471,6 +1548,7 @@ int umgen_destroy(umgen_engine* e) {
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : e->gemm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto& pr : e->attn_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : e->layer_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (e->tb.gmap) {}   // tables are in allocs
     if (e->bg_stream) { hipStreamSynchronize(e->bg_stream); hipStreamDestroy(e->bg_stream); }
     if (e->full_stream) hipStreamDestroy(e->full_stream);

@@ -8,6 +8,7 @@ fallback -- constructing the engine without a GPU / without libumgen_hip.so rais
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -22,13 +23,17 @@ from .weights import OPTIONAL_KEYS, expected_keys
 
 @MODELS.register_module()
 class UMGen(nn.Module):
-    def __init__(self, config, precision: str = "bf16", max_batch: int = 1, device: int = 0):
+    def __init__(self, config, precision: str = "bf16", max_batch: int = 1, device: Optional[int] = None):
         super().__init__()
         self.config = config
         self.rcfg = config if isinstance(config, RolloutConfig) else RolloutConfig.from_namespace(config)
         self.precision = precision
         self._engine: Optional[Engine] = None
-        self._engine_args = dict(precision=precision, max_batch=max_batch, device=device)
+        # one process per GPU: the harness (Lightning / torchrun) tells the rank its device through LOCAL_RANK and .to(device)
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self._engine_args = dict(precision=precision, max_batch=max_batch, device=int(device))
+        self._state: Optional[Dict[str, np.ndarray]] = None      # host copy of the weights: lets the engine move / grow
         self._loaded = False
         self.frame_idx = 0
         self.seed = 0
@@ -38,7 +43,21 @@ class UMGen(nn.Module):
     def engine(self) -> Engine:
         if self._engine is None:
             self._engine = Engine(self.rcfg, max_cond_frames=min(20, self.rcfg.max_frame_len), **self._engine_args)
+            if self._state is not None:      # re-created on another device / with a larger batch: reload the weights
+                for k, arr in self._state.items():
+                    self._engine.load_tensor(k, arr)
+                self._engine.finalize()
         return self._engine
+
+    def _recreate(self, **changes):
+        """The weights live in the engine's HBM: a new device or a larger scene batch means a new engine."""
+        new = dict(self._engine_args, **changes)
+        if new == self._engine_args:
+            return
+        self._engine_args = new
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
 
     def load_state_dict(self, state_dict, strict: bool = False):
         """infer_fun.load_model_paramter (infer_fun.py:43-50) calls this with ckpt["module"], strict=False."""
@@ -48,6 +67,7 @@ class UMGen(nn.Module):
         for k in want:
             if k not in state_dict:
                 missing.append(k)
+        kept: Dict[str, np.ndarray] = {}
         for k, v in state_dict.items():
             t = v.detach() if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
             if t.dtype == torch.bfloat16:
@@ -56,6 +76,9 @@ class UMGen(nn.Module):
                 arr = t.cpu().float().contiguous().numpy()
             if not eng.load_tensor(k, arr) and k not in OPTIONAL_KEYS:
                 unexpected.append(k)
+            elif k in want or k in OPTIONAL_KEYS:
+                kept[k] = arr
+        self._state = kept
         if strict and (missing or unexpected):
             raise RuntimeError(f"missing keys {missing[:5]}..., unexpected keys {unexpected[:5]}...")
         if not missing:
@@ -63,13 +86,36 @@ class UMGen(nn.Module):
             self._loaded = True
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
-    def to(self, *args, **kwargs):      # weights live in the engine's HBM; moving the module is a no-op
+    # The parameters live in the engine's HBM, not in nn.Parameters.  `.to(device)` / `.cuda(i)` (model_pl.py:366-368, Lightning's
+    # device placement) select the engine's GPU; `.cpu()` (model_pl.py:445-447, around the VAE decode) keeps it where it is.
+    @staticmethod
+    def _device_index(dev) -> Optional[int]:
+        if dev is None:
+            return None
+        if isinstance(dev, int):
+            return dev
+        d = torch.device(dev) if not isinstance(dev, torch.device) else dev
+        if d.type != "cuda":
+            return None
+        return d.index if d.index is not None else int(os.environ.get("LOCAL_RANK", "0"))
+
+    def to(self, *args, **kwargs):
+        dev = kwargs.get("device")
+        for a in args:
+            if isinstance(a, (str, torch.device, int)) and not isinstance(a, bool):
+                dev = a
+        idx = self._device_index(dev)
+        if idx is not None:
+            self._recreate(device=idx)
         return self
 
     def cpu(self):
         return self
 
     def cuda(self, device=None):
+        idx = self._device_index(device if device is not None else "cuda")
+        if idx is not None:
+            self._recreate(device=idx)
         return self
 
     # -- the hot path ----------------------------------------------------------------------------
@@ -89,8 +135,10 @@ class UMGen(nn.Module):
         init = None
         if init_tokens is not None:
             init = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
-                    for k, v in init_tokens.items() if v is not None and k in ("pose", "bbox3d")}
+                    for k, v in init_tokens.items() if v is not None}      # (the engine rejects anything but pose / bbox3d)
         B = toks["pose"].shape[0]
+        if B > self._engine_args["max_batch"]:      # extension over the reference (B = 1): several scenes per call
+            self._recreate(max_batch=B)
         seeds = kwargs.get("seeds", [self.seed + i for i in range(B)])
         return self.engine.rollout(toks, new_frames, cond_frames=cond_frames, input_cond_frames=input_cond_frames,
                                    init_tokens=init, control_test=bool(control_test), seeds=seeds)
