@@ -141,6 +141,16 @@ int umgen_set_profiling(umgen_engine *e, int32_t enable); /* per-launch HIP-even
                                                             * decode step's layer kernel(s); profiled frames launch eagerly */
 int umgen_get_timings(umgen_engine *e, umgen_timings *out);
 
+/* ---- scene formats either side of the rollout (host only, no engine needed) ------------------
+ * DigitalBinsTokenizer.encode/.decode (tokenizer.py:316-354) + Normalize_Standard (normalize.py:7-76) for the ego motion and
+ * Normalize min-max (normalize.py:79-137, 189-229) + the attribute / category tokens of BBox3DTokenizer (tokenizer.py:515-600)
+ * for agent boxes.  Arrays are caller-owned; return 0 or UMGEN_E_INVALID. */
+int umgen_tokenize_ego(const double *pose_diff /*[n][3] (dx, dy, dheading)*/, int64_t n, int64_t *tokens /*[n][3]*/);
+int umgen_detokenize_ego(const int64_t *tokens /*[n][3]*/, int64_t n, float *pose_diff /*[n][3]*/);   /* == UMGen.decode_pose */
+int umgen_tokenize_boxes(const float *boxes /*[n][stride], first 10 columns used*/, int64_t n, int32_t stride,
+                         const int32_t *category_index /*[n], 0..2*/, int64_t *tokens /*[n][11]*/);
+int umgen_detokenize_boxes(const int64_t *slot_tokens /*[n][11]*/, int64_t n, double *boxes /*[n][10]*/);
+
 const char *umgen_last_error(const umgen_engine *e); /* never NULL */
 const char *umgen_version(void);
 int umgen_destroy(umgen_engine *e);

@@ -130,3 +130,25 @@ def test_decoders_match_the_oracle_helpers_and_round_trip(gold):
     inner = (orig[:, :10] > 0) & (orig[:, :10] < 1023)
     np.testing.assert_array_equal(re[:, :10][inner], orig[:, :10][inner])
     np.testing.assert_array_equal(re[:, 10], orig[:, 10])
+
+
+def test_native_tokenizers_equal_the_numpy_statement_of_the_reference_arithmetic():
+    """f-1: umgen_tokenize_* / umgen_detokenize_* (csrc/tokenizers.hip) against the numpy restatement of DigitalBinsTokenizer /
+    Normalize / Normalize_Standard, on random values incl. exact bin edges, out-of-range values and every token id."""
+    rng = np.random.default_rng(0)
+    edges = np.linspace(-1.0, 1.0, 1024)
+    pd = np.concatenate([rng.normal(0, 6, (4000, 3)), (edges[:1023, None] * np.array([10.0, 4.0, 1.0]))[:1000],
+                         np.array([[1e9, -1e9, 0.0], [10.0, 4.0, 1.0], [-10.0, -4.0, -1.0]])])
+    np.testing.assert_array_equal(scene_io.encode_ego(pd), scene_io.encode_ego_numpy(pd))
+    toks = np.stack([np.arange(1024)] * 3, axis=1)
+    np.testing.assert_array_equal(scene_io.decode_ego(toks), scene_io.decode_ego_numpy(toks))
+    lo = np.array([r[0] for r in scene_io.BBOX_RANGE]); hi = np.array([r[1] for r in scene_io.BBOX_RANGE])
+    b = (rng.uniform(-0.1, 1.1, (5000, 12)) * np.concatenate([hi - lo, [1, 1]]) + np.concatenate([lo, [0, 0]])).astype(np.float32)
+    b[:1024, :10] = (np.linspace(0.0, 1.0, 1024)[:, None] * (hi - lo) + lo).astype(np.float32)          # exact edges
+    ci = rng.integers(0, 3, 5000)
+    np.testing.assert_array_equal(scene_io.box_tokens(b, ci), scene_io.box_tokens_numpy(b, ci))
+    frame = np.full((60, 11), BBOX_PAD, dtype=np.int64)
+    frame[:40, :10] = rng.integers(0, 1024, (40, 10)); frame[:40, 10] = rng.integers(1024, 1027, 40)
+    frame[:4, :10] = np.array([0, 1, 1022, 1023])[:, None]
+    got, want = scene_io.decode_boxes(frame.reshape(-1)), scene_io.decode_boxes_numpy(frame.reshape(-1))
+    np.testing.assert_array_equal(got[0], want[0]); assert got[1] == want[1]; np.testing.assert_array_equal(got[2], want[2])

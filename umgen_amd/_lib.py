@@ -14,9 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # UMGEN_LIB_PATH selects an alternative build of the SAME library (kernel experiments with extra -D flags); never a fallback
 LIB_PATH = os.environ.get("UMGEN_LIB_PATH") or os.path.join(HERE, "libumgen_hip.so")
-SOURCES = ["engine.hip", "gemm.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "rowops.hip", "frame.hip", "debug_api.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "debug_api.hip"]
 EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen_rollout", "umgen_frame",
            "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",
+           "umgen_tokenize_ego", "umgen_detokenize_ego", "umgen_tokenize_boxes", "umgen_detokenize_boxes",
            "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench", "umgen_dbg_oar_step"]
 
 PREC_FP32, PREC_BF16 = 0, 1
@@ -124,6 +125,11 @@ def load_library() -> C.CDLL:
     lib.umgen_last_error.restype = C.c_char_p
     lib.umgen_version.restype = C.c_char_p
     lib.umgen_destroy.argtypes = [vp]
+    f64p, f32p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    lib.umgen_tokenize_ego.argtypes = [f64p, C.c_int64, i64p]
+    lib.umgen_detokenize_ego.argtypes = [i64p, C.c_int64, f32p]
+    lib.umgen_tokenize_boxes.argtypes = [f32p, C.c_int64, i32, i32p, i64p]
+    lib.umgen_detokenize_boxes.argtypes = [i64p, C.c_int64, f64p]
     fp = C.POINTER(C.c_float)
     lib.umgen_dbg_linear.argtypes = [i32, vp, vp, fp, i32, i32, i32, i32, i32, vp]
     lib.umgen_dbg_attn_spatial.argtypes = [i32, vp, vp, i32, i32, i32, vp]

@@ -15,9 +15,11 @@ Mirrors, for the evaluation configuration only, what the reference does between 
 
 and the artefact on the output side (projects/tools/model_pl.py:350-355): ``<name>_tokens.pkl``.
 
-The arithmetic is numpy on the host, dtype for dtype what the reference's numpy does (float32 boxes, float64 ego motion, float64
-bin edges), so token ids are identical; `tests/test_scene_io.py` pins it on seeded synthetic scenes against vectors recorded
-from the reference's own dataset class (`tests/golden/make_scene_golden.py`).  Control scenes (`data/controlled_scenes`) are
+The (de)tokenisers and normalisers are native entry points of libumgen_hip.so (umgen_tokenize_ego / _boxes, umgen_detokenize_*;
+csrc/tokenizers.hip), dtype for dtype what the reference's numpy does (float32 boxes, float64 ego motion, float64 bin edges), so
+token ids are identical; the numpy statements of the same arithmetic below (`*_numpy`) are what the tests compare them with.
+Frame selection, ego motion and the track slotting are host Python.  `tests/test_scene_io.py` pins everything on seeded synthetic
+scenes against vectors recorded from the reference's own dataset class (`tests/golden/make_scene_golden.py`).  Control scenes (`data/controlled_scenes`) are
 already token dicts and are passed through (UMGen_nuplan_dataset.py:196-200).
 """
 from __future__ import annotations
@@ -28,6 +30,9 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
+import ctypes as C
+
+from . import _lib
 from .config import BBOX_PAD, BBOX_RANGE, EGO_STD, N_SLOTS, SLOT_LEN
 
 CATEGORIES = ("vehicle", "bicycle", "pedestrian")          # projects/configs/category.txt
@@ -69,14 +74,39 @@ def ego_motion(meta_info: Sequence[dict], ego_pose_all: np.ndarray, indices: Seq
     return np.asarray(out)
 
 
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _native(rc: int, what: str):
+    if rc != 0:
+        raise ValueError(f"{what}: libumgen_hip returned {rc}")
+
+
 def encode_ego(pose_diff: np.ndarray) -> np.ndarray:
-    """Normalize_Standard(mean 0, std [10, 4, 1]) then the 1024-bin tokenizer over [-1, 1]  ->  [T, 3] tokens."""
+    """Normalize_Standard(mean 0, std [10, 4, 1]) then the 1024-bin tokenizer over [-1, 1]  ->  [T, 3] tokens (native)."""
+    pd = np.ascontiguousarray(pose_diff, dtype=np.float64).reshape(-1, 3)
+    out = np.empty(pd.shape, dtype=np.int64)
+    _native(_lib.load_library().umgen_tokenize_ego(_ptr(pd, C.c_double), pd.shape[0], _ptr(out, C.c_int64)), "umgen_tokenize_ego")
+    return out.reshape(np.shape(pose_diff))
+
+
+def decode_ego(pose_tokens: np.ndarray) -> np.ndarray:
+    """Tokens [..., 3] -> (dx, dy, dheading) float32 -- what UMGen.decode_pose returns (native)."""
+    t = np.ascontiguousarray(pose_tokens, dtype=np.int64).reshape(-1, 3)
+    out = np.empty(t.shape, dtype=np.float32)
+    _native(_lib.load_library().umgen_detokenize_ego(_ptr(t, C.c_int64), t.shape[0], _ptr(out, C.c_float)), "umgen_detokenize_ego")
+    return out.reshape(np.shape(pose_tokens))
+
+
+def encode_ego_numpy(pose_diff: np.ndarray) -> np.ndarray:
+    """numpy statement of encode_ego (reference arithmetic; used by the tests)."""
     inv_std = 1.0 / np.array(EGO_STD, dtype=np.float32)           # float32 reciprocal, as normalize.py:26
     mean = np.array([0, 0, 0], dtype=np.float32)
     return encode_bins((pose_diff - mean) * inv_std, _EGO_BINS).astype(np.int64)
 
 
-def decode_ego(pose_tokens: np.ndarray) -> np.ndarray:
+def decode_ego_numpy(pose_tokens: np.ndarray) -> np.ndarray:
     """Tokens [..., 3] -> (dx, dy, dheading) float32: bin mid-points (DigitalBinsTokenizer.decode, tokenizer.py:332-354) divided by
     the float32 reciprocal std (Normalize_Standard.unnormalize_ego, normalize.py:65-76) -- what UMGen.decode_pose returns."""
     t = np.asarray(pose_tokens, dtype=np.int64)
@@ -86,6 +116,17 @@ def decode_ego(pose_tokens: np.ndarray) -> np.ndarray:
 
 
 def decode_boxes(bbox3d_tokens: np.ndarray):
+    """Frame tokens [660] -> (boxes float64 [n, 10], categories list[str], slot indices), native attribute decode."""
+    t = np.asarray(bbox3d_tokens, dtype=np.int64).reshape(N_SLOTS, SLOT_LEN)
+    keep = np.nonzero(~np.any(t == BBOX_PAD, axis=1))[0]
+    sl = np.ascontiguousarray(t[keep])
+    out = np.empty((sl.shape[0], 10), dtype=np.float64)
+    _native(_lib.load_library().umgen_detokenize_boxes(_ptr(sl, C.c_int64), sl.shape[0], _ptr(out, C.c_double)), "umgen_detokenize_boxes")
+    cats = [CATEGORIES[c - 1024] if 1024 <= c < 1024 + len(CATEGORIES) else "none" for c in t[keep, 10].tolist()]
+    return out, cats, keep
+
+
+def decode_boxes_numpy(bbox3d_tokens: np.ndarray):
     """Frame tokens [660] -> (boxes float64 [n, 10], categories list[str], slot indices): slots holding any pad token are dropped
     (BBox3DTokenizer.decode, tokenizer.py:689-806), attributes are bin mid-points mapped back through their min-max ranges
     (Normalize.unnormalize_bbox3d, normalize.py:189-229)."""
@@ -112,6 +153,23 @@ def filter_boxes(boxes: Sequence, cats: Sequence[Sequence[str]], track_ids: Sequ
     return fb, fc, ft
 
 
+def box_tokens(b: np.ndarray, cat_index: Sequence[int]) -> np.ndarray:
+    """Boxes [n, >=10] float32 + vocabulary indices -> [n, 11] tokens (min-max normalise, bin, category token): native."""
+    b = np.ascontiguousarray(np.atleast_2d(b), dtype=np.float32)
+    ci = np.ascontiguousarray(cat_index, dtype=np.int32)
+    out = np.empty((b.shape[0], SLOT_LEN), dtype=np.int64)
+    _native(_lib.load_library().umgen_tokenize_boxes(_ptr(b, C.c_float), b.shape[0], b.shape[1], _ptr(ci, C.c_int32), _ptr(out, C.c_int64)),
+            "umgen_tokenize_boxes")
+    return out
+
+
+def box_tokens_numpy(b: np.ndarray, cat_index: Sequence[int]) -> np.ndarray:
+    """numpy statement of box_tokens (Normalize.normalize_* + DigitalBinsTokenizer.encode per attribute; used by the tests)."""
+    b = np.atleast_2d(b)
+    cols = [encode_bins((b[:, a] - lo) / (hi - lo), _BOX_BINS) for a, (lo, hi) in enumerate(BBOX_RANGE)]
+    return np.concatenate([np.stack(cols, axis=-1), (np.asarray(cat_index) + 1024)[:, None]], axis=-1).astype(np.int64)
+
+
 def encode_boxes(boxes: Sequence[np.ndarray], cats: Sequence[Sequence[str]], track_ids: Sequence[np.ndarray],
                  vocab: Sequence[str] = CATEGORIES) -> np.ndarray:
     """Per-frame boxes [n_t, >=10] (float32), categories and track ids -> [T, 660] tokens: each of the first 10 attributes is
@@ -123,12 +181,7 @@ def encode_boxes(boxes: Sequence[np.ndarray], cats: Sequence[Sequence[str]], tra
         if len(c) == 0:
             per_frame.append(np.zeros((0, SLOT_LEN), dtype=np.int64))
             continue
-        cols = []
-        for a, (lo, hi) in enumerate(BBOX_RANGE):
-            col = b[:, a] if b.ndim == 2 else b[np.newaxis, :][:, a]
-            cols.append(encode_bins((col - lo) / (hi - lo), _BOX_BINS))
-        cat = np.array([vocab.index(x) for x in c]) + 1024
-        per_frame.append(np.concatenate([np.stack(cols, axis=-1), cat[:, None]], axis=-1).astype(np.int64))
+        per_frame.append(box_tokens(b, [vocab.index(x) for x in c]))
     # bbox_slotting (tokenizer.py:809-952): np.any() decides whether a frame "has" boxes, so a frame whose ids are all 0 counts
     # as empty -- kept as is
     ids = np.concatenate([np.asarray(t)[:] if np.any(t) else np.array([]) for t in track_ids]) if len(track_ids) else np.array([])
