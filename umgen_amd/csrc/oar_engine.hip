@@ -119,12 +119,21 @@ __device__ inline void unpack8(const u32x4_t& w, float (&o)[8]) {
     o[4] = __uint_as_float(w.z << 16); o[5] = __uint_as_float(w.z & 0xffff0000u);
     o[6] = __uint_as_float(w.w << 16); o[7] = __uint_as_float(w.w & 0xffff0000u);
 }
-__device__ inline float dot8(const u32x4_t& w, const float (&x)[8], float acc) {
-    float w8[8];
-    unpack8(w, w8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc = fmaf(w8[e], x[e], acc);
+// 8 bf16 weights x 8 fp32 activations on the packed fp32 FMA (v_pk_fma_f32: two MACs per instruction): the even / odd elements
+// accumulate in the two halves of acc
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ inline f32x2_t up2(u32 w) { return f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ inline f32x2_t dot8(const u32x4_t& w, const f32x2_t (&x)[4], f32x2_t acc) {
+    acc = __builtin_elementwise_fma(up2(w.x), x[0], acc);
+    acc = __builtin_elementwise_fma(up2(w.y), x[1], acc);
+    acc = __builtin_elementwise_fma(up2(w.z), x[2], acc);
+    acc = __builtin_elementwise_fma(up2(w.w), x[3], acc);
     return acc;
+}
+__device__ inline void load8p(const float* p, f32x2_t (&o)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = f32x2_t{a.x, a.y}; o[1] = f32x2_t{a.z, a.w}; o[2] = f32x2_t{b.x, b.y}; o[3] = f32x2_t{b.z, b.w};
 }
 
 // R rows of a [N][768] matrix held by one wave: chunk a[r] = k 8l..8l+7 of row r; the 256 tail columns of rows (2j, 2j+1) are
@@ -145,44 +154,45 @@ __device__ inline void req768(Rows768<R>& w, const bf16_t* W, int row0, int lane
     }
 }
 template <int R>
-__device__ inline void dot768(const Rows768<R>& w, const float (&x1)[8], const float (&x2)[8], int lane, float (&out)[R]) {
-    float acc[R];
+__device__ inline void dot768(const Rows768<R>& w, const f32x2_t (&x1)[4], const f32x2_t (&x2)[4], int lane, float (&out)[R]) {
+    const f32x2_t zero = {0.f, 0.f};
+    f32x2_t acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = dot8(w.a[r], x1, 0.f);
+    for (int r = 0; r < R; ++r) acc[r] = dot8(w.a[r], x1, zero);
 #pragma unroll
     for (int j = 0; j < (R + 1) / 2; ++j) {
-        const float p = dot8(w.b[j], x2, 0.f);
-        acc[2 * j] += (lane < 32) ? p : 0.f;
-        if (2 * j + 1 < R) acc[2 * j + 1] += (lane >= 32) ? p : 0.f;
+        const f32x2_t p = dot8(w.b[j], x2, zero);
+        acc[2 * j] += (lane < 32) ? p : zero;
+        if (2 * j + 1 < R) acc[2 * j + 1] += (lane >= 32) ? p : zero;
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) out[r] = wave_sum(acc[r]);
+    for (int r = 0; r < R; ++r) out[r] = wave_sum(acc[r].x + acc[r].y);
 }
 
 // LayerNorm (weight only, eps 1e-5, module.py:26-37) of the 768-vector in LDS, in the lane's dot-product layout
-__device__ inline void ln768(const float* xs, const float* lnw, int lane, float (&x1)[8], float (&x2)[8]) {
-    float l1[8], l2[8];
-    load8(lnw + lane * 8, l1);
-    load8(lnw + 512 + (lane & 31) * 8, l2);
-    load8(xs + lane * 8, x1);
-    load8(xs + 512 + (lane & 31) * 8, x2);
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += x1[e];
-    float s2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s2 += x2[e];
-    s += (lane < 32) ? s2 : 0.f;
+__device__ inline void ln768(const float* xs, const float* lnw, int lane, f32x2_t (&x1)[4], f32x2_t (&x2)[4]) {
+    f32x2_t l1[4], l2[4];
+    load8p(lnw + lane * 8, l1);
+    load8p(lnw + 512 + (lane & 31) * 8, l2);
+    load8p(xs + lane * 8, x1);
+    load8p(xs + 512 + (lane & 31) * 8, x2);
+    f32x2_t s1 = (x1[0] + x1[1]) + (x1[2] + x1[3]);
+    f32x2_t s2 = (x2[0] + x2[1]) + (x2[2] + x2[3]);
+    float s = s1.x + s1.y;
+    s += (lane < 32) ? (s2.x + s2.y) : 0.f;
     const float mean = wave_sum(s) / (float)E;
-    float q = 0.f, q2 = 0.f;
+    const f32x2_t mean2 = {mean, mean};
+    f32x2_t q1 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float d = x1[e] - mean; q = fmaf(d, d, q); }
+    for (int e = 0; e < 4; ++e) { const f32x2_t d = x1[e] - mean2; q1 = __builtin_elementwise_fma(d, d, q1); }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float d = x2[e] - mean; q2 = fmaf(d, d, q2); }
-    q += (lane < 32) ? q2 : 0.f;
+    for (int e = 0; e < 4; ++e) { const f32x2_t d = x2[e] - mean2; q2 = __builtin_elementwise_fma(d, d, q2); }
+    float q = q1.x + q1.y;
+    q += (lane < 32) ? (q2.x + q2.y) : 0.f;
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+    const f32x2_t rstd2 = {rstd, rstd};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { x1[e] = (x1[e] - mean) * rstd * l1[e]; x2[e] = (x2[e] - mean) * rstd * l2[e]; }
+    for (int e = 0; e < 4; ++e) { x1[e] = (x1[e] - mean2) * rstd2 * l1[e]; x2[e] = (x2[e] - mean2) * rstd2 * l2[e]; }
 }
 
 __device__ inline float bf16_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
@@ -241,14 +251,15 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // for x (the other D - 1 groups are working); the mlp projection's follow once the attention has freed its registers
             u32x4_t* w2p = reinterpret_cast<u32x4_t*>(lds + L_W2) + wave * (2 * 6 * 64) + lane;
 #pragma unroll
-            for (int r = 0; r < RP; ++r)
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 6; ++i) w2[r][i] = ldwu(lw.Wproj + (long)(rowo + r) * F + 512 * i, (u32)lane * 8u);
             req768(wq, lw.Wqkv, rowq, lane);
             req768(wo, lw.Wo, rowo, lane);
             req768(wf, lw.Wfc, rowf, lane);
             // two of the three mlp c_proj rows are parked in LDS until P5 (the attention needs the registers); they were requested
-            // first, so this waits for them only -- the rest stays in flight (this wave alone reads its parked rows back)
+            // first, so this waits for them only -- the rest stays in flight (this wave alone reads its parked rows back).  The
+            // third row is requested after c_fc, when registers are free again, and lands while the wave waits for h.
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -295,7 +306,8 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             if (k_lo < k_hi) kv_req(0, k_lo);
             if (k_lo + 8 * KP < k_hi) kv_req(1, k_lo + 8 * KP);
             {
-                float x1[8], x2[8], out[RQ];
+                f32x2_t x1[4], x2[4];
+                float out[RQ];
                 ln768(xs, lnw, lane, x1, x2);
                 dot768<RQ>(wq, x1, x2, lane, out);
                 float v = 0.f;
@@ -454,9 +466,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     as[col] = fmaf(e1, p1[d], e0 * p0[d]) / Ls;
                 }
                 __syncthreads();
-                float x1[8], x2[8], out[RO];
-                load8(as + lane * 8, x1);
-                load8(as + 512 + (lane & 31) * 8, x2);
+                f32x2_t x1[4], x2[4];
+                float out[RO];
+                load8p(as + lane * 8, x1);
+                load8p(as + 512 + (lane & 31) * 8, x2);
                 dot768<RO>(wo, x1, x2, lane, out);
                 float v = 0.f;
 #pragma unroll
@@ -471,7 +484,8 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             gather<2>(c, tid, gxb, E, tg + 3, xb);
             stamp(6);   // waited for x'
             {
-                float x1[8], x2[8], out[RF];
+                f32x2_t x1[4], x2[4];
+                float out[RF];
                 ln768(xb, lnw + E, lane, x1, x2);
                 dot768<RF>(wf, x1, x2, lane, out);
                 float v = 0.f;
@@ -479,23 +493,26 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 for (int r = 0; r < RF; ++r) v = (lane == r) ? out[r] : v;
                 if (lane < RF) put_local(gh + rowf + lane, tg + 4, gelu_erf(v));
             }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w2[2][i] = ldwu(lw.Wproj + (long)(rowo + 2) * F + 512 * i, (u32)lane * 8u);
             stamp(7);   // LN + c_fc rows
             // ================= P5: h -> mlp c_proj -> x'' (next layer's x) =================
             gather<6>(c, tid, gh, F, tg + 4, hs);
             stamp(8);   // waited for h
             {
                 float out[RP];
+                f32x2_t acc[RP];
 #pragma unroll
-                for (int r = 0; r < RP; ++r) {
-                    float acc = 0.f;
+                for (int r = 0; r < RP; ++r) acc[r] = f32x2_t{0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        float xv[8];
-                        load8(hs + lane * 8 + 512 * i, xv);
-                        acc = dot8(r < 2 ? w2p[(r * 6 + i) * 64] : w2[r][i], xv, acc);
-                    }
-                    out[r] = wave_sum(acc);
+                for (int i = 0; i < 6; ++i) {       // (chunk-major: each h chunk is read from LDS once for the three rows)
+                    f32x2_t xv[4];
+                    load8p(hs + lane * 8 + 512 * i, xv);
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) acc[r] = dot8(r < 2 ? w2p[(r * 6 + i) * 64] : w2[r][i], xv, acc[r]);
                 }
+#pragma unroll
+                for (int r = 0; r < RP; ++r) out[r] = wave_sum(acc[r].x + acc[r].y);
                 float v = 0.f;
 #pragma unroll
                 for (int r = 0; r < RP; ++r) v = (lane == r) ? out[r] : v;
