@@ -1235,8 +1235,8 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
             return 0;
         };
         // (a CU-masked decode stream never passes: its CUs are spread over all XCDs)
+        // and with the overlap on (UMGEN_OVERLAP=1) every frame runs the five-launch decode layer: one decode path per engine)
         if (!e->overlap) { if (int rc = census(e->stream, 8, e->eng_fg)) return rc; }
-        if (e->full_stream) { if (int rc = census(e->full_stream, 8, e->eng_full)) return rc; }
         e->eng_enabled = e->eng_fg.ok || e->eng_full.ok;
         if (getenv("UMGEN_DEBUG_TIMING"))
             fprintf(stderr, "[umgen] decode engine: decode stream %s (%d XCDs), unmasked stream %s\n", e->eng_fg.ok ? "ok" : "off", e->eng_fg.NG,
