@@ -39,3 +39,19 @@ def test_oracle_matches_reference_golden(name):
     assert o.counters.get("rule_blanked", 0) > 0 and o.counters.get("rule_free", 0) > 0
     if ctl:
         assert o.counters.get("control_resample", 0) > 0
+
+
+def test_recorded_oracle_cases_are_current():
+    """tests/golden/oracle_cases.npz (what the -m gpu tests compare the engine with instead of re-running the oracle on the GPU
+    box) still is what the oracle produces: the cheapest case -- one history frame, two new frames, sliding window -- is
+    re-recorded live and compared, and the sampler helper the recorded top-p / top-k cases depend on is pinned bit for bit."""
+    from tests.golden.make_oracle_cases import CASES, PATH
+
+    rec = np.load(PATH)
+    live = {}
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    CASES["edge"](live)
+    for k, v in live.items():
+        np.testing.assert_array_equal(rec[k], v, err_msg=k)
+    for name in CASES:      # every case of the generator is present in the file
+        assert any(k.startswith({"pad_avoid": "padavoid"}.get(name, name) + "_") for k in rec.files), name
