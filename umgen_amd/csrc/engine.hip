@@ -120,6 +120,7 @@ struct umgen_engine {
     OarLayerDev* d_layers = nullptr;
     unsigned long long *eng_gx = nullptr, *eng_gloc = nullptr;
     unsigned int *eng_ticket = nullptr, *eng_err = nullptr;
+    std::vector<void*> eng_wp2;             // per BlockOAR: mlp c_proj repacked for the engine's hidden-unit split (repack_mlp_proj)
     unsigned long long* eng_stamps = nullptr;   // UMGEN_DEBUG_TIMING: per-phase ticks of the engine (printed at destroy)
     size_t eng_gloc_bytes = 0;
     int fg_xcds = 8;
@@ -944,6 +945,37 @@ int build_tables(umgen_engine* e) {
     return 0;
 }
 
+// Decode engine (oar_engine.hip): the mlp c_proj of every BlockOAR, repacked for the hidden-unit split.  CU c of a group owns
+// hidden units 96 c .. 96 c + 95; thread t of its workgroup holds, as 16-byte units of 8 bf16 in the order it requests them,
+//   unit j < 12 : W[t][96 c + 8 j .. + 7]                                  (all 96 columns of output row t)
+//   unit 12 + j : W[512 + (t & 255)][96 c + 8 (6 (t >> 8) + j) .. + 7]     (half of the columns of one of the rows 512..767)
+// layout [32 CUs][18 units][512 threads][8]: a wave's request of one unit is 1 KB contiguous.
+int repack_mlp_proj(umgen_engine* e) {
+    const int E = e->E, F4 = 4 * E;
+    std::vector<bf16_t> src((size_t)E * F4), dst((size_t)kEngGroup * kEngWpUnits * kEngThreads * 8);
+    std::vector<OarLayerDev> hl(e->oar.size());
+    HIPCHK(e, hipMemcpy(hl.data(), e->d_layers, hl.size() * sizeof(OarLayerDev), hipMemcpyDeviceToHost));
+    if (e->eng_wp2.size() != e->oar.size()) {
+        e->eng_wp2.assign(e->oar.size(), nullptr);
+        for (auto& p : e->eng_wp2)
+            if (int rc = dev_alloc(e, &p, dst.size() * sizeof(bf16_t))) return rc;
+    }
+    for (size_t li = 0; li < e->oar.size(); ++li) {
+        HIPCHK(e, hipMemcpy(src.data(), e->oar[li].mlp.Wproj, src.size() * sizeof(bf16_t), hipMemcpyDeviceToHost));
+        for (int c = 0; c < kEngGroup; ++c)
+            for (int j = 0; j < kEngWpUnits; ++j)
+                for (int t = 0; t < kEngThreads; ++t) {
+                    const int row = j < 12 ? t : 512 + (t & 255);
+                    const int col = 96 * c + 8 * (j < 12 ? j : 6 * (t >> 8) + (j - 12));
+                    memcpy(&dst[(((size_t)c * kEngWpUnits + j) * kEngThreads + t) * 8], &src[(size_t)row * F4 + col], 8 * sizeof(bf16_t));
+                }
+        HIPCHK(e, hipMemcpy(e->eng_wp2[li], dst.data(), dst.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+        hl[li].Wp2 = reinterpret_cast<const bf16_t*>(e->eng_wp2[li]);
+    }
+    HIPCHK(e, hipMemcpy(e->d_layers, hl.data(), hl.size() * sizeof(OarLayerDev), hipMemcpyHostToDevice));
+    return 0;
+}
+
 }  // namespace
 
 // =============================================================================================================
@@ -1185,7 +1217,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         for (int i = 0; i < cfg->n_oar_layer; ++i) {
             const SubW& w = e->oar[i];
             hl[i] = OarLayerDev{reinterpret_cast<const bf16_t*>(w.attn.Wqkv), reinterpret_cast<const bf16_t*>(w.attn.Wo),
-                                reinterpret_cast<const bf16_t*>(w.mlp.Wfc), reinterpret_cast<const bf16_t*>(w.mlp.Wproj),
+                                reinterpret_cast<const bf16_t*>(w.mlp.Wfc), reinterpret_cast<const bf16_t*>(w.mlp.Wproj), nullptr,
                                 w.attn.bqkv, w.attn.bo, w.ln_a, w.ln_b};
         }
         HIPCHK(e, hipMemcpy(e->d_layers, hl.data(), hl.size() * sizeof(OarLayerDev), hipMemcpyHostToDevice));
@@ -1320,6 +1352,7 @@ int umgen_finalize_weights(umgen_engine* e) {
     }
     const int rc = e->cfg.precision == UMGEN_PREC_BF16 ? build_tables<bf16_t>(e) : build_tables<float>(e);
     if (rc) return rc;
+    if (e->eng_enabled) { if (int rc2 = repack_mlp_proj(e)) return rc2; }
     e->finalized = true;
     return UMGEN_OK;
 }
@@ -1534,7 +1567,7 @@ int umgen_destroy(umgen_engine* e) {
     if (e->eng_stamps) {
         unsigned long long st[16];
         if (hipMemcpy(st, e->eng_stamps, 128, hipMemcpyDeviceToHost) == hipSuccess && st[10]) {
-            const char* nm[10] = {"wait x", "qkv rows", "wait qkv", "attention", "wait partials", "c_proj", "wait x'", "c_fc", "wait h", "mlp proj"};
+            const char* nm[10] = {"wait x", "qkv rows", "wait qkv", "attention", "wait partials", "c_proj", "wait x'", "c_fc + partial sums", "wait partial sums", "add partials"};
             fprintf(stderr, "[umgen] decode engine, group 0 rank 0, us per item over %llu items:", st[10]);
             double tot = 0;
             for (int p = 0; p < 10; ++p) { fprintf(stderr, " %s %.2f", nm[p], (double)st[p] / 100.0 / (double)st[10]); tot += (double)st[p] / 100.0 / (double)st[10]; }

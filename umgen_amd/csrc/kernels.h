@@ -121,9 +121,11 @@ template <typename T> void launch_qkv_attn(hipStream_t s, const QkvAttnArgs& a);
 constexpr int kEngE = 768, kEngH = 16;         // the width the engine is built for (UMGen_Large); other widths use the launches above
 constexpr int kEngThreads = 512;               // one workgroup per CU
 constexpr int kEngGroup = 32;                  // workgroups per group == CUs per XCD
-constexpr int kEngLocStride = 3 * kEngE + 2 * kEngH * 50 + kEngE + 4 * kEngE + kEngE;   // granules per group: q|k|v, half partials, x', h, x
+constexpr int kEngWpUnits = 18;                // 16-byte units of the repacked mlp c_proj slice per thread (12 of its full row + 6 of a shared row)
+constexpr int kEngLocStride = 3 * kEngE + 2 * kEngH * 50 + kEngE + kEngGroup * kEngE + kEngE;   // granules per group: q|k|v, half partials, x', mlp partial sums [32][768], x
 struct OarLayerDev {                           // one BlockOAR's parameters (module.py:378-400)
     const bf16_t *Wqkv, *Wo, *Wfc, *Wproj;
+    const bf16_t *Wp2;                         // mlp c_proj repacked for the hidden-unit split: [32 CUs][18 units][512 threads][8] (engine.hip repack_mlp_proj)
     const float *bqkv, *bo, *ln_a, *ln_b;
 };
 struct OarState;

@@ -17,6 +17,10 @@
 // is not used and the decode step runs as the five-launch form (gemv.hip).  Every poll is bounded; a give-up is reported
 // through OarEngineArgs::err and fails the frame loudly.
 //
+// The MLP is split by HIDDEN UNITS: CU c owns c_fc rows 96c..96c+95 and the matching 96 columns of the mlp c_proj, so gelu(c_fc)
+// never leaves the CU; what is exchanged are the CUs' partial sums of the 768 outputs (each CU then adds the 32 partials of its
+// own 24 rows): a 768-granule gather instead of a 3072-granule one, and the projection needs no cross-lane reduction.
+//
 // Arithmetic (fixed, independent of B / D / group placement, so scenes are batch-invariant): fp32 activations, bf16 weights and
 // bf16 K/V cache, fp32 accumulation.  Row dot products: lane l owns k = 8l..8l+7 (+512 i), 8 sequential FMAs per chunk, DPP
 // wave sum.  Attention of a head: its keys are split in two halves (two CUs), each half in 8 wave spans, each span in groups
@@ -47,15 +51,15 @@ constexpr float kScaleQK = 0.14433756729740643f;   // float32(1/sqrt(48)), modul
 constexpr int L_XS = 0;                    // x of the item (kept until the attention projection's residual)   [768]
 constexpr int L_XB = L_XS + E;             // x' (kept until the MLP projection's residual)                    [768]
 constexpr int L_AS = L_XB + E;             // merged attention output                                            [768]
-constexpr int L_HS = L_AS + E;             // gelu(c_fc) vector                                                 [3072]
-constexpr int L_QKV = L_HS + F;            // q_h | k_h | v_h of this CU's head                                  [144 -> 160]
+constexpr int L_HS = L_AS + E;             // this CU's 96 gelu(c_fc) values [96] | half-row sums [256] | gathered mlp partial sums [32][24]   [1152]
+constexpr int L_QKV = L_HS + 1152;          // q_h | k_h | v_h of this CU's head                                  [144 -> 160]
 constexpr int L_GP = L_QKV + 160;          // gathered half partials [32][50]                                   [1600]
 constexpr int L_SM = L_GP + 2 * H * 50;    // per lane-group m [64], l [64], weights [64]                        [192]
 constexpr int L_SO = L_SM + 192;           // per lane-group o [64][48]                                          [3072]
 constexpr int L_MISC = L_SO + 64 * 48;     // rank / scratch                                                      [16]
 constexpr int L_LN = L_MISC + 16;          // ln_1 | ln_2 weights of the item                                     [1536]
-constexpr int L_W2 = L_LN + 2 * E;         // parked mlp c_proj rows 0, 1 of every wave: [8][2][6][64] x 16 B      [24576]
-constexpr int L_TOTAL = L_W2 + NW * 2 * 6 * 64 * 4;
+constexpr int L_W2 = L_LN + 2 * E;         // parked mlp c_proj units 0..11 of every thread: [12][512] x 16 B      [24576]
+constexpr int L_TOTAL = L_W2 + 12 * NT * 4;
 
 __device__ inline u32 xcc_id() {
     u32 x;
@@ -64,10 +68,12 @@ __device__ inline u32 xcc_id() {
 }
 __device__ inline u64 gran(u32 tag, float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); }
 // in-group edge: plain store, stays in the XCD's L2 (readers bypass their L1 with sc1 loads)
-__device__ inline void put_local(u64* g, u32 tag, float v) { __hip_atomic_store(g, gran(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (every global access below is `wave-uniform base [32-bit per-lane index]`: the saddr + voffset form needs no 64-bit pointer per
+// lane; spilled pointers cost a scratch reload whose s_waitcnt vmcnt(0) also waits for every K/V and weight request in flight)
+__device__ inline void put_local(u64* g, u32 i, u32 tag, float v) { __hip_atomic_store(g + i, gran(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // cross-group edge: write-through
-__device__ inline void put_far(u64* g, u32 tag, float v) { __hip_atomic_store(g, gran(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline u64 get(const u64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void put_far(u64* g, u32 i, u32 tag, float v) { __hip_atomic_store(g + i, gran(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline u64 get(const u64* g, u32 i) { return __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct Ctx {
     u32* err;
@@ -86,7 +92,7 @@ __device__ inline void gather(Ctx& c, int tid, const u64* g, int n, u32 tag, flo
             u64 v[PER];
 #pragma unroll
             for (int k = 0; k < PER; ++k)
-                if (((need & ~got) >> k) & 1u) v[k] = get(g + tid + k * NT);
+                if (((need & ~got) >> k) & 1u) v[k] = get(g, (u32)tid + (u32)(k * NT));
 #pragma unroll
             for (int k = 0; k < PER; ++k)
                 if (((need & ~got) >> k) & 1u) {
@@ -199,6 +205,8 @@ __device__ inline float bf16_round(float v) { return bf16_to_f32(f32_to_bf16(v))
 
 }  // namespace
 
+// STAMPS: per-phase 100 MHz time stamps of (group 0, rank 0) into OarEngineArgs::stamps (UMGEN_DEBUG_TIMING); compiled out otherwise
+template <bool STAMPS>
 __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid0 = threadIdx.x;
@@ -210,10 +218,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
     __syncthreads();
     const int w0 = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<u32*>(lds + L_MISC)[0]);
     Ctx c{a.err, false};
-    const bool timer = a.stamps != nullptr && g == 0 && w0 == 0 && tid0 == 0;
+    const bool timer = STAMPS && a.stamps != nullptr && g == 0 && w0 == 0 && tid0 == 0;
     unsigned long long t_prev = 0;
     auto stamp = [&](int p) {
-        if (timer) { const unsigned long long t = wall_clock64(); if (p >= 0) a.stamps[p] += t - t_prev; t_prev = t; }
+        if (STAMPS && timer) { const unsigned long long t = wall_clock64(); if (p >= 0) a.stamps[p] += t - t_prev; t_prev = t; }
     };
     const int Lk = a.st->step;              // cached keys before this step == position of the new token
     const u32 ep = a.st->epoch;
@@ -223,7 +231,6 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
     float* xs = lds + L_XS;
     float* xb = lds + L_XB;
     float* as = lds + L_AS;
-    float* hs = lds + L_HS;
 
     for (int rd = 0; rd < rounds; ++rd) {
         const int s = rd * R + pipe;
@@ -238,32 +245,32 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             u64* gqkv = a.gloc + (long)gl * kEngLocStride;
             u64* gpart = gqkv + 3 * E;
             u64* gxb = gpart + 2 * H * 50;
-            u64* gh = gxb + E;
-            u64* gxl = gh + F;                       // in-group x edge (D == 1)
+            u64* gpy = gxb + E;                      // mlp partial sums [32 producers][768 rows]
+            u64* gxl = gpy + CU * E;                 // in-group x edge (D == 1)
             Rows768<RQ> wq;
             Rows768<RO> wo;
             Rows768<RF> wf;
-            u32x4_t w2[RP][6];
+            u32x4_t wpl[6];                          // units 12..17 of the mlp c_proj slice (requested after the attention)
             const int rowq = (w * NW + wave) * RQ, rowo = (w * NW + wave) * RO, rowf = (w * NW + wave) * RF;
             const OarLayerDev lw = a.layers[l];
             const u32 tg = ep + (u32)((rd * 64 + l) * 8);
             // q|k|v, attention-projection and c_fc rows of this wave are requested NOW: they are in flight while the group waits
             // for x (the other D - 1 groups are working); the mlp projection's follow once the attention has freed its registers
-            u32x4_t* w2p = reinterpret_cast<u32x4_t*>(lds + L_W2) + wave * (2 * 6 * 64) + lane;
+            u32x4_t* w2p = reinterpret_cast<u32x4_t*>(lds + L_W2) + tid;
+            const bf16_t* wp2 = lw.Wp2 + (long)w * kEngWpUnits * NT * 8;
+            {
+                u32x4_t wp[12];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+                for (int j = 0; j < 12; ++j) wp[j] = ldwu(wp2 + (long)j * NT * 8, (u32)tid * 8u);
+                req768(wq, lw.Wqkv, rowq, lane);
+                req768(wo, lw.Wo, rowo, lane);
+                req768(wf, lw.Wfc, rowf, lane);
+                // the first 12 units of the mlp c_proj slice (this thread's full row) are parked in LDS until P4 (the attention needs the
+                // registers); they were requested first, so this waits for them only -- the rest stays in flight (only this thread
+                // reads its parked units back).  Units 12..17 are requested once the attention has freed its registers.
 #pragma unroll
-                for (int i = 0; i < 6; ++i) w2[r][i] = ldwu(lw.Wproj + (long)(rowo + r) * F + 512 * i, (u32)lane * 8u);
-            req768(wq, lw.Wqkv, rowq, lane);
-            req768(wo, lw.Wo, rowo, lane);
-            req768(wf, lw.Wfc, rowf, lane);
-            // two of the three mlp c_proj rows are parked in LDS until P5 (the attention needs the registers); they were requested
-            // first, so this waits for them only -- the rest stays in flight (this wave alone reads its parked rows back).  The
-            // third row is requested after c_fc, when registers are free again, and lands while the wave waits for h.
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int i = 0; i < 6; ++i) w2p[(r * 6 + i) * 64] = w2[r][i];
+                for (int j = 0; j < 12; ++j) w2p[j * NT] = wp[j];
+            }
             // attention geometry of this CU: head hh, half of the L + 1 keys, split in 8 wave spans of 8-key passes
             const int hh = w >> 1, half = w & 1;
             const int nk = Lk + 1;
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // ================= P1: x -> LN -> q | k | v =================
             float* lnw = lds + L_LN;
             if (l == 0) {
-                for (int i = tid; i < E; i += NT) xs[i] = a.xdec[(long)s * E + i];
+                for (u32 i = (u32)tid; i < (u32)E; i += NT) xs[i] = (a.xdec + (long)s * E)[i];
             } else {
                 gather<2>(c, tid, D == 1 ? gxl : a.gx + (long)s * E, E, tg + 0, xs);
             }
@@ -308,7 +315,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             if (touched == 0x7ff00123u) lnw[0] = 0.f;   // (never true for bf16 K/V bit patterns XORed; keeps the prefetch loads alive)
             __syncthreads();
             stamp(0);   // waited for x
-            constexpr int KP = 2, NB = 3;              // 8-key passes per register buffer, buffers (NB * KP * 8 keys of a wave in flight)
+#ifndef UMGEN_ENG_NB
+#define UMGEN_ENG_NB 2
+#endif
+            // 8-key passes per register buffer, buffers (NB * KP * 8 keys of a wave in flight).  NB = 3 costs 30 spilled VGPRs whose
+            // reloads (s_waitcnt vmcnt(0)) also wait for every request in flight; with the K/V rows already in the L2 two suffice
+            constexpr int KP = 2, NB = UMGEN_ENG_NB;
             u32x4_t kc[NB][KP], vc[NB][KP];
             auto kv_req = [&](int buf, int k0) {
 #pragma unroll
@@ -331,15 +343,15 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 v += bq;
                 if (lane < RQ) {
                     const int n = rowq + lane;
-                    put_local(gqkv + n, tg + 1, v);
+                    put_local(gqkv, (u32)n, tg + 1, v);
                     if (n >= E) {   // K / V rows of the new token: bf16 into the cache (head-major [2][H][Lmax][48])
                         const int cc = n - E, kvsel = cc / E, hc = cc % E;
-                        a.kvcache[(long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride +
-                                  ((long)(kvsel * H + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim] = f32_to_bf16(v);
+                        (a.kvcache + (long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride)[
+                            (u32)(((kvsel * H + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim)] = f32_to_bf16(v);
                     }
                 }
             }
-            if (k_lo + 16 * KP < k_hi) kv_req(2, k_lo + 16 * KP);   // (the q|k|v rows' registers are free now)
+            if (NB > 2 && k_lo + 16 * KP < k_hi) kv_req(NB > 2 ? 2 : 0, k_lo + 16 * KP);   // (the q|k|v rows' registers are free now)
             stamp(1);   // LN + q|k|v rows
             // ================= P2: attention of (head hh, half) =================
             {
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     for (u32 spins = 0;;) {
                         bool ok = true;
                         u64 v = 0;
-                        if (tid < 3 * kHeadDim) { v = get(gqkv + src); ok = (u32)(v >> 32) == tg + 1; }
+                        if (tid < 3 * kHeadDim) { v = get(gqkv, (u32)src); ok = (u32)(v >> 32) == tg + 1; }
                         if (ok && tid < 3 * kHeadDim) qs[tid] = __uint_as_float((u32)v);
                         if (!__any(!ok)) break;
                         if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, (tg + 1) | 0x80000000u); c.failed = true; break; }
@@ -419,9 +431,9 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         chunk(kc[1], vc[1], k0 + 8 * KP);
                         if (k0 + 8 * KP * (NB + 1) < k_hi) kv_req(1, k0 + 8 * KP * (NB + 1));
                     }
-                    if (k0 + 16 * KP < k_hi) {
-                        chunk(kc[2], vc[2], k0 + 16 * KP);
-                        if (k0 + 8 * KP * (NB + 2) < k_hi) kv_req(2, k0 + 8 * KP * (NB + 2));
+                    if (NB > 2 && k0 + 16 * KP < k_hi) {
+                        chunk(kc[NB > 2 ? 2 : 0], vc[NB > 2 ? 2 : 0], k0 + 16 * KP);
+                        if (k0 + 8 * KP * (NB + 2) < k_hi) kv_req(NB > 2 ? 2 : 0, k0 + 8 * KP * (NB + 2));
                     }
                 }
                 // 64 lane-group partials of this CU -> LDS -> one half partial (m, l, o[48]) published by wave 0
@@ -458,8 +470,8 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
 #pragma unroll
                         for (int jg = 0; jg < 8; ++jg) o += fold[jg * kHeadDim + tid];
                         u64* gp = gpart + (hh * 2 + half) * 50;
-                        put_local(gp + tid, tg + 2, o);
-                        if (tid == 0) { put_local(gp + 48, tg + 2, M); put_local(gp + 49, tg + 2, Ls); }
+                        put_local(gp, (u32)tid, tg + 2, o);
+                        if (tid == 0) { put_local(gp, 48u, tg + 2, M); put_local(gp, 49u, tg + 2, Ls); }
                     }
                     __syncthreads();   // fold (the gather buffer) is free again
                 }
@@ -468,6 +480,8 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // ================= P3: merge the halves -> c_proj -> x' =================
             gather<4>(c, tid, gpart, 2 * H * 50, tg + 2, lds + L_GP);
             stamp(4);   // waited for the half partials
+#pragma unroll
+            for (int j = 0; j < 6; ++j) wpl[j] = ldwu(wp2 + (long)(12 + j) * NT * 8, (u32)tid * 8u);
             {
                 const float* gp = lds + L_GP;
                 for (int col = tid; col < E; col += NT) {
@@ -491,13 +505,16 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 for (int r = 0; r < RO; ++r) v = (lane == r) ? out[r] : v;
                 if (lane < RO) {
                     const int n = rowo + lane;
-                    put_local(gxb + n, tg + 3, xs[n] + (v + bo));
+                    put_local(gxb, (u32)n, tg + 3, xs[n] + (v + bo));
                 }
             }
             stamp(5);   // merge + c_proj rows
-            // ================= P4: x' -> LN -> c_fc -> GELU =================
+            // ================= P4: x' -> LN -> c_fc -> GELU -> this CU's partial sums of the mlp c_proj =================
             gather<2>(c, tid, gxb, E, tg + 3, xb);
             stamp(6);   // waited for x'
+            float* hsl = lds + L_HS;              // [96] gelu(c_fc) of this CU's hidden units
+            float* hrow = hsl + 96;               // [256] second halves of the shared rows 512..767
+            float* part = hrow + 256;             // [32][24] gathered partial sums (P5)
             {
                 f32x2_t x1[4], x2[4];
                 float out[RF];
@@ -506,41 +523,70 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 float v = 0.f;
 #pragma unroll
                 for (int r = 0; r < RF; ++r) v = (lane == r) ? out[r] : v;
-                if (lane < RF) put_local(gh + rowf + lane, tg + 4, gelu_erf(v));
+                if (lane < RF) hsl[wave * RF + lane] = gelu_erf(v);
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) w2[2][i] = ldwu(lw.Wproj + (long)(rowo + 2) * F + 512 * i, (u32)lane * 8u);
-            stamp(7);   // LN + c_fc rows
-            // ================= P5: h -> mlp c_proj -> x'' (next layer's x) =================
-            gather<6>(c, tid, gh, F, tg + 4, hs);
-            stamp(8);   // waited for h
+            __syncthreads();
             {
-                float out[RP];
-                f32x2_t acc[RP];
+                // thread t: all 96 columns of output row t (units 0..11, parked in LDS) + half of the columns of row 512 + (t & 255)
+                // (units 12..17: columns 48 (t >> 8) .. +47); every lane reads the same h values (LDS broadcast)
+                const f32x2_t zero = {0.f, 0.f};
+                f32x2_t accA = zero, accB = zero;
 #pragma unroll
-                for (int r = 0; r < RP; ++r) acc[r] = f32x2_t{0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {       // (chunk-major: each h chunk is read from LDS once for the three rows)
+                for (int j = 0; j < 12; ++j) {
                     f32x2_t xv[4];
-                    load8p(hs + lane * 8 + 512 * i, xv);
-#pragma unroll
-                    for (int r = 0; r < RP; ++r) acc[r] = dot8(r < 2 ? w2p[(r * 6 + i) * 64] : w2[r][i], xv, acc[r]);
+                    load8p(hsl + 8 * j, xv);
+                    accA = dot8(w2p[j * NT], xv, accA);
                 }
+                const int cb = 6 * (tid >> 8);
 #pragma unroll
-                for (int r = 0; r < RP; ++r) out[r] = wave_sum(acc[r].x + acc[r].y);
-                float v = 0.f;
-#pragma unroll
-                for (int r = 0; r < RP; ++r) v = (lane == r) ? out[r] : v;
-                if (lane < RP) {
-                    const int n = rowo + lane;
-                    const float xn = xb[n] + v;
-                    if (l + 1 == a.n_layers) a.xdec[(long)s * E + n] = xn;
-                    else if (D == 1) put_local(gxl + n, tg + 8, xn);
-                    else put_far(a.gx + (long)s * E + n, tg + 8, xn);
+                for (int j = 0; j < 6; ++j) {
+                    f32x2_t xv[4];
+                    load8p(hsl + 8 * (cb + j), xv);
+                    accB = dot8(wpl[j], xv, accB);
                 }
+                const float yA = accA.x + accA.y;
+                float yB = accB.x + accB.y;
+                if (tid >= 256) hrow[tid - 256] = yB;
+                __syncthreads();
+                u64* mine = gpy + (long)w * E;
+                put_local(mine, (u32)tid, tg + 4, yA);
+                if (tid < 256) put_local(mine, 512u + (u32)tid, tg + 4, yB + hrow[tid]);
+            }
+            stamp(7);   // LN + c_fc rows + partial sums
+            // ================= P5: the 32 partial sums of this CU's 24 rows -> x'' (next layer's x) =================
+            if (!c.failed) {
+                // producer p's partials of rows 24 w .. 24 w + 23 sit at gpy[p * 768 + 24 w + r]: 768 granules in 32 runs of 192 B
+                u32 got = 0;
+                const u32 need = (tid < 256) ? 3u : 1u;
+                for (u32 spins = 0;;) {
+                    u64 v[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if (((need & ~got) >> k) & 1u) { const u32 i = (u32)tid + (u32)(k * NT); v[k] = get(gpy + 24 * w, (i / 24u) * (u32)E + i % 24u); }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if (((need & ~got) >> k) & 1u) {
+                            if ((u32)(v[k] >> 32) == tg + 4) { part[tid + k * NT] = __uint_as_float((u32)v[k]); got |= 1u << k; }
+                        }
+                    if (!__any(got != need)) break;
+                    if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, (tg + 4) | 0x80000000u); c.failed = true; break; }
+                    if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
+                }
+            }
+            __syncthreads();
+            stamp(8);   // waited for the partial sums
+            if (tid < 24) {
+                float sum = 0.f;
+#pragma unroll
+                for (int p = 0; p < CU; ++p) sum += part[p * 24 + tid];      // fixed order: producer 0, 1, ..., 31
+                const int n = 24 * w + tid;
+                const float xn = xb[n] + sum;
+                if (l + 1 == a.n_layers) (a.xdec + (long)s * E)[(u32)n] = xn;
+                else if (D == 1) put_local(gxl, (u32)n, tg + 8, xn);
+                else put_far(a.gx + (long)s * E, (u32)n, tg + 8, xn);
             }
             stamp(9);   // mlp c_proj rows
-            if (timer) a.stamps[10] += 1;
+            if (STAMPS && timer) a.stamps[10] += 1;
         }
     }
 }
@@ -570,12 +616,14 @@ hipError_t launch_oar_engine_census(hipStream_t s, int n_groups, unsigned int* d
 hipError_t launch_oar_engine(hipStream_t s, const OarEngineArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(oar_engine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)oar_engine_lds_bytes());
-        if (rc != hipSuccess) return rc;
+        for (const void* f : {reinterpret_cast<const void*>(oar_engine_kernel<false>), reinterpret_cast<const void*>(oar_engine_kernel<true>)}) {
+            hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oar_engine_lds_bytes());
+            if (rc != hipSuccess) return rc;
+        }
         attr_set = true;
     }
-    hipLaunchKernelGGL(oar_engine_kernel, dim3(a.NG * kEngGroup), dim3(kEngThreads), oar_engine_lds_bytes(), s, a);
+    if (a.stamps) hipLaunchKernelGGL(oar_engine_kernel<true>, dim3(a.NG * kEngGroup), dim3(kEngThreads), oar_engine_lds_bytes(), s, a);
+    else hipLaunchKernelGGL(oar_engine_kernel<false>, dim3(a.NG * kEngGroup), dim3(kEngThreads), oar_engine_lds_bytes(), s, a);
     return hipGetLastError();
 }
 
