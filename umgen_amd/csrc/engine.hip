@@ -1571,6 +1571,7 @@ int umgen_destroy(umgen_engine* e) {
             fprintf(stderr, "[umgen] decode engine, group 0 rank 0, us per item over %llu items:", st[10]);
             double tot = 0;
             for (int p = 0; p < 10; ++p) { fprintf(stderr, " %s %.2f", nm[p], (double)st[p] / 100.0 / (double)st[10]); tot += (double)st[p] / 100.0 / (double)st[10]; }
+            fprintf(stderr, " (c_fc part %.2f)", (double)st[11] / 100.0 / (double)st[10]);
             fprintf(stderr, " | total %.2f\n", tot);
         }
     }

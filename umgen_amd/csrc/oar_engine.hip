@@ -526,6 +526,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 if (lane < RF) hsl[wave * RF + lane] = gelu_erf(v);
             }
             __syncthreads();
+            stamp(11);  // LN + c_fc rows + GELU
             {
                 // thread t: all 96 columns of output row t (units 0..11, parked in LDS) + half of the columns of row 512 + (t & 255)
                 // (units 12..17: columns 48 (t >> 8) .. +47); every lane reads the same h values (LDS broadcast)
