@@ -813,18 +813,34 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         const int ns_cached = attn_nsplit(j);       // fused-decode experiment: splits over the cached keys only
         const int gkey = eng ? 0 : (e->fused_decode ? ns_cached : ns);   // the engine derives its key geometry from the device-side step
         if (graphs) {
-            hipGraphExec_t& ge = e->step_graph[mod][gkey];
+            // With the decode engine a step is 3 kernel nodes and ~600 us, and a graph launch costs ~7 us on the device (the gap between
+            // the sampler of one replay and the engine of the next, rocprofv3 kernel trace): runs of steps of the same kind are replayed
+            // 16 or 4 at a time (gkey 1 / 2; the engine derives everything else from the device-side step counter).
+            int run = 1;
+            if (eng) {
+                int same = 1;
+                while (same < 16 && j + same < j_end) {
+                    const int jn = j + same;
+                    const int mn = (jn >= kMapC0 && jn < kMapEos) ? 1 : (jn >= kBoxC0 && jn < kBoxEos) ? 2 : (jn >= kImgC0 && jn < kImgEos) ? 3 : 0;
+                    if (mn != mod) break;
+                    ++same;
+                }
+                run = same >= 16 ? 16 : (same >= 4 ? 4 : 1);
+            }
+            hipGraphExec_t& ge = e->step_graph[mod][eng ? (run == 16 ? 2 : (run == 4 ? 1 : 0)) : gkey];
             if (!ge) {
                 hipGraph_t g;
                 HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
                 e->in_capture = true;
-                enqueue_step<T>(e, B, mod, ns, ns_cached, nullptr, 0);
+                for (int r = 0; r < run; ++r) enqueue_step<T>(e, B, mod, ns, ns_cached, nullptr, 0);
                 e->in_capture = false;
                 HIPCHK(e, hipStreamEndCapture(st, &g));
                 HIPCHK(e, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
                 HIPCHK(e, hipGraphDestroy(g));
             }
             HIPCHK(e, hipGraphLaunch(ge, st));
+            e->tm.oar_kernels += (int64_t)(run - 1) * ((eng ? 1 : (e->fused_decode ? 4 : 5) * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
+            j += run - 1;
         } else if (int rc = enqueue_step<T>(e, B, mod, ns, ns_cached, tr, j)) {
             return rc;
         }

@@ -465,6 +465,21 @@ __device__ inline void write_next_input(const SampleArgs& a, int b, int j, const
     float* xo = a.x_next + (long)b * E;
     for (int c = threadIdx.x; c < E; c += blockDim.x) xo[c] = (emb_f ? emb_f[c] : bf16_to_f32(emb_b[c])) + cr[c];
 }
+// the same with the conditioning row already in registers (requested at the start of the sampler kernel: one memory round trip
+// less behind the sampled token); E <= 6 * 256
+struct CondRow { float v[6]; };
+__device__ inline CondRow load_cond_row(const SampleArgs& a, int b, int j) {
+    CondRow r;
+    const float* cr = a.cond + ((long)b * kSeq + (j + 1)) * a.tb.E;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const int c = threadIdx.x + 256 * i; r.v[i] = c < a.tb.E ? cr[c] : 0.f; }
+    return r;
+}
+__device__ inline void write_next_input(const SampleArgs& a, int b, const float* emb_f, const CondRow& r) {
+    float* xo = a.x_next + (long)b * a.tb.E;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const int c = threadIdx.x + 256 * i; if (c < a.tb.E) xo[c] = emb_f[c] + r.v[i]; }
+}
 
 // steps whose emitted scene token is known: pose prefix (bos, 3 pose tokens, eos) and every bos/eos (d_token_pos,
 // UMGen.py:976-984, 1046-1050)
@@ -486,6 +501,7 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
     const bool use_forced = a.st->use_forced != 0, use_control = a.st->use_control != 0;
     const int pos1 = j + 1;   // the reference's 1-based curr_seq_len
     const unsigned long long seed = a.seeds[b];
+    const CondRow crow = load_cond_row(a, b, j);
     const float* lg = a.logits + (long)b * a.ld_logits;
     const int topk = a.mod == 1 ? sp.top_k_map : (a.mod == 3 ? sp.topk_image : sp.top_k);
     // top-p: the image head receives topk_image as its "p" (UMGen.py:1133) => the whole distribution is kept
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
     }
     if (threadIdx.x == 0) toks[off + k] = tok;
     const float* emb = (a.mod == 1) ? a.tb.gmap + (long)tok * E : (a.mod == 3 ? a.tb.gimg + (long)tok * E : a.tb.be + (long)tok * E);
-    write_next_input(a, b, j, emb, nullptr);
+    write_next_input(a, b, emb, crow);
     finish_step(a.st);
 }
 void launch_sample_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchKernelGGL(sample_token_kernel, dim3(B), dim3(256), 0, s, a); }

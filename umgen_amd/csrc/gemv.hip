@@ -178,7 +178,9 @@ __device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
                                 if (a.kv_f32) a.kv_f32[(long)mm * 2 * a.E + c] = v;
                             }
                         } else {
-                            __builtin_nontemporal_store((a.out_mode == GEMV_OUT_GELU) ? gelu_erf(v) : v, &a.out[(long)mm * a.ldo + n]);
+                            // (head logits are read by ONE workgroup right away: a plain store keeps them in the L2)
+                            if (a.out_mode == GEMV_OUT_GELU) __builtin_nontemporal_store(gelu_erf(v), &a.out[(long)mm * a.ldo + n]);
+                            else a.out[(long)mm * a.ldo + n] = v;
                         }
                     }
                 }
