@@ -1,5 +1,8 @@
 // Attention kernels (replace flash_attn_func at module.py:218-225 / 497-504; semantics: exact softmax attention,
 // scale 1/sqrt(48) applied to q.k in fp32, bottom-right aligned causal mask where causal).  head_dim is 48 everywhere.
+#include <cstdlib>
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace umgen {
@@ -220,6 +223,291 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
     }
 }
 
+#ifdef UMGEN_ATTN_VARIANTS   // only tools/micro/attn_bench.hip builds these (measured round 2, profiles/r02_attn_variants.txt)
+// ---------------------------------------------------------------------------------------------------------
+// Second form of the same kernel (same tiles, LDS images and MFMA operand maps), with the levers of the round-2 VALU diet as
+// template bits so each one is measured on its own (tools/micro/attn_bench.hip):
+//   1  cross-row maxima through v_permlane16_swap / v_permlane32_swap (VALU) instead of two ds_bpermute round trips
+//   2  softmax denominators on the matrix pipe: a fourth "d block" whose A operand is all ones sums the SAME bf16 p values the
+//      P.V product uses (l = sum of rounded p; 4 MFMAs per key tile instead of 32 v_add_f32 + the final cross-lane sum)
+//   4  O is rescaled on every tile (no wave-uniform branch in the middle of the tile body)
+//   8  P.V per query tile right behind its softmax (V fragments of the whole key tile held in registers), so the second query
+//      tile's softmax runs beside the first one's MFMAs
+//   16 s_setprio 1 around the MFMA groups
+// The key tail (S % 64) is a peeled last tile: the body of full tiles carries no masking code.
+// ---------------------------------------------------------------------------------------------------------
+// (inline-asm maxima reading MFMA results gave NaNs: the hazard recogniser places no wait states for asm operands)
+__device__ __forceinline__ float vmax2(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float xmax16(float x) {   // max(x[lane], x[lane ^ 16])
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xmax32(float x) {   // max(x[lane], x[lane ^ 32])
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+int g_attn_variant = 0;   // set by the bench
+
+template <int QT, int OPT>
+__global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                                                 bf16_t* __restrict__ y, int S, int S_pad, int H, int nq, int npairs) {
+    constexpr bool PERM = OPT & 1, ONES = OPT & 2, ALWAYS = OPT & 4, PER_T = OPT & 8, PRIO = OPT & 16;
+    constexpr bool X_NOLOAD = OPT & 64, X_NOEXP = OPT & 128, X_NOBAR = OPT & 256;   // timing experiments only (wrong results)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTileBytes];
+    const int E = H * kHeadDim;
+    const int b = blockIdx.x;
+    const int group = b / (8 * nq), rem = b % (8 * nq);
+    const int pair = group * 8 + (rem & 7), qb = rem >> 3;
+    if (pair >= npairs) return;
+    const int f = pair / H, h = pair % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int q0 = (qb * 4 + wave) * (QT * 16);
+    const long ld = 2L * E;
+    const bf16_t* qbase = qk + (long)f * S * ld + h * kHeadDim;
+    const bf16_t* kbase = qbase + E;
+    const bf16_t* vbase = vt + ((long)f * H + h) * kHeadDim * S_pad;
+
+    // staging: identical to attn_spatial_mfma_kernel
+    const bool mid_is_k = tid < 128;
+    const int r0 = tid / 6, p0 = tid % 6;
+    const int c1 = tid + 256;
+    const int r1 = mid_is_k ? c1 / 6 : (c1 - 384) >> 3, p1 = mid_is_k ? c1 % 6 : (c1 - 384) & 7;
+    const int c2 = tid + 512 - 384, r2 = c2 >> 3, p2 = c2 & 7;
+    const bf16_t* g0 = kbase + p0 * 8;
+    const bf16_t* g1 = mid_is_k ? kbase + p1 * 8 : vbase + (long)r1 * S_pad + p1 * 8;
+    const bf16_t* g2 = vbase + (long)r2 * S_pad + p2 * 8;
+    auto koff = [&](int r, int pp) { return r * kKStride + (pp < 4 ? pp * 16 : 64 + (pp - 4) * 32); };
+    auto voff = [&](int r, int pp) { return 64 * kKStride + r * kVStride + (((2 * pp) ^ (r & 15)) & ~1) * 8; };
+    const int l0 = koff(r0, p0);
+    const int l1 = mid_is_k ? koff(r1, p1) : voff(r1, p1);
+    const int l2 = voff(r2, p2);
+    const bool hi0 = p0 >= 4, hi1 = mid_is_k && p1 >= 4, swap1 = !mid_is_k && (r1 & 1), swap2 = r2 & 1;
+    uint4 sg0, sg1, sg2;
+    auto gload = [&](int k0) {
+        sg0 = *reinterpret_cast<const uint4*>(g0 + (long)min(k0 + r0, S - 1) * ld);
+        sg1 = *reinterpret_cast<const uint4*>(mid_is_k ? g1 + (long)min(k0 + r1, S - 1) * ld : g1 + k0);
+        sg2 = *reinterpret_cast<const uint4*>(g2 + k0);
+    };
+    auto kstore = [](unsigned char* dst, uint4 v, bool hi) {
+        if (hi) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2*>(dst + 16) = make_uint2(v.z, v.w);
+        } else {
+            *reinterpret_cast<uint4*>(dst) = v;
+        }
+    };
+    auto vstore = [](unsigned char* dst, uint4 v, bool sw) {
+        *reinterpret_cast<uint4*>(dst) = sw ? make_uint4(v.z, v.w, v.x, v.y) : v;
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* base = lds + buf * kTileBytes;
+        kstore(base + l0, sg0, hi0);
+        if (mid_is_k) kstore(base + l1, sg1, hi1); else vstore(base + l1, sg1, swap1);
+        vstore(base + l2, sg2, swap2);
+    };
+    for (int i = tid; i < 2 * 64 * 4; i += 256) {
+        const int buf = i >> 8, r = (i >> 2) & 63, sl = i & 3;
+        *reinterpret_cast<uint2*>(lds + buf * kTileBytes + r * kKStride + 64 + sl * 16 + 8) = make_uint2(0u, 0u);
+    }
+
+    bf16x8_t qlo[QT], qhi[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qr = min(q0 + t * 16 + c16, S - 1);
+        qlo[t] = *reinterpret_cast<const bf16x8_t*>(qbase + qr * ld + 8 * g);
+        union { bf16x8_t v; uint2 u[2]; } qh;
+        qh.u[0] = *reinterpret_cast<const uint2*>(qbase + qr * ld + 32 + 4 * g);
+        qh.u[1] = make_uint2(0u, 0u);
+        qhi[t] = qh.v;
+    }
+    f32x4_t o[QT][3], ls[QT];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -INFINITY;
+        l[t] = 0.f;
+        ls[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[t][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    const float c = kScale * kLog2e;
+    const int ntile = (S + 63) / 64;
+
+    auto tile = [&](auto masked, int it) {
+        constexpr bool MASK = decltype(masked)::value;
+        const int k0 = it * 64;
+        const unsigned char* kt_l = lds + (it & 1) * kTileBytes;
+        const unsigned char* vt_l = kt_l + 64 * kKStride;
+        f32x4_t st[QT][4];
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const unsigned char* kr = kt_l + (kt * 16 + c16) * kKStride;
+            const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kr + 16 * g);
+            const bf16x8_t khi = *reinterpret_cast<const bf16x8_t*>(kr + 64 + 16 * g);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(klo, qlo[t], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                st[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(khi, qhi[t], a, 0, 0, 0);
+            }
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        bf16x8_t va[3][2];
+        if (PER_T) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const unsigned char* vr = vt_l + (d * 16 + c16) * kVStride;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    union { bf16x8_t v; uint2 u[2]; } a;
+                    a.u[0] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g) ^ c16) << 3));
+                    a.u[1] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g + 4) ^ c16) << 3));
+                    va[d][hh] = a.v;
+                }
+            }
+        }
+        if (MASK) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + kt * 16 + 4 * g + r >= S) {
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) st[t][kt][r] = -INFINITY;
+                    }
+        }
+        bf16x8_t pb[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx;
+            if (PERM) {
+                mx = vmax3(st[t][0][0], st[t][0][1], st[t][0][2]);
+                mx = vmax3(mx, st[t][0][3], st[t][1][0]);
+                mx = vmax3(mx, st[t][1][1], st[t][1][2]);
+                mx = vmax3(mx, st[t][1][3], st[t][2][0]);
+                mx = vmax3(mx, st[t][2][1], st[t][2][2]);
+                mx = vmax3(mx, st[t][2][3], st[t][3][0]);
+                mx = vmax3(mx, st[t][3][1], st[t][3][2]);
+                mx = fmaxf(mx, st[t][3][3]);   // (a compiler-visible VALU write in front of the swap: it places the hazard wait states)
+                mx = xmax16(mx);
+                mx = xmax32(mx);
+            } else {
+                mx = st[t][0][0];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][kt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+            }
+            const float mn = PERM ? vmax2(m[t], mx) : fmaxf(m[t], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m[t] - mn) * c);
+            m[t] = mn;
+            const float mc = mn * c;
+            float ps = 0.f;
+            float p[4][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[kt][r] = X_NOEXP ? st[t][kt][r] * c - mc : __builtin_amdgcn_exp2f(st[t][kt][r] * c - mc);
+                    if (!ONES) ps += p[kt][r];
+                }
+            if (!ONES) l[t] = l[t] * alpha + ps;
+            if (ALWAYS || !__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t][d][r] *= alpha;
+                if (ONES) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ls[t][r] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[t][hh][j] = (__bf16)p[2 * hh + (j >> 2)][j & 3];
+            if (PER_T) {
+                if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[d][hh], pb[t][hh], o[t][d], 0, 0, 0);
+                    if (ONES) ls[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[t][hh], ls[t], 0, 0, 0);
+                }
+                if (PRIO) __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        if (!PER_T) {
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const unsigned char* vr = vt_l + (d * 16 + c16) * kVStride;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    union { bf16x8_t v; uint2 u[2]; } a;
+                    a.u[0] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g) ^ c16) << 3));
+                    a.u[1] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g + 4) ^ c16) << 3));
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, pb[t][hh], o[t][d], 0, 0, 0);
+                }
+            }
+            if (ONES) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) ls[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[t][hh], ls[t], 0, 0, 0);
+            }
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+        }
+        if (!X_NOLOAD && it + 1 < ntile) {
+            lstore((it + 1) & 1);
+            if (it + 2 < ntile) gload(k0 + 128);
+        }
+        if (!X_NOBAR) __syncthreads();
+    };
+
+    gload(0);
+    __syncthreads();
+    lstore(0);
+    if (ntile > 1) gload(64);
+    __syncthreads();
+    const bool tail = (S & 63) != 0;
+    const int nfull = tail ? ntile - 1 : ntile;
+    for (int it = 0; it < nfull; ++it) tile(std::false_type{}, it);
+    if (tail) tile(std::true_type{}, ntile - 1);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float lt;
+        if (ONES) {
+            lt = ls[t][0];            // every row of the ones block holds the same sum over all keys
+        } else {
+            lt = l[t];
+            lt += __shfl_xor(lt, 16);
+            lt += __shfl_xor(lt, 32);
+        }
+        const float inv = 1.0f / lt;
+        const int qr = q0 + t * 16 + c16;
+        if (qr < S) {
+            bf16_t* yr = y + ((long)f * S + qr) * E + h * kHeadDim + 4 * g;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float v[4] = {o[t][d][0] * inv, o[t][d][1] * inv, o[t][d][2] * inv, o[t][d][3] * inv};
+                store4(yr + d * 16, v);
+            }
+        }
+    }
+}
+
+#endif   // UMGEN_ATTN_VARIANTS
+
 #ifndef UMGEN_ATTN_QT
 #define UMGEN_ATTN_QT 2   // measured: 2 query tiles per wave (2 waves/SIMD) beats 4 (1 wave/SIMD)
 #endif
@@ -228,7 +516,19 @@ void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t
     const int nq = (S + 4 * QT * 16 - 1) / (4 * QT * 16);
     // F*H pairs; groups of 8 pairs need F*H % 8 == 0 -- pad the pair count up and let the surplus blocks exit
     const int pairs = ((F * H + 7) / 8) * 8;
-    hipLaunchKernelGGL(attn_spatial_mfma_kernel<QT>, dim3(pairs * nq), dim3(256), 0, s, qk, vt, y, S, S_pad, H, nq, F * H);
+    const dim3 grid(pairs * nq), block(256);
+#ifdef UMGEN_ATTN_VARIANTS
+#define UMGEN_ATTN_CASE(OPT) \
+    case OPT: hipLaunchKernelGGL((attn_spatial_mfma2_kernel<QT, OPT>), grid, block, 0, s, qk, vt, y, S, S_pad, H, nq, F * H); return;
+    switch (g_attn_variant) {
+        UMGEN_ATTN_CASE(1) UMGEN_ATTN_CASE(2) UMGEN_ATTN_CASE(3) UMGEN_ATTN_CASE(7) UMGEN_ATTN_CASE(11) UMGEN_ATTN_CASE(15)
+        UMGEN_ATTN_CASE(19) UMGEN_ATTN_CASE(23) UMGEN_ATTN_CASE(27) UMGEN_ATTN_CASE(31) UMGEN_ATTN_CASE(32)
+        UMGEN_ATTN_CASE(71) UMGEN_ATTN_CASE(327) UMGEN_ATTN_CASE(135) UMGEN_ATTN_CASE(455)
+        default: break;
+    }
+#undef UMGEN_ATTN_CASE
+#endif
+    hipLaunchKernelGGL(attn_spatial_mfma_kernel<QT>, grid, block, 0, s, qk, vt, y, S, S_pad, H, nq, F * H);
 }
 
 // ---------------------------------------------------------------------------------------------------------
