@@ -22,12 +22,15 @@ constexpr float kLog2e = 1.4426950408889634f;
 // Blocks of one (frame, head) are mapped to the same XCD (block b runs on XCD b % 8) so its K/V stay in one L2.
 // ---------------------------------------------------------------------------------------------------------
 // LDS images (SQ_LDS_BANK_CONFLICT was 44 % of the LDS cycles with plain 112 B / 144 B rows and 8-byte fragment reads):
-//   K row (144 B): d 0..31 as four 16 B pieces, then d 32..47 as four 16 B slots of [4 values | 4 zeros] -- the half-filled MFMA's
-//     A operand is one ds_read_b128 (zero halves written once); 36 dwords per row puts the 8 rows of a b128 phase on all 32 banks.
+//   K row (128 B) = eight 16 B chunks: d 0..31 in chunks 0..3, d 32..47 in chunks 4, 5, zeros (written once) in chunks 6, 7 -- the
+//     half-filled MFMA takes d 32..47 in k-slot groups 0, 1 and zeros in groups 2, 3; both A operands are one ds_read_b128.  Chunk c of
+//     row r is stored at c ^ 2*((r >> 1) & 3): a ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...
+//     (MI355X_MICROARCH.md, LDS), and this XOR puts each group's 16 lanes on 16 distinct 16-byte slots of the 256-byte bank row
+//     (round 1's 144 B rows were 2-way: 27 M of 86 M LDS cycles per launch, profiles/r02_attn_variants.txt).
 //   Vt row (128 B): sixteen 8 B key groups, group s stored at s ^ (row & 15): the 16 rows of a b64 phase hit 16 distinct bank pairs.
-constexpr int kKStride = 144;
+constexpr int kKStride = 128;
 constexpr int kVStride = 128;
-constexpr int kTileBytes = 64 * kKStride + 48 * kVStride;   // 15360
+constexpr int kTileBytes = 64 * kKStride + 48 * kVStride;   // 14336
 
 template <int QT>
 __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
@@ -59,44 +62,35 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
     const bf16_t* g0 = kbase + p0 * 8;
     const bf16_t* g1 = mid_is_k ? kbase + p1 * 8 : vbase + (long)r1 * S_pad + p1 * 8;
     const bf16_t* g2 = vbase + (long)r2 * S_pad + p2 * 8;
-    // LDS byte offsets: K piece p < 4 -> p*16; p = 4, 5 (d 32..47) -> slots 2(p-4), 2(p-4)+1 behind byte 64 (8 B each, see above);
+    // LDS byte offsets: K piece p -> chunk p ^ 2*((row >> 1) & 3) of the row;
     // Vt piece p (key groups 2p, 2p+1) -> the aligned 16 B pair (2p ^ row) & ~1, halves swapped when the row is odd
-    auto koff = [&](int r, int pp) { return r * kKStride + (pp < 4 ? pp * 16 : 64 + (pp - 4) * 32); };
+    auto koff = [&](int r, int pp) { return r * kKStride + ((pp ^ (2 * ((r >> 1) & 3))) << 4); };
     auto voff = [&](int r, int pp) { return 64 * kKStride + r * kVStride + (((2 * pp) ^ (r & 15)) & ~1) * 8; };
     const int l0 = koff(r0, p0);
     const int l1 = mid_is_k ? koff(r1, p1) : voff(r1, p1);
     const int l2 = voff(r2, p2);
-    const bool hi0 = p0 >= 4, hi1 = mid_is_k && p1 >= 4, swap1 = !mid_is_k && (r1 & 1), swap2 = r2 & 1;
+    const bool swap1 = !mid_is_k && (r1 & 1), swap2 = r2 & 1;
     uint4 sg0, sg1, sg2;
     auto gload = [&](int k0) {
         sg0 = *reinterpret_cast<const uint4*>(g0 + (long)min(k0 + r0, S - 1) * ld);
         sg1 = *reinterpret_cast<const uint4*>(mid_is_k ? g1 + (long)min(k0 + r1, S - 1) * ld : g1 + k0);
         sg2 = *reinterpret_cast<const uint4*>(g2 + k0);
     };
-    auto kstore = [](unsigned char* dst, uint4 v, bool hi) {
-        if (hi) {
-            *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
-            *reinterpret_cast<uint2*>(dst + 16) = make_uint2(v.z, v.w);
-        } else {
-            *reinterpret_cast<uint4*>(dst) = v;
-        }
-    };
     auto vstore = [](unsigned char* dst, uint4 v, bool sw) {
         *reinterpret_cast<uint4*>(dst) = sw ? make_uint4(v.z, v.w, v.x, v.y) : v;
     };
     auto lstore = [&](int buf) {
         unsigned char* base = lds + buf * kTileBytes;
-        kstore(base + l0, sg0, hi0);
-        if (mid_is_k) kstore(base + l1, sg1, hi1); else vstore(base + l1, sg1, swap1);
+        *reinterpret_cast<uint4*>(base + l0) = sg0;
+        vstore(base + l1, sg1, swap1);   // (swap1 is false for the K chunks)
         vstore(base + l2, sg2, swap2);
     };
-    // the zero halves of the K hi slots (both buffers) are written once
-    for (int i = tid; i < 2 * 64 * 4; i += 256) {
-        const int buf = i >> 8, r = (i >> 2) & 63, sl = i & 3;
-        *reinterpret_cast<uint2*>(lds + buf * kTileBytes + r * kKStride + 64 + sl * 16 + 8) = make_uint2(0u, 0u);
+    {   // the zero chunks 6, 7 of every K row (both buffers) are written once
+        const int buf = tid >> 7, r = (tid >> 1) & 63, sl = 6 + (tid & 1);
+        *reinterpret_cast<uint4*>(lds + buf * kTileBytes + r * kKStride + ((sl ^ (2 * ((r >> 1) & 3))) << 4)) = make_uint4(0u, 0u, 0u, 0u);
     }
 
-    // head_dim 48 = one full K=32 MFMA (d 0..31) + one half-filled K=32 MFMA (d 32..47 in k-slots 8g..8g+3, zeros in 8g+4..8g+7).
+    // head_dim 48 = one full K=32 MFMA (d 0..31) + one half-filled K=32 MFMA (d 32..47 in k-slots 0..15, zeros in 16..31).
     // (The legacy v_mfma_f32_16x16x16_bf16 for the 16-wide remainder gave tile-dependent wrong results under some register
     //  allocations on ROCm 7.2 -- chained behind the 8-pass 16x16x32 through SrcC -- so it is not used.)
     bf16x8_t qlo[QT], qhi[QT];
@@ -104,9 +98,9 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
     for (int t = 0; t < QT; ++t) {
         const int qr = min(q0 + t * 16 + c16, S - 1);
         qlo[t] = *reinterpret_cast<const bf16x8_t*>(qbase + qr * ld + 8 * g);
-        union { bf16x8_t v; uint2 u[2]; } qh;
-        qh.u[0] = *reinterpret_cast<const uint2*>(qbase + qr * ld + 32 + 4 * g);
-        qh.u[1] = make_uint2(0u, 0u);
+        union { bf16x8_t v; uint4 w; } qh;
+        qh.w = *reinterpret_cast<const uint4*>(qbase + qr * ld + 32 + 8 * (g & 1));
+        if (g >= 2) qh.w = make_uint4(0u, 0u, 0u, 0u);
         qhi[t] = qh.v;
     }
     f32x4_t o[QT][3];
@@ -133,8 +127,9 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const unsigned char* kr = kt_l + (kt * 16 + c16) * kKStride;
-            const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kr + 16 * g);
-            const bf16x8_t khi = *reinterpret_cast<const bf16x8_t*>(kr + 64 + 16 * g);   // d 32+4g .. 35+4g | zeros
+            const int ksw = 2 * ((c16 >> 1) & 3);
+            const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kr + ((g ^ ksw) << 4));
+            const bf16x8_t khi = *reinterpret_cast<const bf16x8_t*>(kr + (((4 + g) ^ ksw) << 4));   // d 32+8g .. 39+8g (g < 2) | zeros
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(klo, qlo[t], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -248,14 +243,23 @@ __device__ __forceinline__ float xmax32(float x) {   // max(x[lane], x[lane ^ 32
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+constexpr int kTB = 15360;    // tile buffer of the variants (fits round 1's 144-byte K rows too)
 int g_attn_variant = 0;   // set by the bench
 
 template <int QT, int OPT>
 __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                                                  bf16_t* __restrict__ y, int S, int S_pad, int H, int nq, int npairs) {
     constexpr bool PERM = OPT & 1, ONES = OPT & 2, ALWAYS = OPT & 4, PER_T = OPT & 8, PRIO = OPT & 16;
-    constexpr bool X_NOLOAD = OPT & 64, X_NOEXP = OPT & 128, X_NOBAR = OPT & 256;   // timing experiments only (wrong results)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTileBytes];
+    constexpr bool X_NOLOAD = OPT & 64, X_NOEXP = OPT & 128, X_NOBAR = OPT & 256, X_UNIF = OPT & 512, X_UNIFV = OPT & 1024;
+    // 2048: K image with 128-byte rows, 16-byte chunk c of row r at c ^ 2*((r >> 1) & 3) (conflict-free for the ds_read_b128 lane groups
+    // {0-3,12-15,20-27} ...; the 144-byte rows are 2-way), d 32..47 as two whole chunks + two zero chunks (k-slot groups 2, 3 are zero)
+    // 4096: K / Vt tiles straight from global memory into the LDS images (global_load_lds_dwordx4, swizzles applied on the source
+    // side, 16-byte chunk XOR for Vt as well): no staging registers, no ds_write pass
+    constexpr bool GLDS = OPT & 4096;
+    constexpr bool NEWK = (OPT & 2048) || GLDS;
+    constexpr int kKStride = 144;   // (round 1's K rows, kept here for the A/B; shadows the namespace constant)
+    constexpr int kKB = NEWK ? 64 * 128 : 64 * kKStride;   // timing experiments only (wrong results)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTB];
     const int E = H * kHeadDim;
     const int b = blockIdx.x;
     const int group = b / (8 * nq), rem = b % (8 * nq);
@@ -279,12 +283,14 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
     const bf16_t* g0 = kbase + p0 * 8;
     const bf16_t* g1 = mid_is_k ? kbase + p1 * 8 : vbase + (long)r1 * S_pad + p1 * 8;
     const bf16_t* g2 = vbase + (long)r2 * S_pad + p2 * 8;
-    auto koff = [&](int r, int pp) { return r * kKStride + (pp < 4 ? pp * 16 : 64 + (pp - 4) * 32); };
-    auto voff = [&](int r, int pp) { return 64 * kKStride + r * kVStride + (((2 * pp) ^ (r & 15)) & ~1) * 8; };
+    auto koff = [&](int r, int pp) {
+        return NEWK ? r * 128 + ((pp ^ (2 * ((r >> 1) & 3))) << 4) : r * kKStride + (pp < 4 ? pp * 16 : 64 + (pp - 4) * 32);
+    };
+    auto voff = [&](int r, int pp) { return kKB + r * kVStride + (((2 * pp) ^ (r & 15)) & ~1) * 8; };
     const int l0 = koff(r0, p0);
     const int l1 = mid_is_k ? koff(r1, p1) : voff(r1, p1);
     const int l2 = voff(r2, p2);
-    const bool hi0 = p0 >= 4, hi1 = mid_is_k && p1 >= 4, swap1 = !mid_is_k && (r1 & 1), swap2 = r2 & 1;
+    const bool hi0 = !NEWK && p0 >= 4, hi1 = !NEWK && mid_is_k && p1 >= 4, swap1 = !mid_is_k && (r1 & 1), swap2 = r2 & 1;
     uint4 sg0, sg1, sg2;
     auto gload = [&](int k0) {
         sg0 = *reinterpret_cast<const uint4*>(g0 + (long)min(k0 + r0, S - 1) * ld);
@@ -303,14 +309,40 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
         *reinterpret_cast<uint4*>(dst) = sw ? make_uint4(v.z, v.w, v.x, v.y) : v;
     };
     auto lstore = [&](int buf) {
-        unsigned char* base = lds + buf * kTileBytes;
+        unsigned char* base = lds + buf * kTB;
         kstore(base + l0, sg0, hi0);
         if (mid_is_k) kstore(base + l1, sg1, hi1); else vstore(base + l1, sg1, swap1);
         vstore(base + l2, sg2, swap2);
     };
-    for (int i = tid; i < 2 * 64 * 4; i += 256) {
-        const int buf = i >> 8, r = (i >> 2) & 63, sl = i & 3;
-        *reinterpret_cast<uint2*>(lds + buf * kTileBytes + r * kKStride + 64 + sl * 16 + 8) = make_uint2(0u, 0u);
+    // GLDS: 14 one-KB segments per tile (8 K rows or 8 Vt rows each); wave w issues segments w, w + 4, w + 8, w + 12
+    auto issue = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int seg = wave + 4 * i;
+            if (seg < 14) {
+                unsigned char* dst = lds + buf * kTB + seg * 1024;
+                const int row = (seg < 8 ? 8 * seg : 8 * (seg - 8)) + (lane >> 3), pc = lane & 7;
+                if (seg < 8) {
+                    const int lc = pc ^ (2 * ((row >> 1) & 3));
+                    if (lc < 6)   // (chunks 6, 7 hold the zeros written once: their lanes stay off)
+                        __builtin_amdgcn_global_load_lds((const void*)(kbase + (long)min(k0 + row, S - 1) * ld + lc * 8),
+                                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                } else {
+                    const int lc = pc ^ ((row >> 1) & 7);
+                    __builtin_amdgcn_global_load_lds((const void*)(vbase + (long)row * S_pad + k0 + lc * 8),
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
+            }
+        }
+    };
+    if (NEWK) {
+        const int buf = tid >> 7, r = (tid >> 1) & 63, sl = 6 + (tid & 1);   // chunks 6, 7 of every K row, both buffers
+        *reinterpret_cast<uint4*>(lds + buf * kTB + r * 128 + ((sl ^ (2 * ((r >> 1) & 3))) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (int i = tid; i < 2 * 64 * 4; i += 256) {
+            const int buf = i >> 8, r = (i >> 2) & 63, sl = i & 3;
+            *reinterpret_cast<uint2*>(lds + buf * kTB + r * kKStride + 64 + sl * 16 + 8) = make_uint2(0u, 0u);
+        }
     }
 
     bf16x8_t qlo[QT], qhi[QT];
@@ -318,9 +350,14 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
     for (int t = 0; t < QT; ++t) {
         const int qr = min(q0 + t * 16 + c16, S - 1);
         qlo[t] = *reinterpret_cast<const bf16x8_t*>(qbase + qr * ld + 8 * g);
-        union { bf16x8_t v; uint2 u[2]; } qh;
-        qh.u[0] = *reinterpret_cast<const uint2*>(qbase + qr * ld + 32 + 4 * g);
-        qh.u[1] = make_uint2(0u, 0u);
+        union { bf16x8_t v; uint2 u[2]; uint4 w; } qh;
+        if (NEWK) {
+            qh.w = *reinterpret_cast<const uint4*>(qbase + qr * ld + 32 + 8 * (g & 1));
+            if (g >= 2) qh.w = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            qh.u[0] = *reinterpret_cast<const uint2*>(qbase + qr * ld + 32 + 4 * g);
+            qh.u[1] = make_uint2(0u, 0u);
+        }
         qhi[t] = qh.v;
     }
     f32x4_t o[QT][3], ls[QT];
@@ -341,16 +378,20 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
 
     auto tile = [&](auto masked, int it) {
         constexpr bool MASK = decltype(masked)::value;
+        // byte offset of 8-byte key group gr inside this lane's Vt row
+        auto vgran = [&](int gr) { return GLDS ? (((gr >> 1) ^ ((c16 >> 1) & 7)) << 4) + (gr & 1) * 8 : (gr ^ c16) << 3; };
         const int k0 = it * 64;
-        const unsigned char* kt_l = lds + (it & 1) * kTileBytes;
-        const unsigned char* vt_l = kt_l + 64 * kKStride;
+        const unsigned char* kt_l = lds + (it & 1) * kTB;
+        const unsigned char* vt_l = kt_l + kKB;
+        if (GLDS && !X_NOLOAD && it + 1 < ntile) issue((it + 1) & 1, k0 + 64);   // (that buffer's readers passed the barrier)
         f32x4_t st[QT][4];
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            const unsigned char* kr = kt_l + (kt * 16 + c16) * kKStride;
-            const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kr + 16 * g);
-            const bf16x8_t khi = *reinterpret_cast<const bf16x8_t*>(kr + 64 + 16 * g);
+            const unsigned char* kr = kt_l + (kt * 16 + (X_UNIF ? 0 : c16)) * (NEWK ? 128 : kKStride);   // X_UNIF: one address per wave (broadcast reads)
+            const int ksw = 2 * ((c16 >> 1) & 3);
+            const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kr + (X_UNIF ? 0 : NEWK ? (g ^ ksw) << 4 : 16 * g));
+            const bf16x8_t khi = *reinterpret_cast<const bf16x8_t*>(kr + (X_UNIF ? 64 : NEWK ? ((4 + g) ^ ksw) << 4 : 64 + 16 * g));
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(klo, qlo[t], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -366,8 +407,8 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     union { bf16x8_t v; uint2 u[2]; } a;
-                    a.u[0] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g) ^ c16) << 3));
-                    a.u[1] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g + 4) ^ c16) << 3));
+                    a.u[0] = *reinterpret_cast<const uint2*>(vr + vgran(8 * hh + g));
+                    a.u[1] = *reinterpret_cast<const uint2*>(vr + vgran(8 * hh + g + 4));
                     va[d][hh] = a.v;
                 }
             }
@@ -449,12 +490,12 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
             if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const unsigned char* vr = vt_l + (d * 16 + c16) * kVStride;
+                const unsigned char* vr = vt_l + (d * 16 + (X_UNIFV ? 0 : c16)) * kVStride;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     union { bf16x8_t v; uint2 u[2]; } a;
-                    a.u[0] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g) ^ c16) << 3));
-                    a.u[1] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g + 4) ^ c16) << 3));
+                    a.u[0] = *reinterpret_cast<const uint2*>(vr + (X_UNIFV ? 8 * hh : vgran(8 * hh + g)));
+                    a.u[1] = *reinterpret_cast<const uint2*>(vr + (X_UNIFV ? 8 * hh + 32 : vgran(8 * hh + g + 4)));
 #pragma unroll
                     for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, pb[t][hh], o[t][d], 0, 0, 0);
                 }
@@ -467,18 +508,24 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
             }
             if (PRIO) __builtin_amdgcn_s_setprio(0);
         }
-        if (!X_NOLOAD && it + 1 < ntile) {
+        if (!GLDS && !X_NOLOAD && it + 1 < ntile) {
             lstore((it + 1) & 1);
             if (it + 2 < ntile) gload(k0 + 128);
         }
-        if (!X_NOBAR) __syncthreads();
+        if (!X_NOBAR) __syncthreads();   // (GLDS: the barrier's release waits for this wave's LDS-bound loads)
     };
 
-    gload(0);
-    __syncthreads();
-    lstore(0);
-    if (ntile > 1) gload(64);
-    __syncthreads();
+    if (GLDS) {
+        __syncthreads();   // zero chunks written
+        issue(0, 0);
+        __syncthreads();
+    } else {
+        gload(0);
+        __syncthreads();
+        lstore(0);
+        if (ntile > 1) gload(64);
+        __syncthreads();
+    }
     const bool tail = (S & 63) != 0;
     const int nfull = tail ? ntile - 1 : ntile;
     for (int it = 0; it < nfull; ++it) tile(std::false_type{}, it);
@@ -523,7 +570,9 @@ void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t
     switch (g_attn_variant) {
         UMGEN_ATTN_CASE(1) UMGEN_ATTN_CASE(2) UMGEN_ATTN_CASE(3) UMGEN_ATTN_CASE(7) UMGEN_ATTN_CASE(11) UMGEN_ATTN_CASE(15)
         UMGEN_ATTN_CASE(19) UMGEN_ATTN_CASE(23) UMGEN_ATTN_CASE(27) UMGEN_ATTN_CASE(31) UMGEN_ATTN_CASE(32)
-        UMGEN_ATTN_CASE(71) UMGEN_ATTN_CASE(327) UMGEN_ATTN_CASE(135) UMGEN_ATTN_CASE(455)
+        UMGEN_ATTN_CASE(71) UMGEN_ATTN_CASE(327) UMGEN_ATTN_CASE(135) UMGEN_ATTN_CASE(455) UMGEN_ATTN_CASE(967) UMGEN_ATTN_CASE(1479) UMGEN_ATTN_CASE(1991)
+        UMGEN_ATTN_CASE(2048) UMGEN_ATTN_CASE(2051) UMGEN_ATTN_CASE(2055) UMGEN_ATTN_CASE(2503)
+        UMGEN_ATTN_CASE(4096) UMGEN_ATTN_CASE(4099) UMGEN_ATTN_CASE(4103) UMGEN_ATTN_CASE(4107) UMGEN_ATTN_CASE(4115)
         default: break;
     }
 #undef UMGEN_ATTN_CASE
