@@ -19,8 +19,13 @@ __host__ __device__ inline float bf16_to_f32(bf16_t v) {
     c.u = ((uint32_t)v) << 16;
     return c.f;
 }
-// round-to-nearest-even, NaN preserved (same as torch's float -> bfloat16)
+// round-to-nearest-even, NaN preserved (same as torch's float -> bfloat16).  On the device this is the hardware conversion
+// (v_cvt_pk_bf16_f32, RNE; same bits for every non-NaN input) instead of six integer operations per value: the GEMM / LayerNorm /
+// attention epilogues convert 32 values per lane and tile.
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+#endif
     union { uint32_t u; float f; } c;
     c.f = f;
     uint32_t u = c.u;
@@ -104,10 +109,9 @@ __device__ inline void store4(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ inline void store4(bf16_t* p, const float (&v)[4]) {
-    uint2 o;
-    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-    *reinterpret_cast<uint2*>(p) = o;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    const bf16x4_t o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};   // two v_cvt_pk_bf16_f32
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, o);
 }
 
 // ---- build-owned counter-based RNG: bit-for-bit the oracle's rng_u24 (oracle/umgen_oracle.py) ----
