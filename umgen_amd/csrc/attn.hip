@@ -17,8 +17,8 @@ constexpr float kLog2e = 1.4426950408889634f;
 //                                                     P registers are exactly its B-operand elements: no cross-lane traffic)
 // Q, K are row-major [token][2E]; V is stored transposed per (frame, head) by the QKV GEMM epilogue (GEMM_VT).
 // A workgroup = 4 waves x (QT*16) queries of one (frame, head).  The 64-key K tile [64][48] and Vt tile [48][64] are staged
-// once per workgroup into double-buffered LDS (16-byte global loads prefetched into registers one tile ahead; row strides
-// 112 B / 144 B make the ds_read_b128 / ds_read_b64 fragment reads bank-conflict free) and shared by the 4 waves.
+// once per workgroup into double-buffered LDS (16-byte global loads prefetched into registers one tile ahead; images laid out
+// for conflict-free ds_read_b128 / ds_read_b64 fragment reads, see below) and shared by the 4 waves.
 // Blocks of one (frame, head) are mapped to the same XCD (block b runs on XCD b % 8) so its K/V stay in one L2.
 // ---------------------------------------------------------------------------------------------------------
 // LDS images (SQ_LDS_BANK_CONFLICT was 44 % of the LDS cycles with plain 112 B / 144 B rows and 8-byte fragment reads):
