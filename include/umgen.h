@@ -120,7 +120,9 @@ int umgen_finalize_weights(umgen_engine *e);
 /* UMGen.inference(new_frames, cond_frames, input_cond_frames=T_in, input_cond_tokens, init_tokens, control_test)
  * for B independent scenes (the reference is B = 1; scenes never interact).
  *   pose/map/bbox3d/image : [B][T_in][S_mod] int64 history tokens (first T_in frames are used)
- *   ctrl_pose/ctrl_bbox3d : NULL, or [B][T_ctl][3] / [B][T_ctl][660] control tokens (init_tokens; -1 = free)
+ *   ctrl_pose/ctrl_bbox3d : NULL, or [B][T_ctl][3] / [B][T_ctl][660] control tokens (init_tokens; -1 = free).  Either may be given
+ *                           alone: pose only (ego controlled), bbox3d only with control_test (agents controlled, the ego net
+ *                           infers the pose; UMGen.py:1438-1473), or both (the reference's control pickles)
  *   out_*                 : [B][T_in + new_frames][S_mod], caller-allocated
  */
 int umgen_rollout(umgen_engine *e, int32_t B, int32_t T_in, int32_t new_frames, int32_t cond_frames,

@@ -33,7 +33,9 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
     scene = synthetic_scene(scene_id, n_frames=input_cond_frames)
     tokens = {k: torch.from_numpy(v) for k, v in scene.items()}
     init = None
-    if control:
+    if control == "bbox3d":   # agent control only: the ego net infers the pose; control tokens for the first two new frames
+        init = {"bbox3d": torch.from_numpy(synthetic_control(scene_id, n_frames=2)["bbox3d"])}
+    elif control:
         init = {k: torch.from_numpy(v) for k, v in synthetic_control(scene_id, n_frames=new_frames).items()}
 
     rec = {"cond": [], "ego_logits": [], "logits": {m: [] for m in LOGIT_POS}, "count": {m: 0 for m in LOGIT_POS}}
@@ -63,14 +65,15 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
 
     out = model.inference(new_frames=new_frames, cond_frames=cond_frames, pred_task="pose_map_bbox3d_image",
                           input_cond_tokens=tokens, init_tokens=init, input_cond_frames=input_cond_frames,
-                          control_test=control, cond_on_par=True, infer_from_gt=False)
+                          control_test=bool(control), cond_on_par=True, infer_from_gt=False)
     blob = {f"out_{m}": out[m].astype(np.int16) for m in out}
     blob["cond_rows"] = np.stack(rec["cond"]).astype(np.float32)
     if rec["ego_logits"]:
         blob["ego_logits"] = np.stack(rec["ego_logits"]).astype(np.float32)
     for m in LOGIT_POS:
         blob[f"logits_{m}"] = np.stack(rec["logits"][m]).astype(np.float32)
-    blob["meta"] = np.array([weight_seed, scene_id, cond_frames, input_cond_frames, new_frames, int(control)], dtype=np.int64)
+    blob["meta"] = np.array([weight_seed, scene_id, cond_frames, input_cond_frames, new_frames, 2 if control == "bbox3d" else int(control)],
+                            dtype=np.int64)   # last entry: 0 video, 1 pose + bbox3d control, 2 bbox3d-only control (2 control frames)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **blob)
     print("wrote", path, {k: v.shape for k, v in blob.items()})
@@ -80,8 +83,13 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     cfg = tiny_config()
-    run_case("tiny_video_greedy", cfg, weight_seed=1, scene_id=0, cond_frames=3, input_cond_frames=3, new_frames=2, control=False)
-    run_case("tiny_control_greedy", cfg, weight_seed=2, scene_id=1, cond_frames=3, input_cond_frames=2, new_frames=3, control=True)
+    only = sys.argv[1:]
+    cases = [("tiny_video_greedy", dict(weight_seed=1, scene_id=0, cond_frames=3, input_cond_frames=3, new_frames=2, control=False)),
+             ("tiny_control_greedy", dict(weight_seed=2, scene_id=1, cond_frames=3, input_cond_frames=2, new_frames=3, control=True)),
+             ("tiny_boxctl_greedy", dict(weight_seed=3, scene_id=2, cond_frames=3, input_cond_frames=2, new_frames=3, control="bbox3d"))]
+    for name, kw in cases:
+        if not only or name in only:
+            run_case(name, cfg, **kw)
 
 
 if __name__ == "__main__":

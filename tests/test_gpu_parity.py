@@ -11,7 +11,7 @@ import torch
 
 from umgen_amd.config import MOD_ORDER, tiny_config
 from umgen_amd.engine import Engine
-from umgen_amd.synth import synthetic_control, synthetic_scene
+from umgen_amd.synth import golden_init_tokens, synthetic_control, synthetic_scene
 from umgen_amd.weights import synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
@@ -34,16 +34,16 @@ def make_engine(cfg, seed, precision, max_batch=1):
     return e
 
 
-@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy"])
+@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy"])
 def test_fp32_greedy_rollout_is_token_exact_vs_reference_golden(name):
-    """fp32 parity mode: the whole rollout (ego net, 3 TAR stacks, 2206-step OAR loop, rule constraint, control)
-    reproduces the token sequences recorded from the reference itself, bit for bit."""
+    """fp32 parity mode: the whole rollout (ego net, 3 TAR stacks, 2206-step OAR loop, rule constraint, control with pose +
+    bbox3d tokens and with bbox3d tokens alone) reproduces the token sequences recorded from the reference itself, bit for bit."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
     cfg = tiny_config().greedy()
     e = make_engine(cfg, ws, "fp32")
     scene = synthetic_scene(sid, n_frames=icf)
-    init = synthetic_control(sid, n_frames=nf) if ctl else None
+    init = golden_init_tokens(sid, nf, ctl)
     out = e.rollout(scene, nf, cond_frames=cf, input_cond_frames=icf, init_tokens=init, control_test=bool(ctl), seeds=[0])
     for m in MOD_ORDER:
         np.testing.assert_array_equal(out[m], g[f"out_{m}"].astype(np.int64), err_msg=m)
@@ -227,8 +227,8 @@ def test_edge_cases_single_history_frame_zero_new_frames_and_errors(oc):
     with pytest.raises(UMGenError, match="bbox3d token -1"):
         e.rollout(bad, 1, cond_frames=2, input_cond_frames=1)
     ctl = synthetic_control(30, n_frames=1)
-    with pytest.raises(UMGenError, match="without init_tokens"):
-        e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"bbox3d": ctl["bbox3d"]}, control_test=True)      # bbox3d-only control
+    with pytest.raises(UMGenError, match="without control_test"):
+        e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"bbox3d": ctl["bbox3d"]}, control_test=False)     # bbox3d tokens need control_test
     with pytest.raises(UMGenError, match="not supported"):
         e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"pose": ctl["pose"], "map": scene["map"]})
     with pytest.raises(UMGenError, match="shape"):

@@ -9,7 +9,7 @@ import torch
 
 from oracle.umgen_oracle import OracleUMGen
 from umgen_amd.config import tiny_config
-from umgen_amd.synth import synthetic_control, synthetic_scene
+from umgen_amd.synth import golden_init_tokens, synthetic_control, synthetic_scene
 from umgen_amd.weights import synthetic_state_dict
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -17,7 +17,7 @@ LOGIT_POS = {"map": [0, 1, 511, 1023], "bbox3d": [0, 9, 10, 11, 330, 659], "imag
 COND_ROWS = [0, 1, 4, 5, 6, 500, 1030, 1031, 1032, 1042, 1692, 1693, 1694, 2000, 2206]
 
 
-@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy"])
+@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy"])
 def test_oracle_matches_reference_golden(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
@@ -25,7 +25,7 @@ def test_oracle_matches_reference_golden(name):
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     o = OracleUMGen(cfg, synthetic_state_dict(cfg, seed=ws))
     out = o.inference(nf, cf, synthetic_scene(sid, n_frames=icf), input_cond_frames=icf,
-                      init_tokens=synthetic_control(sid, n_frames=nf) if ctl else None,
+                      init_tokens=golden_init_tokens(sid, nf, ctl),
                       control_test=bool(ctl), trace=True)
     for m in ("pose", "map", "bbox3d", "image"):
         np.testing.assert_array_equal(out[m], g[f"out_{m}"].astype(np.int64), err_msg=m)

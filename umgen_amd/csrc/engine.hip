@@ -1426,7 +1426,7 @@ int umgen_frame(umgen_engine* e, int32_t T, const int64_t* pose, const int64_t* 
     if (int rc = check_scene_tokens(e, (size_t)T, pose, map, bbox3d, image)) return rc;
     if (ctrl_pose) { if (int rc = check_tokens(e, "control pose", ctrl_pose, 3, e->cfg.pose_vocab, false)) return rc; }
     if (ctrl_bbox3d) { if (int rc = check_tokens(e, "control bbox3d", ctrl_bbox3d, kNBox, e->cfg.bbox3d_vocab, true)) return rc; }
-    if (ctrl_bbox3d && !ctrl_pose) return e->fail(UMGEN_E_UNSUPPORTED, "control bbox3d tokens without control pose tokens: not a path the reference's callers take (model_pl.py:137-171 passes both)");
+    if (ctrl_bbox3d && !control_test) return e->fail(UMGEN_E_UNSUPPORTED, "init_tokens['bbox3d'] without control_test is not a supported reference path");
     std::vector<int> p((size_t)T * 3), m((size_t)T * kNMap), bx((size_t)T * kNBox), im((size_t)T * kNImg);
     for (size_t i = 0; i < p.size(); ++i) p[i] = (int)pose[i];
     for (size_t i = 0; i < m.size(); ++i) m[i] = (int)map[i];
@@ -1467,8 +1467,6 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
     if ((ctrl_pose || ctrl_bbox3d) && T_ctl < 1) return e->fail(UMGEN_E_INVALID, "control tokens given with T_ctl=%d", T_ctl);
     if (ctrl_pose) { if (int rc = check_tokens(e, "control pose", ctrl_pose, (size_t)B * T_ctl * 3, e->cfg.pose_vocab, false)) return rc; }
     if (ctrl_bbox3d) { if (int rc = check_tokens(e, "control bbox3d", ctrl_bbox3d, (size_t)B * T_ctl * kNBox, e->cfg.bbox3d_vocab, true)) return rc; }
-    if (ctrl_bbox3d && !ctrl_pose)   // the reference's loop ends a control rollout on the pose tokens only (UMGen.py:1613-1619)
-        return e->fail(UMGEN_E_UNSUPPORTED, "control bbox3d tokens without control pose tokens: not a path the reference's callers take (model_pl.py:137-171 passes both)");
     e->tm = umgen_timings{};
     e->overlap_suspended = false;
     const int T_out = T_in + new_frames;
@@ -1488,7 +1486,11 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
                 }
     }
     int T_cur = T_in;
+    // Control tokens (UMGen.py:1605-1619, 1438-1473).  With pose tokens the rollout leaves control mode for good once they are used
+    // up (init_tokens = None, control_test = False); bbox3d tokens alone (agents controlled, ego inferred by the ego net) simply stop
+    // applying after their last frame (get_mod_tokens returns None past the end).
     bool have_ctl = (ctrl_pose != nullptr) && T_ctl > 0;
+    bool have_box = (ctrl_bbox3d != nullptr) && T_ctl > 0;
     std::vector<int> frame_out((size_t)B * kTokPerFrame);
     for (int idx = 0; idx < new_frames; ++idx) {
         if (T_cur > cond_frames) {   // sliding window (UMGen.py:1600-1603)
@@ -1501,21 +1503,24 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
             }
             T_cur = cond_frames;
         }
-        if (have_ctl && idx >= T_ctl) { have_ctl = false; control_test = 0; }   // control tokens exhausted (UMGen.py:1613-1619)
+        if (have_ctl && idx >= T_ctl) { have_ctl = false; have_box = false; control_test = 0; }   // control tokens exhausted (UMGen.py:1613-1619)
+        if (have_box && idx >= T_ctl) have_box = false;
         std::vector<int> cp;
         std::vector<unsigned char> cs;
         if (have_ctl) {
             cp.resize((size_t)B * 3);
             for (int b = 0; b < B; ++b)
                 for (int a = 0; a < 3; ++a) cp[b * 3 + a] = (int)ctrl_pose[((size_t)b * T_ctl + idx) * 3 + a];
-            if (ctrl_bbox3d && control_test) {
+        }
+        if (have_box) {
+            if (control_test) {
                 cs.assign((size_t)B * kSlots, 0);
                 for (int b = 0; b < B; ++b)
                     for (int i = 0; i < kNBox; ++i) {
                         const int64_t v = ctrl_bbox3d[((size_t)b * T_ctl + idx) * kNBox + i];
                         if (v != -1) { hist[2][((size_t)b * T_cur + (T_cur - 1)) * kNBox + i] = (int)v; cs[(size_t)b * kSlots + i / kSlotLen] = 1; }
                     }
-            } else if (ctrl_bbox3d) {
+            } else {
                 return e->fail(UMGEN_E_UNSUPPORTED, "init_tokens['bbox3d'] without control_test is not a supported reference path");
             }
         }

@@ -127,18 +127,19 @@ class Engine:
             extra = [k for k, v in init_tokens.items() if v is not None and k not in ("pose", "bbox3d")]
             if extra:   # the reference would condition infer_oar_net on them (init_mods); this engine does not implement that
                 raise UMGenError(f"init_tokens for {extra} are not supported (only 'pose' and 'bbox3d' control tokens)")
-            if init_tokens.get("pose") is None and init_tokens.get("bbox3d") is not None:
-                raise UMGenError("init_tokens['bbox3d'] without init_tokens['pose'] is not supported: the reference's control "
-                                 "rollouts always pass both (model_pl.py:137-171) and end on the pose tokens (UMGen.py:1613-1619)")
         if init_tokens is not None and init_tokens.get("pose") is not None:
             cp = _i64(init_tokens["pose"])
             if cp.ndim != 3 or cp.shape[0] != B or cp.shape[2] != CONTENT_LEN["pose"]:
                 raise UMGenError(f"init_tokens['pose'] has shape {cp.shape}, expected ({B}, T_ctl, {CONTENT_LEN['pose']})")
             T_ctl = cp.shape[1]
-            if init_tokens.get("bbox3d") is not None:
-                cb = _i64(init_tokens["bbox3d"])
-                if cb.shape != (B, T_ctl, CONTENT_LEN["bbox3d"]):
-                    raise UMGenError(f"init_tokens['bbox3d'] has shape {cb.shape}, expected {(B, T_ctl, CONTENT_LEN['bbox3d'])}")
+        if init_tokens is not None and init_tokens.get("bbox3d") is not None:   # with or without pose tokens (UMGen.py:1458-1473)
+            cb = _i64(init_tokens["bbox3d"])
+            if cp is None:
+                if cb.ndim != 3 or cb.shape[0] != B or cb.shape[2] != CONTENT_LEN["bbox3d"]:
+                    raise UMGenError(f"init_tokens['bbox3d'] has shape {cb.shape}, expected ({B}, T_ctl, {CONTENT_LEN['bbox3d']})")
+                T_ctl = cb.shape[1]
+            elif cb.shape != (B, T_ctl, CONTENT_LEN["bbox3d"]):
+                raise UMGenError(f"init_tokens['bbox3d'] has shape {cb.shape}, expected {(B, T_ctl, CONTENT_LEN['bbox3d'])}")
         smp, keep = self._sampling(sampling or self.cfg, seeds if seeds is not None else [0] * B)
         self._check(self.lib.umgen_rollout(
             self._h, B, T_in, new_frames, cond_frames, _p64(arrs["pose"]), _p64(arrs["map"]), _p64(arrs["bbox3d"]),

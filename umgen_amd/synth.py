@@ -48,3 +48,11 @@ def synthetic_control(scene_id: int, n_frames: int = 30, slot: Optional[int] = 3
             box[0, t, slot, 10] = 1024
             attrs = np.clip(attrs + rng.integers(-3, 4, size=attrs.shape), 0, 1023)
     return {"pose": pose, "bbox3d": box.reshape(1, n_frames, -1)}
+
+
+def golden_init_tokens(scene_id: int, new_frames: int, control: int) -> Optional[Dict[str, np.ndarray]]:
+    """init_tokens of a recorded golden case (tests/golden/make_golden.py, meta[5]): 0 video, 1 pose + bbox3d control for every new
+    frame, 2 bbox3d-only control (the ego net infers the pose) for the first two new frames."""
+    if control == 2:
+        return {"bbox3d": synthetic_control(scene_id, n_frames=2)["bbox3d"]}
+    return synthetic_control(scene_id, n_frames=new_frames) if control else None
