@@ -247,7 +247,7 @@ constexpr int kTB = 15360;    // tile buffer of the variants (fits round 1's 144
 int g_attn_variant = 0;   // set by the bench
 
 template <int QT, int OPT>
-__global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+__global__ __launch_bounds__((OPT & 8192) ? 512 : 256) void attn_spatial_mfma2_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                                                  bf16_t* __restrict__ y, int S, int S_pad, int H, int nq, int npairs) {
     constexpr bool PERM = OPT & 1, ONES = OPT & 2, ALWAYS = OPT & 4, PER_T = OPT & 8, PRIO = OPT & 16;
     constexpr bool X_NOLOAD = OPT & 64, X_NOEXP = OPT & 128, X_NOBAR = OPT & 256, X_UNIF = OPT & 512, X_UNIFV = OPT & 1024;
@@ -256,6 +256,9 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
     // 4096: K / Vt tiles straight from global memory into the LDS images (global_load_lds_dwordx4, swizzles applied on the source
     // side, 16-byte chunk XOR for Vt as well): no staging registers, no ds_write pass
     constexpr bool GLDS = OPT & 4096;
+    // 8192: 8 waves (256 queries) per workgroup share the K / Vt tiles: half the staging traffic per query (GLDS staging only)
+    constexpr int NWV = (OPT & 8192) ? 8 : 4;
+    static_assert(NWV == 4 || GLDS, "the 8-wave form stages with global_load_lds");
     constexpr bool NEWK = (OPT & 2048) || GLDS;
     constexpr int kKStride = 144;   // (round 1's K rows, kept here for the A/B; shadows the namespace constant)
     constexpr int kKB = NEWK ? 64 * 128 : 64 * kKStride;   // timing experiments only (wrong results)
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
     const int f = pair / H, h = pair % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g = lane >> 4;
-    const int q0 = (qb * 4 + wave) * (QT * 16);
+    const int q0 = (qb * NWV + wave) * (QT * 16);
     const long ld = 2L * E;
     const bf16_t* qbase = qk + (long)f * S * ld + h * kHeadDim;
     const bf16_t* kbase = qbase + E;
@@ -317,8 +320,8 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
     // GLDS: 14 one-KB segments per tile (8 K rows or 8 Vt rows each); wave w issues segments w, w + 4, w + 8, w + 12
     auto issue = [&](int buf, int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int seg = wave + 4 * i;
+        for (int i = 0; i < (14 + NWV - 1) / NWV; ++i) {
+            const int seg = wave + NWV * i;
             if (seg < 14) {
                 unsigned char* dst = lds + buf * kTB + seg * 1024;
                 const int row = (seg < 8 ? 8 * seg : 8 * (seg - 8)) + (lane >> 3), pc = lane & 7;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma2_kernel(const bf16_t* _
             }
         }
     };
-    if (NEWK) {
+    if (NEWK && tid < 256) {
         const int buf = tid >> 7, r = (tid >> 1) & 63, sl = 6 + (tid & 1);   // chunks 6, 7 of every K row, both buffers
         *reinterpret_cast<uint4*>(lds + buf * kTB + r * 128 + ((sl ^ (2 * ((r >> 1) & 3))) << 4)) = make_uint4(0u, 0u, 0u, 0u);
     } else {
@@ -566,13 +569,17 @@ void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t
     const dim3 grid(pairs * nq), block(256);
 #ifdef UMGEN_ATTN_VARIANTS
 #define UMGEN_ATTN_CASE(OPT) \
-    case OPT: hipLaunchKernelGGL((attn_spatial_mfma2_kernel<QT, OPT>), grid, block, 0, s, qk, vt, y, S, S_pad, H, nq, F * H); return;
+    case OPT: { \
+        const int nw = ((OPT) & 8192) ? 8 : 4, nq2 = (S + nw * QT * 16 - 1) / (nw * QT * 16); \
+        hipLaunchKernelGGL((attn_spatial_mfma2_kernel<QT, OPT>), dim3(pairs * nq2), dim3(nw * 64), 0, s, qk, vt, y, S, S_pad, H, nq2, F * H); \
+        return; }
     switch (g_attn_variant) {
         UMGEN_ATTN_CASE(1) UMGEN_ATTN_CASE(2) UMGEN_ATTN_CASE(3) UMGEN_ATTN_CASE(7) UMGEN_ATTN_CASE(11) UMGEN_ATTN_CASE(15)
         UMGEN_ATTN_CASE(19) UMGEN_ATTN_CASE(23) UMGEN_ATTN_CASE(27) UMGEN_ATTN_CASE(31) UMGEN_ATTN_CASE(32)
         UMGEN_ATTN_CASE(71) UMGEN_ATTN_CASE(327) UMGEN_ATTN_CASE(135) UMGEN_ATTN_CASE(455) UMGEN_ATTN_CASE(967) UMGEN_ATTN_CASE(1479) UMGEN_ATTN_CASE(1991)
         UMGEN_ATTN_CASE(2048) UMGEN_ATTN_CASE(2051) UMGEN_ATTN_CASE(2055) UMGEN_ATTN_CASE(2503)
         UMGEN_ATTN_CASE(4096) UMGEN_ATTN_CASE(4099) UMGEN_ATTN_CASE(4103) UMGEN_ATTN_CASE(4107) UMGEN_ATTN_CASE(4115)
+        UMGEN_ATTN_CASE(12288) UMGEN_ATTN_CASE(12291) UMGEN_ATTN_CASE(12295)
         default: break;
     }
 #undef UMGEN_ATTN_CASE
