@@ -1594,6 +1594,10 @@ int umgen_destroy(umgen_engine* e) {
             for (int p = 0; p < 10; ++p) { fprintf(stderr, " %s %.2f", nm[p], (double)st[p] / 100.0 / (double)st[10]); tot += (double)st[p] / 100.0 / (double)st[10]; }
             fprintf(stderr, " (c_fc part %.2f)", (double)st[11] / 100.0 / (double)st[10]);
             fprintf(stderr, " | total %.2f\n", tot);
+            if (st[15])
+                fprintf(stderr, "[umgen] decode engine, prologue of a launch (%llu launches): kernel entry -> rank, step, epoch known %.2f us; kernel entry -> first item's q|k|v + parked mlp rows there %.2f us"
+                        "; kernel entry -> first item's x, LN weights and q|k|v rows there %.2f us\n", st[15], (double)st[12] / 100.0 / (double)st[15],
+                        (double)st[13] / 100.0 / (double)st[15], (double)st[14] / 100.0 / (double)st[15]);
         }
     }
     for (auto& row : e->step_graph)

@@ -80,6 +80,17 @@ struct Ctx {
     bool failed;
 };
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a release fence, and on gfx950 loads and stores share vmcnt: the
+// fence becomes s_waitcnt vmcnt(0), i.e. EVERY barrier drains the weight requests in flight -- harmless while they arrive during a
+// group's idle wait, but on an item that has none (a launch's first item; every item when a group runs a whole scene) the first
+// barrier of P1 waited for the whole 14 MB.  Nothing here needs global-memory ordering at a barrier: granules are self-validating
+// (tag + value in one 8-byte store) and the K/V rows written are read by later launches.
+__device__ inline void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // the workgroup gathers granules [0, n) of g into dst[0, n)
 template <int PER>
 __device__ inline void gather(Ctx& c, int tid, const u64* g, int n, u32 tag, float* dst) {
@@ -103,7 +114,7 @@ __device__ inline void gather(Ctx& c, int tid, const u64* g, int n, u32 tag, flo
             if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
         }
     }
-    __syncthreads();
+    wg_barrier();
 }
 
 // Pointers read out of the layer table are generic to the compiler (flat loads): cast them to the global address space.
@@ -205,26 +216,48 @@ __device__ inline float bf16_round(float v) { return bf16_to_f32(f32_to_bf16(v))
 
 }  // namespace
 
+#ifndef UMGEN_ENG_STAGGER_US
+#define UMGEN_ENG_STAGGER_US 10
+#endif
+constexpr int kStaggerTicks = UMGEN_ENG_STAGGER_US * 100;   // wall_clock64 ticks (100 MHz)
+
 // STAMPS: per-phase 100 MHz time stamps of (group 0, rank 0) into OarEngineArgs::stamps (UMGEN_DEBUG_TIMING); compiled out otherwise
 template <bool STAMPS>
 __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid0 = threadIdx.x;
+    const unsigned long long t_k0 = wall_clock64();   // 100 MHz
     // ---- who am I: group (XCD) and rank inside it ----
     const u32 xcc = xcc_id();
     const int g = a.xcc_group[xcc];
     if (g >= a.NG) return;   // (the census guarantees this never happens)
     if (tid0 == 0) reinterpret_cast<u32*>(lds + L_MISC)[0] = atomicAdd(a.ticket + g, 1u) & (u32)(CU - 1);
-    __syncthreads();
+    wg_barrier();
     const int w0 = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<u32*>(lds + L_MISC)[0]);
     Ctx c{a.err, false};
     const bool timer = STAMPS && a.stamps != nullptr && g == 0 && w0 == 0 && tid0 == 0;
     unsigned long long t_prev = 0;
+    unsigned long long t_entry = (STAMPS && timer) ? wall_clock64() : 0ull;
+    if (STAMPS && timer) a.stamps[12] += t_entry - t_k0;
+    bool first_item = true;
     auto stamp = [&](int p) {
-        if (STAMPS && timer) { const unsigned long long t = wall_clock64(); if (p >= 0) a.stamps[p] += t - t_prev; t_prev = t; }
+        if (STAMPS && timer) {
+            const unsigned long long t = wall_clock64();
+            if (p >= 0) a.stamps[p] += t - t_prev;
+            if (first_item) {
+                if (p == 0) { a.stamps[14] += t - t_k0; a.stamps[15] += 1; first_item = false; }   // kernel entry -> the first item's P1 can start
+            }
+            t_prev = t;
+        }
     };
     const int Lk = a.st->step;              // cached keys before this step == position of the new token
     const u32 ep = a.st->epoch;
+    if (STAMPS && timer) {
+        asm volatile("" ::"v"(Lk + (int)ep));   // (both loads have returned)
+        const unsigned long long t = wall_clock64();
+        a.stamps[12] += t - t_entry;
+        t_entry = t;
+    }
     const int R = a.R, D = a.D;
     const int rounds = (a.B + R - 1) / R;
     const int pipe = g / D, q = g % D;      // pipeline (scene slot of the round) and position in it
@@ -236,6 +269,13 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
         const int s = rd * R + pipe;
         if (s >= a.B) continue;
         for (int l = q; l < a.n_layers; l += D) {
+            // Launch-time stagger: every group would request its first layer's 14 MB at kernel entry -- 114 MB at once, HBM-bound, and
+            // the one stream that is on the critical path (group 0, layer 0: nothing to hide it behind) took 19 us instead of the
+            // 11 us of its XCD port.  Group q's first request waits q x UMGEN_ENG_STAGGER_US: its x is q layers away anyway.
+            if (rd == 0 && l == q && q > 0 && D > 1) {
+                const unsigned long long until = t_k0 + (unsigned long long)(q * kStaggerTicks);
+                while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+            }
             // Everything below is derived from these four values INSIDE the item: laundering them keeps the compiler from hoisting
             // ~100 VGPRs / SGPRs of loop-invariant addresses out of the layer loop (they spilled to scratch, on the critical path)
             int tid = tid0, w = w0, gl = g;
@@ -258,18 +298,35 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // for x (the other D - 1 groups are working); the mlp projection's follow once the attention has freed its registers
             u32x4_t* w2p = reinterpret_cast<u32x4_t*>(lds + L_W2) + tid;
             const bf16_t* wp2 = lw.Wp2 + (long)w * kEngWpUnits * NT * 8;
+            // A launch's first item (layer 0) has no idle wait to hide its 14 MB behind, and a wave's loads return in order: what it needs
+            // first is requested first -- x, the LN weights and biases, then the q|k|v rows -- so that P1 starts after ~6 MB of the
+            // stream instead of behind all of it (measured: 18 us from kernel entry to the start of P1 with the weights requested first).
+            float lnr[3];   // ln_1 | ln_2 weights (1536 floats over 512 threads), staged through LDS once x is here
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lnr[k] = ldg((tid + k * NT < E ? lw.ln_a : lw.ln_b - E) + tid + k * NT);
+            float bq = 0.f, bo = 0.f;
+            if (lane < RQ) bq = ldg(lw.bqkv + rowq + lane);
+            if (lane < RO) bo = ldg(lw.bo + rowo + lane);
+            float x_first[2] = {0.f, 0.f};
+            if (l == 0) {
+                x_first[0] = ldg(a.xdec + (long)s * E + tid);
+                if (tid + NT < E) x_first[1] = ldg(a.xdec + (long)s * E + tid + NT);
+            }
             {
                 u32x4_t wp[12];
+                req768(wq, lw.Wqkv, rowq, lane);
 #pragma unroll
                 for (int j = 0; j < 12; ++j) wp[j] = ldwu(wp2 + (long)j * NT * 8, (u32)tid * 8u);
-                req768(wq, lw.Wqkv, rowq, lane);
-                req768(wo, lw.Wo, rowo, lane);
-                req768(wf, lw.Wfc, rowf, lane);
+
                 // the first 12 units of the mlp c_proj slice (this thread's full row) are parked in LDS until P4 (the attention needs the
-                // registers); they were requested first, so this waits for them only -- the rest stays in flight (only this thread
-                // reads its parked units back).  Units 12..17 are requested once the attention has freed its registers.
+                // registers); only the q|k|v rows were requested before them, so this waits for those two -- the rest stays in flight
+                // (only this thread reads its parked units back).  Units 12..17 are requested once the attention has freed its registers.
 #pragma unroll
                 for (int j = 0; j < 12; ++j) w2p[j * NT] = wp[j];
+                // (the other two matrices only now: every wave's q|k|v and parked rows reach the memory system ahead of anybody's c_proj / c_fc rows)
+                req768(wo, lw.Wo, rowo, lane);
+                req768(wf, lw.Wfc, rowf, lane);
+                if (STAMPS && timer && first_item) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a.stamps[13] += wall_clock64() - t_k0; }
             }
             // attention geometry of this CU: head hh, half of the L + 1 keys, split in 8 wave spans of 8-key passes
             const int hh = w >> 1, half = w & 1;
@@ -286,8 +343,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // byte ranges, head-major cache) into the XCD's L2 meanwhile -- one dword per 128-byte line, default cache policy, issued
             // BEHIND the non-temporal weight requests so that the weight stream does not push them out again.  The attention's own
             // loads then hit the L2 (4.3 TB/s per XCD) instead of the fabric port (1.3 TB/s): K/V was 2.6 us of the layer at L = 1100.
+            // (Not on layer 0: a launch's first item has no idle wait, and the touch loop consumes its loads -- which return behind the whole
+            //  weight stream, a wave's loads being in order: P1 started 6.6 us late.)
             u32 touched = 0;
-            if (D > 1) {
+            if (D > 1 && l != 0) {
                 const int n_lines = ((kb - ka) * kHeadDim * 2 + 127) >> 7;
                 const char* k0p = reinterpret_cast<const char*>(kbase + (long)ka * kHeadDim);
                 const char* v0p = reinterpret_cast<const char*>(vbase + (long)ka * kHeadDim);
@@ -296,24 +355,18 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     touched ^= *(const UMGEN_GLOBAL u32*)(v0p + ((long)ln << 7));
                 }
             }
-            float lnr[3];   // ln_1 | ln_2 weights (1536 floats over 512 threads), staged through LDS once x is here
-#pragma unroll
-            for (int k = 0; k < 3; ++k) lnr[k] = ldg((tid + k * NT < E ? lw.ln_a : lw.ln_b - E) + tid + k * NT);
-            float bq = 0.f, bo = 0.f;
-            if (lane < RQ) bq = ldg(lw.bqkv + rowq + lane);
-            if (lane < RO) bo = ldg(lw.bo + rowo + lane);
             stamp(-1);
             // ================= P1: x -> LN -> q | k | v =================
             float* lnw = lds + L_LN;
             if (l == 0) {
-                for (u32 i = (u32)tid; i < (u32)E; i += NT) xs[i] = (a.xdec + (long)s * E)[i];
+                xs[tid] = x_first[0];
+                if (tid + NT < E) xs[tid + NT] = x_first[1];
             } else {
                 gather<2>(c, tid, D == 1 ? gxl : a.gx + (long)s * E, E, tg + 0, xs);
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) lnw[tid + k * NT] = lnr[k];
-            if (touched == 0x7ff00123u) lnw[0] = 0.f;   // (never true for bf16 K/V bit patterns XORed; keeps the prefetch loads alive)
-            __syncthreads();
+            wg_barrier();
             stamp(0);   // waited for x
 #ifndef UMGEN_ENG_NB
 #define UMGEN_ENG_NB 2
@@ -353,6 +406,9 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             }
             if (NB > 2 && k_lo + 16 * KP < k_hi) kv_req(NB > 2 ? 2 : 0, k_lo + 16 * KP);   // (the q|k|v rows' registers are free now)
             stamp(1);   // LN + q|k|v rows
+            // (never true for bf16 K/V bit patterns XORed; keeps the L2 touch loads alive.  Consumed HERE, not before P1: a wave's loads return
+            //  in order, so on a launch's first item the touches arrive behind the whole weight stream -- P1 waited 6.6 us for them)
+            if (touched == 0x7ff00123u) (lds + L_SM)[0] = 0.f;
             // ================= P2: attention of (head hh, half) =================
             {
                 // q_h | k_h | v_h of the new token
@@ -369,7 +425,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
                     }
                 }
-                __syncthreads();
+                wg_barrier();
                 stamp(2);   // waited for q_h | k_h | v_h
                 float q8[8];   // this lane's piece of q
 #pragma unroll
@@ -445,7 +501,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
 #pragma unroll
                     for (int e = 0; e < 8; ++e) so[gi * kHeadDim + piece * 8 + e] = o8[e];
                 }
-                __syncthreads();
+                wg_barrier();
                 {
                     // every wave recomputes the 64 merge weights (cheap), then thread (jg, d) folds 8 of the 64 partial rows of
                     // column d; 48 threads add the 8 folds in a fixed order and publish the half partial (m, l, o[48])
@@ -464,7 +520,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         }
                         fold[jg * kHeadDim + d] = o;
                     }
-                    __syncthreads();
+                    wg_barrier();
                     if (tid < kHeadDim) {
                         float o = 0.f;
 #pragma unroll
@@ -473,7 +529,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         put_local(gp, (u32)tid, tg + 2, o);
                         if (tid == 0) { put_local(gp, 48u, tg + 2, M); put_local(gp, 49u, tg + 2, Ls); }
                     }
-                    __syncthreads();   // fold (the gather buffer) is free again
+                    wg_barrier();   // fold (the gather buffer) is free again
                 }
             }
             stamp(3);   // attention of this CU's half
@@ -494,7 +550,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     const float Ls = fmaf(e1, p1[49], e0 * p0[49]);
                     as[col] = fmaf(e1, p1[d], e0 * p0[d]) / Ls;
                 }
-                __syncthreads();
+                wg_barrier();
                 f32x2_t x1[4], x2[4];
                 float out[RO];
                 load8p(as + lane * 8, x1);
@@ -525,7 +581,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 for (int r = 0; r < RF; ++r) v = (lane == r) ? out[r] : v;
                 if (lane < RF) hsl[wave * RF + lane] = gelu_erf(v);
             }
-            __syncthreads();
+            wg_barrier();
             stamp(11);  // LN + c_fc rows + GELU
             {
                 // thread t: all 96 columns of output row t (units 0..11, parked in LDS) + half of the columns of row 512 + (t & 255)
@@ -548,7 +604,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 const float yA = accA.x + accA.y;
                 float yB = accB.x + accB.y;
                 if (tid >= 256) hrow[tid - 256] = yB;
-                __syncthreads();
+                wg_barrier();
                 u64* mine = gpy + (long)w * E;
                 put_local(mine, (u32)tid, tg + 4, yA);
                 if (tid < 256) put_local(mine, 512u + (u32)tid, tg + 4, yB + hrow[tid]);
@@ -574,7 +630,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
                 }
             }
-            __syncthreads();
+            wg_barrier();
             stamp(8);   // waited for the partial sums
             if (tid < 24) {
                 float sum = 0.f;
