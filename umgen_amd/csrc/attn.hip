@@ -733,13 +733,16 @@ __global__ __launch_bounds__(HG * TMAX * 4) void attn_temporal_kernel(const T* _
             const float4 k4 = *reinterpret_cast<const float4*>(kp + d);
             a = fmaf(q[d], k4.x, a); a = fmaf(q[d + 1], k4.y, a); a = fmaf(q[d + 2], k4.z, a); a = fmaf(q[d + 3], k4.w, a);
         }
-        a += __shfl_xor(a, 1);
-        a += __shfl_xor(a, 2);
+        // the 4 lanes of a query are one DPP quad: quad_perm [1,0,3,2] / [2,3,0,1] (same sums as __shfl_xor 1 / 2, without the two
+        // dependent ds_bpermute round trips per key)
+        a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xf, 0xf, true));
+        a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xf, 0xf, true));
         if (tk <= tmax) {
             a *= kScale;
             const float mn = fmaxf(m, a);
-            const float alpha = expf(m - mn);
-            const float p = expf(a - mn);
+            // bf16 mode: hardware exp (as in the spatial kernel); fp32 parity mode keeps expf
+            const float alpha = sizeof(T) == 2 ? __expf(m - mn) : expf(m - mn);
+            const float p = sizeof(T) == 2 ? __expf(a - mn) : expf(a - mn);
             m = mn;
             l = l * alpha + p;
 #pragma unroll
@@ -775,7 +778,11 @@ void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int Tn, int 
     }
     if (H % 4 == 0) {
         const size_t shm = (size_t)T_ * 3 * 4 * kHeadDim * sizeof(float);
-        hipLaunchKernelGGL((attn_temporal_kernel<T, 4>), dim3((unsigned)((long)B * S * (H / 4))), dim3(4 * kTmax * 4), shm, s, qkv, y, Tn, S, H, tr);
+        // the evaluation window is 20 slots: with 20 query slots per head every lane of the 5 waves has a query (32 slots: 12 of 32 idle)
+        if (T_ <= 20)
+            hipLaunchKernelGGL((attn_temporal_kernel<T, 4, 20>), dim3((unsigned)((long)B * S * (H / 4))), dim3(4 * 20 * 4), shm, s, qkv, y, Tn, S, H, tr);
+        else
+            hipLaunchKernelGGL((attn_temporal_kernel<T, 4>), dim3((unsigned)((long)B * S * (H / 4))), dim3(4 * kTmax * 4), shm, s, qkv, y, Tn, S, H, tr);
     } else if (H % 2 == 0) {
         const size_t shm = (size_t)T_ * 3 * 2 * kHeadDim * sizeof(float);
         hipLaunchKernelGGL((attn_temporal_kernel<T, 2>), dim3((unsigned)((long)B * S * (H / 2))), dim3(2 * kTmax * 4), shm, s, qkv, y, Tn, S, H, tr);
