@@ -556,7 +556,7 @@ int enqueue_step(umgen_engine* e, int B, int mod, int ns, int ns_cached, const u
         fflush(dump);
     }
     SampleArgs sa{};
-    sa.st = e->d_state; sa.tb = e->tb; sa.logits = e->logits; sa.logits_tar = e->logits_tar; sa.ld_logits = 8192;
+    sa.st = e->d_state; sa.tb = e->tb; sa.logits = e->logits; sa.logits_tar = e->logits_tar; sa.ld_logits = 8192; sa.ld_tar = e->cfg.bbox3d_vocab;
     sa.cond = e->cond; sa.x_next = e->xdec; sa.tokens = e->d_tokens; sa.prev_box = e->d_prev_box; sa.control_slot = e->d_control;
     sa.boxes = e->d_boxes; sa.n_boxes = e->d_nboxes; sa.seeds = e->d_seeds; sa.forced = e->d_forced; sa.counters = e->d_counters;
     if (mod == 0) {
@@ -565,13 +565,8 @@ int enqueue_step(umgen_engine* e, int B, int mod, int ns, int ns_cached, const u
         const void* head = mod == 1 ? e->head_ar_map : (mod == 2 ? e->head_ar_box : e->head_ar_img);
         const int V = mod == 1 ? e->cfg.map_vocab : (mod == 2 ? e->cfg.bbox3d_vocab : e->cfg.img_vocab);
         gemv<T>(e, e->xdec, E, e->ln_oar, head, nullptr, V, E, B, GEMV_OUT_F32, e->logits, sa.ld_logits);
-        if (mod == 2) {   // head_tar_bbox3d on the conditioning row of this position (UMGen.py:1087,1103)
-            GemvArgs a{};
-            a.x = e->cond; a.ldx = (long)kSeq * E; a.d_xoff = &e->d_state->step; a.xoff_mul = E; a.W = e->head_tar_box;
-            a.N = V; a.K = E; a.M = B; a.out_mode = GEMV_OUT_F32; a.out = e->logits_tar; a.ldo = sa.ld_logits; a.E = E;
-            a.rows_per_block = rows_per_block_for(e, B);
-            launch_gemv<T>(st, a);
-        }
+        // (head_tar_bbox3d on the conditioning rows, UMGen.py:1087,1103: the rows do not depend on the decoded tokens, so all 660
+        //  positions were multiplied once before the loop -- tar_head_logits -- instead of one GEMV launch per bbox3d step)
         if (tr) {
             float* dst = mod == 1 ? tr->logits_map : (mod == 2 ? tr->logits_bbox3d : tr->logits_image);
             const int k = mod == 1 ? j - kMapC0 : (mod == 2 ? j - kBoxC0 : j - kImgC0);
@@ -787,6 +782,13 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     st = dec;
     e->stream = dec;
     launch_first_input(st, B, E, e->tb.tske + (long)e->cfg.task_id * E, e->cond, e->xdec);
+    {   // tar_head_logits: logits_tar[b][k][:] = head_tar_bbox3d . cond[b][kBoxC0 + k][:]  (exact fp32 FMA chain, bf16 or fp32 weights)
+        GemmArgs g{};
+        g.P = e->head_tar_box; g.Q = e->cond + (long)kBoxC0 * E; g.Mi = e->cfg.bbox3d_vocab; g.Nj = kNBox; g.K = E; g.ldp = E; g.ldq = E;
+        g.strideP = 0; g.strideQ = (long)kSeq * E; g.batch = B; g.mode = GEMM_STORE_F32; g.out = e->logits_tar; g.ldo = e->cfg.bbox3d_vocab;
+        g.strideO = (long)kNBox * e->cfg.bbox3d_vocab;
+        launch_gemm_valu<T, float>(st, g);
+    }
     if (ov_active && io.next_follows) {
         const auto tp0 = std::chrono::steady_clock::now();
         if (int rc = launch_prefix<T>(e, io, ego)) return rc;
@@ -1192,7 +1194,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (int rc = dalloc(e, &e->kvnew, Bm * 2 * E)) return rc;
     if (int rc = dalloc(e, &e->hdec, 3 * Bm * 4 * E)) return rc;
     if (int rc = dalloc(e, &e->logits, 3 * Bm * 8192)) return rc;
-    if (int rc = dalloc(e, &e->logits_tar, Bm * 8192)) return rc;
+    if (int rc = dalloc(e, &e->logits_tar, Bm * kNBox * (size_t)cfg->bbox3d_vocab)) return rc;
     e->kv_scene_stride = (long)e->Lmax * 2 * E;
     e->kv_layer_stride = (long)Bm * e->kv_scene_stride;
     if (int rc = dev_alloc(e, &e->kvcache, (size_t)cfg->n_oar_layer * e->kv_layer_stride * e->tsz)) return rc;

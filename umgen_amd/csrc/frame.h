@@ -59,8 +59,9 @@ struct SampleArgs {
     OarState* st;
     EmbedTables tb;
     const float* logits;       // [B][ld_logits] current AR head
-    const float* logits_tar;   // [B][ld_logits] head_tar_bbox3d on the conditioning row (bbox3d steps only)
+    const float* logits_tar;   // [B][660][ld_tar] head_tar_bbox3d on the conditioning rows of the 660 bbox3d positions (one GEMM per frame)
     int ld_logits;
+    int ld_tar;
     int vocab;                 // vocab of the current AR head
     int mod;                   // 1 map, 2 bbox3d, 3 image
     const float* cond;         // [B][2207][E]

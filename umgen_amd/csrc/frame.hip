@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
     else { off = kOffImg; k = j - kImgC0; }
     int* toks = a.tokens + (long)b * kTokPerFrame;
     if (a.mod == 2) {
-        const float* lt = a.logits_tar + (long)b * a.ld_logits;
+        const float* lt = a.logits_tar + ((long)b * kNBox + k) * a.ld_tar;
         const int prev = a.prev_box[(long)b * kNBox + k];
         if (use_control) {   // UMGen.py:1083-1089
             const int object_id = (pos1 - 1032) / kSlotLen;
