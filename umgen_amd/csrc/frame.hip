@@ -261,10 +261,14 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
         const float cv = sh.cand_v[lane];
         const int ci = sh.cand_i[lane];
         int rank = 0;
-        for (int j = 0; j < 4 * kMaxK; ++j) {
+        // only the kk real candidates of each wave (the other slots hold -inf and precede nobody): slot j = 16 (j / kk) + j % kk
+        const int ncand = 4 * kk;
+        for (int jj = 0, w4 = 0, it = 0; jj < ncand; ++jj) {
+            const int j = w4 * kMaxK + it;
             const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j));
             const int oi = __builtin_amdgcn_readlane(ci, j);
             rank += (ov > cv || (ov == cv && oi < ci)) ? 1 : 0;
+            if (++it == kk) { it = 0; ++w4; }
         }
         if (rank == kk - 1) sh.kth = cv;   // exactly one lane (ranks are a permutation)
     }
