@@ -33,7 +33,9 @@ enum {
     UMGEN_E_UNSUPPORTED = -5
 };
 
-enum { UMGEN_PREC_FP32 = 0, UMGEN_PREC_BF16 = 1 };
+/* FP32: exact-fp32 parity mode.  BF16: bf16 weights / operands / KV cache (the bench mode, BASELINE.json configs[1]).
+ * FP16: the same kernels with IEEE-half operands -- the reference's own arithmetic (torch.cuda.amp.autocast fp16, UMGen.py:1604-1605) */
+enum { UMGEN_PREC_FP32 = 0, UMGEN_PREC_BF16 = 1, UMGEN_PREC_FP16 = 2 };
 enum { UMGEN_DT_F32 = 0, UMGEN_DT_BF16 = 1, UMGEN_DT_F16 = 2, UMGEN_DT_F64 = 3 };
 enum { UMGEN_SAMPLE_TOPK = 0, UMGEN_SAMPLE_TOPP = 1 };
 
@@ -102,7 +104,8 @@ typedef struct umgen_timings {
                              * 5 x n_oar_layer launches of the five-launch form (when profiling enabled; HIP events on the decode stream) */
     int64_t layers_launches; /* decode steps timed that way */
     int32_t decode_engine;  /* 1 when the last frame's decode steps ran on the XCD-resident decode engine */
-    int32_t reserved;
+    int32_t engine_fallback; /* 1 when this configuration would use the decode engine (16-bit mode, n_embd 768) but its census failed at
+                              * umgen_create: the five-launch decode layer runs instead (a warning is printed at create) */
 } umgen_timings;
 
 /* UMGen(config)  -- UMGen.py:53 */

@@ -26,14 +26,21 @@ Modes
   * ``weight_dtype="bf16_engine"`` : the rounding-aware restatement of the engine's production (bf16) mode: bf16
     weights AND a round-to-bf16 at every point where libumgen_hip stores or feeds a bf16 value --
       TAR / ego-TAR sub-blocks (gemm.hip / attn.hip): the LayerNorm output that becomes the GEMM A operand, the q | k | v rows,
-      the softmax probabilities that feed the P.V MFMA of the SPATIAL attention (the row sum keeps the unrounded fp32
-      values), the attention output, the GELU output; accumulation and the residual stream stay fp32;
+      the softmax probabilities that feed the P.V MFMA of the SPATIAL attention (64-key tiles, rounded relative to the running
+      maximum of the online softmax; the row sum keeps the unrounded fp32 values), the attention output, the GELU output; accumulation and the residual stream stay fp32;
       ego decoder (engine.hip run_ego): ln_3(p) and the cross-attention k | v rows;
       OAR decode (gemv.hip / oar_engine.hip): only the K/V cache rows (incl. the new token's); activations stay fp32.
     Everything else (embeddings, LayerNorm statistics, softmax, heads, samplers) is fp32 like the reference (module.py:34-37
     keeps LayerNorm in fp32 inside the autocast region of UMGen.py:1604-1605).  What this mode cannot reproduce is the ORDER
     of fp32 accumulation inside the MFMA tiles and the online-softmax rescaling, so the comparison is a tolerance, stated in
     the tests, not bit equality.  The fp32 mode is untouched by it (pinned by tests/test_oracle.py on the reference goldens).
+  * ``weight_dtype="fp16"`` / ``"fp16_engine"`` : the same two restatements with IEEE half instead of bfloat16 (the engine's
+    UMGEN_PREC_FP16 mode; the reference's own deployment arithmetic is torch.cuda.amp.autocast fp16, UMGen.py:1604-1605).
+
+``perm_seed`` (accumulation-order ensemble): with a seed, every F.linear sums its K dimension in a seeded random order and every
+attention sums its keys in a seeded random order -- mathematically the same function, another order of the fp32 additions.  The
+spread of an ensemble of such runs is the noise floor any implementation with yet another summation order (the MFMA tiles, the
+engine's split softmax) sits in: tests/golden/make_ensemble.py records it and the -m gpu tests bound the engine by it.
 """
 from __future__ import annotations
 
@@ -214,9 +221,14 @@ def _bf16(x: torch.Tensor) -> torch.Tensor:
     return x.bfloat16().float()
 
 
-def _attention(q, k, v, n_head: int, causal: bool, round_p: bool = False) -> torch.Tensor:
+def _fp16(x: torch.Tensor) -> torch.Tensor:
+    return x.half().float()
+
+
+def _attention(q, k, v, n_head: int, causal: bool, round_p=None, perm: Optional[torch.Tensor] = None) -> torch.Tensor:
     """flash_attn_func as called at module.py:218-225 / 497-504 (third-party; semantics fixed in the header).
-    round_p: the engine's spatial attention feeds bf16 probabilities to the P.V MFMA and divides by the fp32 row sum."""
+    round_p: the engine's spatial attention feeds 16-bit probabilities (rounded by this function) to the P.V MFMA and divides by
+    the fp32 row sum.  perm: order in which the keys are summed (accumulation-order ensemble)."""
     B, Tq, C = q.shape
     Tk = k.shape[1]
     D = C // n_head
@@ -229,25 +241,45 @@ def _attention(q, k, v, n_head: int, causal: bool, round_p: bool = False) -> tor
         i = torch.arange(Tq).view(-1, 1)
         j = torch.arange(Tk).view(1, -1)
         att = att.masked_fill(j > i + (Tk - Tq), float("-inf"))
-    if round_p:
-        e = torch.exp(att - att.amax(dim=-1, keepdim=True))
-        return ((_bf16(e) @ vh) / e.sum(dim=-1, keepdim=True)).permute(0, 2, 1, 3).reshape(B, Tq, C)
+    if perm is not None:
+        att, vh = att[..., perm], vh[:, :, perm]
+    if round_p is not None:
+        # the engine's spatial attention (attn.hip): 64-key tiles, online softmax -- the probabilities are rounded to 16 bits RELATIVE
+        # TO THE RUNNING MAXIMUM of their tile (that is what feeds the P.V MFMA), the row sum keeps the unrounded fp32 values and the
+        # fp32 accumulator is rescaled when the maximum moves.  Which value gets which rounding error depends on the key order, so
+        # this (not a one-shot softmax) is the form whose accumulation-order ensemble shows the engine's real noise floor.
+        m = torch.full(att.shape[:-1] + (1,), float("-inf"))
+        l = torch.zeros_like(m)
+        o = torch.zeros(att.shape[:-1] + (D,))
+        for t0 in range(0, Tk, 64):
+            st = att[..., t0:t0 + 64]
+            m_new = torch.maximum(m, st.amax(dim=-1, keepdim=True))
+            alpha = torch.exp(m - m_new)
+            pt = torch.exp(st - m_new)
+            l = l * alpha + pt.sum(dim=-1, keepdim=True)
+            o = o * alpha + round_p(pt) @ vh[:, :, t0:t0 + 64]
+            m = m_new
+        return (o / l).permute(0, 2, 1, 3).reshape(B, Tq, C)
     att = torch.softmax(att, dim=-1)
     return (att @ vh).permute(0, 2, 1, 3).reshape(B, Tq, C)
 
 
 class OracleUMGen:
-    def __init__(self, cfg: RolloutConfig, state_dict: Dict[str, np.ndarray], weight_dtype: str = "fp32"):
+    def __init__(self, cfg: RolloutConfig, state_dict: Dict[str, np.ndarray], weight_dtype: str = "fp32", perm_seed: Optional[int] = None):
         self.cfg = cfg
+        assert weight_dtype in ("fp32", "bf16", "bf16_engine", "fp16", "fp16_engine"), weight_dtype
+        self._round = _fp16 if weight_dtype.startswith("fp16") else _bf16
+        self._perm_gen = torch.Generator().manual_seed(perm_seed) if perm_seed is not None else None
+        self._perms: Dict[int, torch.Tensor] = {}
         self.w: Dict[str, torch.Tensor] = {}
         for k, v in state_dict.items():
             t = torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v
             if t.dtype != torch.bfloat16:
                 t = t.float()
-                if weight_dtype in ("bf16", "bf16_engine") and t.dim() >= 2:
-                    t = t.bfloat16().float()
+                if weight_dtype != "fp32" and t.dim() >= 2:
+                    t = self._round(t)
             self.w[k] = t
-        self.engine_rounding = weight_dtype == "bf16_engine"
+        self.engine_rounding = weight_dtype.endswith("_engine")
         E = cfg.n_embd
         # UMGen.py:137-153 (tables may be overridden by checkpoint entries, UMGen.py:257-261)
         self.fouier_pe = self.w.get("fouier_pe", position_encoding_init(1024, E)).bfloat16()
@@ -265,15 +297,27 @@ class OracleUMGen:
 
     # ---- primitives (module.py) -------------------------------------------------------------
     def _r(self, x):
-        """bf16 round trip at the engine's bf16 storage points (bf16_engine mode only)."""
-        return _bf16(x) if self.engine_rounding else x
+        """16-bit round trip at the engine's 16-bit storage points (bf16_engine / fp16_engine modes only)."""
+        return self._round(x) if self.engine_rounding else x
+
+    def _perm(self, n: int) -> Optional[torch.Tensor]:
+        """Summation order of an n-term reduction (None: natural order).  One fixed permutation per length and oracle instance."""
+        if self._perm_gen is None or n < 2:
+            return None
+        if n not in self._perms:
+            self._perms[n] = torch.randperm(n, generator=self._perm_gen)
+        return self._perms[n]
 
     def _ln(self, x, key):  # module.py:26-37: weight only, eps 1e-5
         w = self.w[key + ".weight"]
         return F.layer_norm(x, w.shape, w, None, 1e-5)
 
     def _lin(self, x, key, bias=True):
-        return F.linear(x, self.w[key + ".weight"], self.w.get(key + ".bias") if bias else None)
+        w = self.w[key + ".weight"]
+        pm = self._perm(w.shape[1])
+        if pm is not None:
+            x, w = x[..., pm], w[:, pm]
+        return F.linear(x, w, self.w.get(key + ".bias") if bias else None)
 
     def _mlp(self, x, key, tar=False):  # module.py:233-250 (exact erf GELU, no bias)
         h = F.gelu(self._lin(x, key + ".c_fc", bias=False))
@@ -291,7 +335,8 @@ class OracleUMGen:
         if kv is not None and kv[0] is not None:
             k = torch.cat([kv[0], k], dim=1)
             v = torch.cat([kv[1], v], dim=1)
-        y = _attention(q, k, v, self.cfg.n_head, causal, round_p=self.engine_rounding and site == "tar_spatial")
+        y = _attention(q, k, v, self.cfg.n_head, causal, round_p=self._round if (self.engine_rounding and site == "tar_spatial") else None,
+                       perm=self._perm(k.shape[1]))
         if site in ("tar_spatial", "tar_temporal"):
             y = self._r(y)
         return self._lin(y, key + ".c_proj"), (k, v)
@@ -325,7 +370,7 @@ class OracleUMGen:
         q = self._lin(qn, key + ".cross_attn.q_attn")
         k = self._r(self._lin(pn, key + ".cross_attn.k_attn"))
         v = self._r(self._lin(pn, key + ".cross_attn.v_attn"))
-        y = _attention(q, k, v, self.cfg.n_head, False)
+        y = _attention(q, k, v, self.cfg.n_head, False, perm=self._perm(k.shape[1]))
         x = x + self._lin(y, key + ".cross_attn.c_proj")
         return x + self._mlp(self._ln(x, key + ".ln_4"), key + ".mlp1")
 
@@ -458,7 +503,7 @@ class OracleUMGen:
             ego = init["pose"]
         else:
             e = self.forward_ego_net(inputs)                              # [1,3,C]
-            lg = F.linear(e, self.w["transformer.head_ego.weight"])[0]      # [3,1024]
+            lg = self._lin(e, "transformer.head_ego", bias=False)[0]      # [3,1024]
             if tr is not None:
                 tr.setdefault("ego_logits", []).append(lg.numpy().copy())
             toks = []
@@ -522,7 +567,7 @@ class OracleUMGen:
                 nxt = axe[d_pos[pos]][None, None]
             else:
                 mod = next(m for m in MOD_ORDER if MOD_START[m] + 1 <= pos <= MOD_START[m] + TOKEN_LEN[m])
-                lg = F.linear(h[0, 0], w[f"transformer.{head[mod]}.weight"])
+                lg = self._lin(h[0, 0], f"transformer.{head[mod]}", bias=False)
                 if logit_trace is not None:
                     logit_trace[mod].append(lg.numpy().copy())
                 u = rng_uniform(seed, frame_idx, pos, DRAW_MAIN)
@@ -559,13 +604,13 @@ class OracleUMGen:
         if control_slots is not None:
             object_id = (pos - 1032) // SLOT_LEN                 # UMGen.py:1084 (category token -> next slot id)
             if object_id in control_slots:
-                lt = F.linear(cond_row, w["transformer.head_tar_bbox3d.weight"]).clone()
+                lt = self._lin(cond_row, "transformer.head_tar_bbox3d", bias=False).clone()
                 lt[-1] = float("-inf")
                 self._count("control_resample")
                 tok = self.sample(lt, cfg.top_k, cfg.p, rng_uniform(seed, frame_idx, pos, DRAW_CONTROL))
         if tok == BBOX_PAD and cfg.merage_ar_tar and int(prev_box[k]) != BBOX_PAD and not cfg.only_ar:
             self._count("pad_avoid")
-            lt = F.linear(cond_row, w["transformer.head_tar_bbox3d.weight"])            # UMGen.py:1092-1104
+            lt = self._lin(cond_row, "transformer.head_tar_bbox3d", bias=False)            # UMGen.py:1092-1104
             tok = self.sample(lt, cfg.top_k, cfg.p, rng_uniform(seed, frame_idx, pos, DRAW_PAD_AVOID))
         return tok
 

@@ -32,12 +32,15 @@ def config(width: str = "full_width", **over):
     return tiny_config(n_embd=E, n_head=H, rule_constrain=False, **over).greedy()
 
 
-def main(width: str = "full_width"):
+def main(width: str = "full_width", modes=("fp32", "bf16_engine")):
     cfg = config(width)
     sd = synthetic_state_dict(cfg, seed=WEIGHT_SEED)
     scene = synthetic_scene(SCENE_ID, n_frames=2)
     forced = None
-    for mode in ("fp32", "bf16_engine"):
+    if "fp32" not in modes:      # teacher forcing always uses the committed fp32 oracle's greedy tokens
+        g = np.load(os.path.join(ROOT, "tests", "golden", f"{width}_fp32.npz"))
+        forced = {m: g[f"tok_{m}"].astype(np.int64)[None] for m in MOD_ORDER}
+    for mode in modes:
         o = OracleUMGen(cfg, sd, weight_dtype=mode)
         ref = o.inference(1, 3, scene, input_cond_frames=2, trace=True, seed=0, forced=forced)
         if forced is None:
@@ -59,5 +62,7 @@ def main(width: str = "full_width"):
 
 
 if __name__ == "__main__":
-    for w in (sys.argv[1:] or ["full_width", "wide2x"]):
-        main(w)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    only = [a[7:] for a in sys.argv[1:] if a.startswith("--mode=")]
+    for w in (args or ["full_width", "wide2x"]):
+        main(w, tuple(only) if only else ("fp32", "bf16_engine"))

@@ -4,7 +4,10 @@ import numpy as np
 import pytest
 import torch
 
-from tests.gpu_util import bf16_bits, bf16_round, check, fp, from_bits, lib, vp
+from tests.gpu_util import bits16, check, fp, from_bits16, lib, round16, vp
+
+PREC = [0, 1, 2]          # fp32 | bf16 | fp16 operands (precision code of the debug hooks)
+EPS16 = {1: 1.0, 2: 0.125}   # 16-bit tolerances are quoted for bf16 (8 mantissa bits); fp16 has 11
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +29,7 @@ def ref_linear(act, W, bias, gelu, resid):
                                                (8300, 768, 768, 0, 1), (8448, 2304, 768, 0, 0), (9000, 1536, 3072, 1, 0),
                                                # >= 1024 output tiles: the persistent kernel (ragged last token tile, every epilogue)
                                                (22001, 768, 768, 0, 1), (12000, 3072, 768, 1, 0), (11003, 768, 3072, 0, 1)])
-@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("bf16", PREC)
 def test_linear(bf16, R, N, K, gelu, resid):
     rng = np.random.default_rng(R + N + K)
     act = rng.standard_normal((R, K), dtype=np.float32)
@@ -34,17 +37,44 @@ def test_linear(bf16, R, N, K, gelu, resid):
     bias = rng.standard_normal((N,), dtype=np.float32) * 0.1
     x0 = rng.standard_normal((R, N), dtype=np.float32) if resid else None
     if bf16:
-        a_in, w_in = bf16_bits(act), bf16_bits(W)
-        act, W = bf16_round(act), bf16_round(W)
+        a_in, w_in = bits16(act, bf16), bits16(W, bf16)
+        act, W = round16(act, bf16), round16(W, bf16)
     else:
         a_in, w_in = act, W
     out = x0.copy() if resid else np.zeros((R, N), dtype=np.uint16 if bf16 else np.float32)
     check(lib().umgen_dbg_linear(bf16, vp(a_in), vp(w_in), fp(bias), R, N, K, gelu, resid, vp(out)))
-    got = out if (resid or not bf16) else from_bits(out)
+    got = out if (resid or not bf16) else from_bits16(out, bf16)
     ref = ref_linear(act, W, bias, gelu, x0)
     # fp32 path: summation-order noise only; bf16 path: exact products, fp32 accumulate, (bf16 output rounding when stored)
-    tol = 2e-5 if not bf16 else (2e-5 if resid else 1.2e-2)
+    tol = 2e-5 if not bf16 else (2e-5 if resid else 1.2e-2 * EPS16[bf16])
     np.testing.assert_allclose(got, ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)
+
+
+@pytest.mark.parametrize("R,N,K,gelu,resid", [(2207, 768, 768, 0, 1), (8300, 768, 768, 0, 1), (8448, 2304, 768, 0, 0), (9000, 1536, 3072, 1, 0),
+                                               (600, 256, 128, 0, 0), (5000, 3072, 768, 1, 0), (257, 768, 3072, 0, 1), (70000, 768, 768, 0, 1),
+                                               (3000, 512, 256, 0, 0)])
+@pytest.mark.parametrize("prec", [1, 2])
+def test_linear_256_tile_kernel(prec, R, N, K, gelu, resid):
+    """gemm256.hip (256 x 256 x 64 tiles, 8-slot LDS ring, one counted wait per k-tile) forced on shapes the launcher would give to
+    the 128-tile kernels too: ragged token counts, the shortest legal K (two k-tiles), many tiles per workgroup (the ring runs on
+    across output tiles), every epilogue.  Bit-identical to the 128-tile kernels (same k order inside and across the MFMAs)."""
+    rng = np.random.default_rng(R + N + K)
+    act = rng.standard_normal((R, K), dtype=np.float32)
+    W = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal((N,), dtype=np.float32) * 0.1
+    x0 = rng.standard_normal((R, N), dtype=np.float32) if resid else None
+    a_in, w_in = bits16(act, prec), bits16(W, prec)
+    act, W = round16(act, prec), round16(W, prec)
+    outs = []
+    for flag in (16, 32):      # 16: force the 256-tile kernel, 32: 128-tile kernels only
+        out = x0.copy() if resid else np.zeros((R, N), dtype=np.uint16)
+        check(lib().umgen_dbg_linear(prec | flag, vp(a_in), vp(w_in), fp(bias), R, N, K, gelu, resid, vp(out)))
+        outs.append(out)
+    got = outs[0] if resid else from_bits16(outs[0], prec)
+    ref = ref_linear(act, W, bias, gelu, x0)
+    tol = 2e-5 if resid else 1.2e-2 * EPS16[prec]
+    np.testing.assert_allclose(got, ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)
+    np.testing.assert_array_equal(outs[0], outs[1])
 
 
 def ref_attention(q, k, v, H, causal):
@@ -63,7 +93,7 @@ def ref_attention(q, k, v, H, causal):
 
 
 @pytest.mark.parametrize("F,S,H", [(2, 2207, 16), (3, 1031, 2), (1, 70, 2), (2, 1693, 4)])
-@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("bf16", PREC)
 def test_attn_spatial(bf16, F, S, H):
     E = H * 48
     rng = np.random.default_rng(S + H)
@@ -71,55 +101,55 @@ def test_attn_spatial(bf16, F, S, H):
     k = rng.standard_normal((F, S, E), dtype=np.float32) * 1.5
     v = rng.standard_normal((F, S, E), dtype=np.float32)
     if bf16:
-        q, k, v = bf16_round(q), bf16_round(k), bf16_round(v)
+        q, k, v = round16(q, bf16), round16(k, bf16), round16(v, bf16)
     qk = np.ascontiguousarray(np.concatenate([q, k], axis=-1))
     y = np.zeros((F, S, E), dtype=np.uint16 if bf16 else np.float32)
-    check(lib().umgen_dbg_attn_spatial(bf16, vp(bf16_bits(qk) if bf16 else qk), vp(bf16_bits(v) if bf16 else v), F, S, H, vp(y)))
-    got = from_bits(y) if bf16 else y
+    check(lib().umgen_dbg_attn_spatial(bf16, vp(bits16(qk, bf16) if bf16 else qk), vp(bits16(v, bf16) if bf16 else v), F, S, H, vp(y)))
+    got = from_bits16(y, bf16) if bf16 else y
     ref = ref_attention(q, k, v, H, False)
-    np.testing.assert_allclose(got, ref, atol=(2e-2 if bf16 else 2e-5), rtol=0)
+    np.testing.assert_allclose(got, ref, atol=(2e-2 * EPS16[bf16] if bf16 else 2e-5), rtol=0)
 
 
 @pytest.mark.parametrize("B,T,S,H", [(1, 20, 333, 16), (2, 3, 100, 2), (1, 40, 77, 4), (1, 64, 31, 2)])
-@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("bf16", PREC)
 def test_attn_temporal(bf16, B, T, S, H):
     E = H * 48
     rng = np.random.default_rng(T + S)
     qkv = rng.standard_normal((B, T, S, 3 * E), dtype=np.float32)
     if bf16:
-        qkv = bf16_round(qkv)
+        qkv = round16(qkv, bf16)
     y = np.zeros((B, T, S, E), dtype=np.uint16 if bf16 else np.float32)
-    bits = bf16_bits(qkv) if bf16 else qkv
+    bits = bits16(qkv, bf16) if bf16 else qkv
     check(lib().umgen_dbg_attn_temporal(bf16, vp(bits), B, T, S, H, 0, vp(y)))
     # slots 0..T-2 ahead of time, the last slot against the slot cache (the rollout's overlapped TAR pass): same bits
     y2 = np.zeros_like(y)
     check(lib().umgen_dbg_attn_temporal(bf16, vp(bits), B, T, S, H, T - 1, vp(y2)))
     np.testing.assert_array_equal(y2, y)
-    got = from_bits(y) if bf16 else y
+    got = from_bits16(y, bf16) if bf16 else y
     x = qkv.transpose(0, 2, 1, 3).reshape(B * S, T, 3 * E)        # (b s) t c
     ref = ref_attention(np.ascontiguousarray(x[..., :E]), np.ascontiguousarray(x[..., E:2 * E]),
                         np.ascontiguousarray(x[..., 2 * E:]), H, True)
     ref = ref.reshape(B, S, T, E).transpose(0, 2, 1, 3)
-    np.testing.assert_allclose(got, ref, atol=(1.6e-2 if bf16 else 2e-5), rtol=0)
+    np.testing.assert_allclose(got, ref, atol=(1.6e-2 * EPS16[bf16] if bf16 else 2e-5), rtol=0)
 
 
 @pytest.mark.parametrize("NQ,L,H", [(1, 1, 16), (1, 7, 16), (3, 2207, 16), (2, 1100, 2)])
-@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("bf16", PREC)
 def test_attn_decode(bf16, NQ, L, H):
     E = H * 48
     rng = np.random.default_rng(L)
     q = rng.standard_normal((NQ, E), dtype=np.float32)
     kv = rng.standard_normal((L, 2 * E), dtype=np.float32)
     if bf16:
-        kv = bf16_round(kv)
+        kv = round16(kv, bf16)
     y = np.zeros((NQ, E), dtype=np.float32)
-    check(lib().umgen_dbg_attn_decode(bf16, fp(q), vp(bf16_bits(kv) if bf16 else kv), NQ, L, H, fp(y)))
+    check(lib().umgen_dbg_attn_decode(bf16, fp(q), vp(bits16(kv, bf16) if bf16 else kv), NQ, L, H, fp(y)))
     ref = ref_attention(q[None], np.ascontiguousarray(kv[None, :, :E]), np.ascontiguousarray(kv[None, :, E:]), H, False)[0]
     np.testing.assert_allclose(y, ref, atol=2e-5, rtol=0)
 
 
 @pytest.mark.parametrize("M,N,K,gelu,ln", [(1, 2304, 768, 0, 1), (3, 3072, 768, 1, 1), (8, 1028, 768, 0, 0), (11, 96, 96, 0, 1)])
-@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("bf16", PREC)
 def test_gemv(bf16, M, N, K, gelu, ln):
     rng = np.random.default_rng(M + N)
     x = rng.standard_normal((M, K), dtype=np.float32) * 2 + 0.3
@@ -127,9 +157,9 @@ def test_gemv(bf16, M, N, K, gelu, ln):
     lw = (1 + 0.1 * rng.standard_normal((K,), dtype=np.float32)).astype(np.float32)
     bias = rng.standard_normal((N,), dtype=np.float32) * 0.1
     if bf16:
-        W = bf16_round(W)
+        W = round16(W, bf16)
     out = np.zeros((M, N), dtype=np.float32)
-    check(lib().umgen_dbg_gemv(bf16, fp(x), fp(lw) if ln else None, vp(bf16_bits(W) if bf16 else W), fp(bias), M, N, K, gelu, fp(out)))
+    check(lib().umgen_dbg_gemv(bf16, fp(x), fp(lw) if ln else None, vp(bits16(W, bf16) if bf16 else W), fp(bias), M, N, K, gelu, fp(out)))
     xin = torch.from_numpy(x).double()
     if ln:
         xin = torch.nn.functional.layer_norm(xin, (K,), torch.from_numpy(lw).double(), None, 1e-5)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <thread>
 #include <unistd.h>
 #include <vector>
@@ -13,10 +14,14 @@ __global__ void census(unsigned* cnt) {
     if (threadIdx.x == 0) atomicAdd(cnt + (x & 15u), 1u);
 }
 int main(int argc, char** argv) {
-    const unsigned xcd_bits = argc > 1 ? strtoul(argv[1], nullptr, 0) : 0xF0u;   // which XCDs to enable
+    // cumask_probe <xcd_bits>        strided mask: bit i set when XCD (i % 8) is in xcd_bits  (0xF0 = "XCDs 4..7 only")
+    // cumask_probe contig <n>        contiguous mask: bits 0 .. n-1
+    const bool contig = argc > 2 && !strcmp(argv[1], "contig");
+    const unsigned xcd_bits = contig ? strtoul(argv[2], nullptr, 0) : (argc > 1 ? strtoul(argv[1], nullptr, 0) : 0xF0u);
     std::vector<uint32_t> mask(8, 0u);
     for (int i = 0; i < 256; ++i)
-        if ((xcd_bits >> (i % 8)) & 1u) mask[i / 32] |= 1u << (i % 32);
+        if (contig ? (unsigned)i < xcd_bits : ((xcd_bits >> (i % 8)) & 1u)) mask[i / 32] |= 1u << (i % 32);
+    printf("%s mask, argument %u: ", contig ? "contiguous" : "strided", xcd_bits);
     hipStream_t s;
     if (hipExtStreamCreateWithCUMask(&s, 8, mask.data()) != hipSuccess) { printf("mask refused\n"); return 2; }
     unsigned* d;

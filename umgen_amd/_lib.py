@@ -14,13 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # UMGEN_LIB_PATH selects an alternative build of the SAME library (kernel experiments with extra -D flags); never a fallback
 LIB_PATH = os.environ.get("UMGEN_LIB_PATH") or os.path.join(HERE, "libumgen_hip.so")
-SOURCES = ["engine.hip", "gemm.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "debug_api.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "debug_api.hip"]
 EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen_rollout", "umgen_frame",
            "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",
            "umgen_tokenize_ego", "umgen_detokenize_ego", "umgen_tokenize_boxes", "umgen_detokenize_boxes",
            "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench", "umgen_dbg_oar_step"]
 
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_FP16 = 0, 1, 2
 DT_F32, DT_BF16, DT_F16, DT_F64 = 0, 1, 2, 3
 
 
@@ -54,7 +54,7 @@ class Timings(C.Structure):
                 ("gemm_ms", C.c_double), ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("oar_bytes", C.c_double),
                 ("attn_ms", C.c_double), ("attn_launches", C.c_int64), ("attn_flops", C.c_double),
                 ("bg_ms", C.c_double), ("overlapped_frames", C.c_int64),
-                ("layers_ms", C.c_double), ("layers_launches", C.c_int64), ("decode_engine", C.c_int32), ("reserved", C.c_int32)]
+                ("layers_ms", C.c_double), ("layers_launches", C.c_int64), ("decode_engine", C.c_int32), ("engine_fallback", C.c_int32)]
 
 
 def hipcc_path() -> str:

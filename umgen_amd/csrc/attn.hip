@@ -32,9 +32,11 @@ constexpr int kKStride = 128;
 constexpr int kVStride = 128;
 constexpr int kTileBytes = 64 * kKStride + 48 * kVStride;   // 14336
 
-template <int QT>
-__global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
-                                                                bf16_t* __restrict__ y, int S, int S_pad, int H, int nq, int npairs) {
+template <int QT, typename TT>
+__global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const TT* __restrict__ qk, const TT* __restrict__ vt,
+                                                                TT* __restrict__ y, int S, int S_pad, int H, int nq, int npairs) {
+    typedef typename Mma16<TT>::vec vec8;
+    typedef typename Mma16<TT>::elem elem_t;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTileBytes];
     const int E = H * kHeadDim;
     // XCD-aware decode of the flat block id: 8 consecutive (frame, head) pairs form a group; inside it b = q*8 + j
@@ -47,9 +49,9 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
     const int c16 = lane & 15, g = lane >> 4;
     const int q0 = (qb * 4 + wave) * (QT * 16);
     const long ld = 2L * E;
-    const bf16_t* qbase = qk + (long)f * S * ld + h * kHeadDim;
-    const bf16_t* kbase = qbase + E;
-    const bf16_t* vbase = vt + ((long)f * H + h) * kHeadDim * S_pad;
+    const TT* qbase = qk + (long)f * S * ld + h * kHeadDim;
+    const TT* kbase = qbase + E;
+    const TT* vbase = vt + ((long)f * H + h) * kHeadDim * S_pad;
 
     // staging assignment: 768 16-byte chunks per tile (K: 64 rows x 6, Vt: 48 rows x 8), 3 per thread.  Chunks 0..383 are K,
     // 384..767 are Vt, so thread tid's chunks tid / tid+256 / tid+512 are K / (K if tid < 128 else Vt) / Vt: the three staging
@@ -59,9 +61,9 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
     const int c1 = tid + 256;
     const int r1 = mid_is_k ? c1 / 6 : (c1 - 384) >> 3, p1 = mid_is_k ? c1 % 6 : (c1 - 384) & 7;
     const int c2 = tid + 512 - 384, r2 = c2 >> 3, p2 = c2 & 7;             // chunk tid+512: Vt row r2, piece p2
-    const bf16_t* g0 = kbase + p0 * 8;
-    const bf16_t* g1 = mid_is_k ? kbase + p1 * 8 : vbase + (long)r1 * S_pad + p1 * 8;
-    const bf16_t* g2 = vbase + (long)r2 * S_pad + p2 * 8;
+    const TT* g0 = kbase + p0 * 8;
+    const TT* g1 = mid_is_k ? kbase + p1 * 8 : vbase + (long)r1 * S_pad + p1 * 8;
+    const TT* g2 = vbase + (long)r2 * S_pad + p2 * 8;
     // LDS byte offsets: K piece p -> chunk p ^ 2*((row >> 1) & 3) of the row;
     // Vt piece p (key groups 2p, 2p+1) -> the aligned 16 B pair (2p ^ row) & ~1, halves swapped when the row is odd
     auto koff = [&](int r, int pp) { return r * kKStride + ((pp ^ (2 * ((r >> 1) & 3))) << 4); };
@@ -93,12 +95,12 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
     // head_dim 48 = one full K=32 MFMA (d 0..31) + one half-filled K=32 MFMA (d 32..47 in k-slots 0..15, zeros in 16..31).
     // (The legacy v_mfma_f32_16x16x16_bf16 for the 16-wide remainder gave tile-dependent wrong results under some register
     //  allocations on ROCm 7.2 -- chained behind the 8-pass 16x16x32 through SrcC -- so it is not used.)
-    bf16x8_t qlo[QT], qhi[QT];
+    vec8 qlo[QT], qhi[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int qr = min(q0 + t * 16 + c16, S - 1);
-        qlo[t] = *reinterpret_cast<const bf16x8_t*>(qbase + qr * ld + 8 * g);
-        union { bf16x8_t v; uint4 w; } qh;
+        qlo[t] = *reinterpret_cast<const vec8*>(qbase + qr * ld + 8 * g);
+        union { vec8 v; uint4 w; } qh;
         qh.w = *reinterpret_cast<const uint4*>(qbase + qr * ld + 32 + 8 * (g & 1));
         if (g >= 2) qh.w = make_uint4(0u, 0u, 0u, 0u);
         qhi[t] = qh.v;
@@ -128,12 +130,12 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
         for (int kt = 0; kt < 4; ++kt) {
             const unsigned char* kr = kt_l + (kt * 16 + c16) * kKStride;
             const int ksw = 2 * ((c16 >> 1) & 3);
-            const bf16x8_t klo = *reinterpret_cast<const bf16x8_t*>(kr + ((g ^ ksw) << 4));
-            const bf16x8_t khi = *reinterpret_cast<const bf16x8_t*>(kr + (((4 + g) ^ ksw) << 4));   // d 32+8g .. 39+8g (g < 2) | zeros
+            const vec8 klo = *reinterpret_cast<const vec8*>(kr + ((g ^ ksw) << 4));
+            const vec8 khi = *reinterpret_cast<const vec8*>(kr + (((4 + g) ^ ksw) << 4));   // d 32+8g .. 39+8g (g < 2) | zeros
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(klo, qlo[t], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                st[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(khi, qhi[t], a, 0, 0, 0);
+                f32x4_t a = Mma16<TT>::mfma(klo, qlo[t], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                st[t][kt] = Mma16<TT>::mfma(khi, qhi[t], a);
             }
         }
         if (k0 + 64 > S) {   // key tail: rows past S are masked out
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
                         for (int t = 0; t < QT; ++t) st[t][kt][r] = -INFINITY;
                     }
         }
-        bf16x8_t pb[QT][2];
+        vec8 pb[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             float mx = st[t][0][0];
@@ -179,18 +181,18 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[t][hh][j] = (__bf16)p[2 * hh + (j >> 2)][j & 3];
+                for (int j = 0; j < 8; ++j) pb[t][hh][j] = (elem_t)p[2 * hh + (j >> 2)][j & 3];
         }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const unsigned char* vr = vt_l + (d * 16 + c16) * kVStride;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                union { bf16x8_t v; uint2 u[2]; } a;
+                union { vec8 v; uint2 u[2]; } a;
                 a.u[0] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g) ^ c16) << 3));       // keys k0 + 32hh + 4g .. +3
                 a.u[1] = *reinterpret_cast<const uint2*>(vr + (((8 * hh + g + 4) ^ c16) << 3));   // keys k0 + 32hh + 16 + 4g .. +3
 #pragma unroll
-                for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, pb[t][hh], o[t][d], 0, 0, 0);
+                for (int t = 0; t < QT; ++t) o[t][d] = Mma16<TT>::mfma(a.v, pb[t][hh], o[t][d]);
             }
         }
         // publish tile it+1 (already in registers) into the other buffer, then fetch tile it+2
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const bf16_t* __
         const float inv = 1.0f / lt;
         const int qr = q0 + t * 16 + c16;
         if (qr < S) {
-            bf16_t* yr = y + ((long)f * S + qr) * E + h * kHeadDim + 4 * g;
+            TT* yr = y + ((long)f * S + qr) * E + h * kHeadDim + 4 * g;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 float v[4] = {o[t][d][0] * inv, o[t][d][1] * inv, o[t][d][2] * inv, o[t][d][3] * inv};
@@ -561,7 +563,8 @@ __global__ __launch_bounds__((OPT & 8192) ? 512 : 256) void attn_spatial_mfma2_k
 #ifndef UMGEN_ATTN_QT
 #define UMGEN_ATTN_QT 2   // measured: 2 query tiles per wave (2 waves/SIMD) beats 4 (1 wave/SIMD)
 #endif
-void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int S_pad, int H) {
+template <typename TT>
+void launch_attn_spatial_mfma(hipStream_t s, const TT* qk, const TT* vt, TT* y, int F, int S, int S_pad, int H) {
     constexpr int QT = UMGEN_ATTN_QT;
     const int nq = (S + 4 * QT * 16 - 1) / (4 * QT * 16);
     // F*H pairs; groups of 8 pairs need F*H % 8 == 0 -- pad the pair count up and let the surplus blocks exit
@@ -584,8 +587,10 @@ void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t
     }
 #undef UMGEN_ATTN_CASE
 #endif
-    hipLaunchKernelGGL(attn_spatial_mfma_kernel<QT>, grid, block, 0, s, qk, vt, y, S, S_pad, H, nq, F * H);
+    hipLaunchKernelGGL((attn_spatial_mfma_kernel<QT, TT>), grid, block, 0, s, qk, vt, y, S, S_pad, H, nq, F * H);
 }
+template void launch_attn_spatial_mfma<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int);
+template void launch_attn_spatial_mfma<f16_t>(hipStream_t, const f16_t*, const f16_t*, f16_t*, int, int, int, int);
 
 // ---------------------------------------------------------------------------------------------------------
 // spatial, generic VALU (parity mode): one thread per query, keys streamed through LDS in tiles of 32
@@ -660,6 +665,7 @@ void launch_attn_spatial_valu(hipStream_t s, const T* qk, const T* vt, T* y, int
 }
 template void launch_attn_spatial_valu<float>(hipStream_t, const float*, const float*, float*, int, int, int, int);
 template void launch_attn_spatial_valu<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int);
+template void launch_attn_spatial_valu<f16_t>(hipStream_t, const f16_t*, const f16_t*, f16_t*, int, int, int, int);
 
 // ---------------------------------------------------------------------------------------------------------
 // temporal: causal attention over the T (<= 32) history frames of one spatial position.
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(HG * TMAX * 4) void attn_temporal_kernel(const T* _
         const int c = tid + NT * it;
         if (c < n_chunks) {
             const int cc = c % chunks_per_seg, seg = (c / chunks_per_seg) % 3, t = c / (3 * chunks_per_seg);
-            if (t < t0 && seg == 0) continue;        // queries of cached slots are not needed
+            if ((t < t0 || t < tr.q0) && seg == 0) continue;        // queries of cached slots / of slots nobody consumes are not needed (their q rows may not exist)
             float v8[8];
             T* cp = cache ? cache + (((long)b * tr.Tcap + t) * S + s) * 2L * E + (long)(seg - 1) * E + hg * W + cc * 8 : nullptr;
             if (t < t0) load8(cp, v8);
@@ -713,7 +719,7 @@ __global__ __launch_bounds__(HG * TMAX * 4) void attn_temporal_kernel(const T* _
     __syncthreads();
     // 4 lanes per (head, query frame): lane part p owns head-dim slice [12p, 12p+12)
     const int part = tid & 3, tq = (tid >> 2) % TMAX, hl = tid / (4 * TMAX);
-    const bool active = tq >= t0 && tq < T_;
+    const bool active = tq >= t0 && tq >= tr.q0 && tq < T_;
     float q[12], o[12];
     const float* qp = sm + ((active ? tq : t0) * 3 + 0) * W + hl * kHeadDim + part * 12;
 #pragma unroll
@@ -793,5 +799,6 @@ void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int Tn, int 
 }
 template void launch_attn_temporal<float>(hipStream_t, const float*, float*, int, int, int, int, TemporalRange);
 template void launch_attn_temporal<bf16_t>(hipStream_t, const bf16_t*, bf16_t*, int, int, int, int, TemporalRange);
+template void launch_attn_temporal<f16_t>(hipStream_t, const f16_t*, f16_t*, int, int, int, int, TemporalRange);
 
 }  // namespace umgen

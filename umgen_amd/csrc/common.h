@@ -10,7 +10,9 @@ constexpr int kSeq = 2207;        // scene positions per frame (infer_fun.py:118
 constexpr int kWave = 64;
 
 typedef unsigned short bf16_t;    // raw bfloat16 bits
+typedef _Float16 f16_t;           // IEEE half: the reference's own autocast dtype (UMGen.py:1604-1605), precision mode UMGEN_PREC_FP16
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
@@ -42,6 +44,51 @@ template <> struct Cvt<float> {
 template <> struct Cvt<bf16_t> {
     __host__ __device__ static inline float to_f(bf16_t v) { return bf16_to_f32(v); }
     __host__ __device__ static inline bf16_t from_f(float v) { return f32_to_bf16(v); }
+};
+template <> struct Cvt<f16_t> {   // v_cvt_f32_f16 / v_cvt_f16_f32 (round-to-nearest-even, overflow -> inf like torch's .half())
+    __host__ __device__ static inline float to_f(f16_t v) { return (float)v; }
+    __host__ __device__ static inline f16_t from_f(float v) { return (f16_t)v; }
+};
+
+// 16-bit MFMA operand traits: both types use v_mfma_f32_16x16x32_* / 32x32x16_* at the same rate and with the same fragment
+// layouts, so every matrix-core kernel is one template over the operand type
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+    typedef bf16x8_t vec;
+    typedef __bf16 elem;
+    __device__ static inline f32x4_t mfma(vec a, vec b, f32x4_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+        return c;
+#endif
+    }
+    __device__ static inline f32x16_t mfma32(vec a, vec b, f32x16_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+        return c;
+#endif
+    }
+};
+template <> struct Mma16<f16_t> {
+    typedef f16x8_t vec;
+    typedef _Float16 elem;
+    __device__ static inline f32x4_t mfma(vec a, vec b, f32x4_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+        return c;
+#endif
+    }
+    __device__ static inline f32x16_t mfma32(vec a, vec b, f32x16_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+        return c;
+#endif
+    }
 };
 
 // wave64 sum, result broadcast to all lanes.  DPP row shifts / broadcasts (7 VALU ops) instead of six dependent
@@ -96,6 +143,11 @@ __device__ inline void load8(const bf16_t* p, float (&o)[8]) {
     o[4] = __uint_as_float(a.z << 16); o[5] = __uint_as_float(a.z & 0xffff0000u);
     o[6] = __uint_as_float(a.w << 16); o[7] = __uint_as_float(a.w & 0xffff0000u);
 }
+__device__ inline void load8(const f16_t* p, float (&o)[8]) {
+    const f16x8_t a = *reinterpret_cast<const f16x8_t*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
+}
 __device__ inline void load4(const float* p, float (&o)[4]) {
     const float4 a = *reinterpret_cast<const float4*>(p);
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
@@ -105,12 +157,23 @@ __device__ inline void load4(const bf16_t* p, float (&o)[4]) {
     o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
     o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
 }
+__device__ inline void load4(const f16_t* p, float (&o)[4]) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    const f16x4_t a = *reinterpret_cast<const f16x4_t*>(p);
+    o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)a[2]; o[3] = (float)a[3];
+}
 __device__ inline void store4(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ inline void store4(bf16_t* p, const float (&v)[4]) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
     const bf16x4_t o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};   // two v_cvt_pk_bf16_f32
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, o);
+}
+
+__device__ inline void store4(f16_t* p, const float (&v)[4]) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    const f16x4_t o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, o);
 }
 

@@ -23,8 +23,9 @@ inline int down(void* h, const void* d, size_t n) { return hipMemcpy(h, d, n, hi
 extern "C" {
 
 // out[R][N] = act[R][K] . W[N][K]^T + bias (+gelu) (+ residual into out when resid != 0).  bf16 != 0: operands are raw
-// bf16 bits and the MFMA kernel runs; else fp32 operands and the exact VALU kernel.  out is fp32 for resid, operand dtype otherwise.
-int umgen_dbg_linear(int bf16, const void* act, const void* W, const float* bias, int R, int N, int K, int gelu, int resid, void* out) {
+// bf16 bits (bf16 == 2: IEEE half bits) and the MFMA kernel runs; else fp32 operands and the exact VALU kernel.  out is fp32 for resid, operand dtype otherwise.
+int umgen_dbg_linear(int flags, const void* act, const void* W, const float* bias, int R, int N, int K, int gelu, int resid, void* out) {
+    const int bf16 = flags & 3;                 // precision code; flag 16: force the 256 x 256 kernel, 32: never use it
     const size_t es = bf16 ? 2 : 4;
     DevBuf dA((size_t)R * K * es), dW((size_t)N * K * es), dB((size_t)N * 4), dO((size_t)R * N * 4);
     if (!dA.p || !dW.p || !dB.p || !dO.p) return UMGEN_E_NOMEM;
@@ -35,7 +36,8 @@ int umgen_dbg_linear(int bf16, const void* act, const void* W, const float* bias
     GemmArgs g{};
     g.P = dW.p; g.Q = dA.p; g.Mi = N; g.Nj = R; g.K = K; g.ldp = K; g.ldq = K; g.batch = 1;
     g.mode = resid ? GEMM_RESID : GEMM_STORE; g.bias = bias ? (const float*)dB.p : nullptr; g.gelu = gelu; g.out = dO.p; g.ldo = N;
-    if (bf16) launch_gemm_bf16_mfma(nullptr, g); else launch_gemm_valu<float, float>(nullptr, g);
+    g.tile256 = (flags & 16) ? 1 : ((flags & 32) ? -1 : 0);
+    if (bf16 == 2) launch_gemm_mfma<f16_t>(nullptr, g); else if (bf16) launch_gemm_mfma<bf16_t>(nullptr, g); else launch_gemm_valu<float, float>(nullptr, g);
     if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
     return down(out, dO.p, osz);
 }
@@ -56,7 +58,8 @@ int umgen_dbg_attn_spatial(int bf16, const void* qk, const void* v, int F, int S
     DevBuf dQK(R * 2 * E * es), dVT(vt.size()), dY(R * E * es);
     if (!dQK.p || !dVT.p || !dY.p) return UMGEN_E_NOMEM;
     if (up(dQK.p, qk, R * 2 * E * es) || up(dVT.p, vt.data(), vt.size())) return UMGEN_E_HIP;
-    if (bf16) launch_attn_spatial_bf16_mfma(nullptr, (const bf16_t*)dQK.p, (const bf16_t*)dVT.p, (bf16_t*)dY.p, F, S, S_pad, H);
+    if (bf16 == 2) launch_attn_spatial_mfma<f16_t>(nullptr, (const f16_t*)dQK.p, (const f16_t*)dVT.p, (f16_t*)dY.p, F, S, S_pad, H);
+    else if (bf16) launch_attn_spatial_mfma<bf16_t>(nullptr, (const bf16_t*)dQK.p, (const bf16_t*)dVT.p, (bf16_t*)dY.p, F, S, S_pad, H);
     else launch_attn_spatial_valu<float>(nullptr, (const float*)dQK.p, (const float*)dVT.p, (float*)dY.p, F, S, S_pad, H);
     if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
     return down(y, dY.p, R * E * es);
@@ -71,7 +74,8 @@ int umgen_dbg_attn_temporal(int bf16, const void* qkv, int B, int T, int S, int 
         DevBuf dQ(R * 3 * E * es), dY(R * E * es);
         if (!dQ.p || !dY.p) return UMGEN_E_NOMEM;
         if (up(dQ.p, qkv, R * 3 * E * es)) return UMGEN_E_HIP;
-        if (bf16) launch_attn_temporal<bf16_t>(nullptr, (const bf16_t*)dQ.p, (bf16_t*)dY.p, B, T, S, H);
+        if (bf16 == 2) launch_attn_temporal<f16_t>(nullptr, (const f16_t*)dQ.p, (f16_t*)dY.p, B, T, S, H);
+        else if (bf16) launch_attn_temporal<bf16_t>(nullptr, (const bf16_t*)dQ.p, (bf16_t*)dY.p, B, T, S, H);
         else launch_attn_temporal<float>(nullptr, (const float*)dQ.p, (float*)dY.p, B, T, S, H);
         if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
         return down(y, dY.p, R * E * es);
@@ -91,7 +95,8 @@ int umgen_dbg_attn_temporal(int bf16, const void* qkv, int B, int T, int S, int 
         if (!dQ.p || !dY.p) return UMGEN_E_NOMEM;
         if (up(dQ.p, hq.data(), hq.size())) return UMGEN_E_HIP;
         TemporalRange tr{t0, dC.p, Tcap, pass == 0 ? 1 : 0};
-        if (bf16) launch_attn_temporal<bf16_t>(nullptr, (const bf16_t*)dQ.p, (bf16_t*)dY.p, B, Tn, S, H, tr);
+        if (bf16 == 2) launch_attn_temporal<f16_t>(nullptr, (const f16_t*)dQ.p, (f16_t*)dY.p, B, Tn, S, H, tr);
+        else if (bf16) launch_attn_temporal<bf16_t>(nullptr, (const bf16_t*)dQ.p, (bf16_t*)dY.p, B, Tn, S, H, tr);
         else launch_attn_temporal<float>(nullptr, (const float*)dQ.p, (float*)dY.p, B, Tn, S, H, tr);
         if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
         if (down(hy.data(), dY.p, hy.size())) return UMGEN_E_HIP;
@@ -113,7 +118,8 @@ int umgen_dbg_attn_decode(int bf16, const float* q, const void* kv, int NQ, int 
     for (int i = 0; i < E; ++i) eye[(size_t)i * E + i] = 1.f;
     if (up(dW.p, eye.data(), eye.size() * 4)) return UMGEN_E_HIP;
     (void)hipMemset(dX.p, 0, (size_t)NQ * E * 4);
-    if (bf16) launch_attn_partial<bf16_t>(nullptr, (const float*)dQ.p, (const bf16_t*)dKV.p, 0, kHeadDim, 2L * E, E, NQ, NQ, H, nullptr, L, attn_nsplit(L), (float*)dP.p);
+    if (bf16 == 2) launch_attn_partial<f16_t>(nullptr, (const float*)dQ.p, (const f16_t*)dKV.p, 0, kHeadDim, 2L * E, E, NQ, NQ, H, nullptr, L, attn_nsplit(L), (float*)dP.p);
+    else if (bf16) launch_attn_partial<bf16_t>(nullptr, (const float*)dQ.p, (const bf16_t*)dKV.p, 0, kHeadDim, 2L * E, E, NQ, NQ, H, nullptr, L, attn_nsplit(L), (float*)dP.p);
     else launch_attn_partial<float>(nullptr, (const float*)dQ.p, (const float*)dKV.p, 0, kHeadDim, 2L * E, E, NQ, NQ, H, nullptr, L, attn_nsplit(L), (float*)dP.p);
     GemvResidArgs a{};
     a.part = (const float*)dP.p; a.H = H; a.ns = attn_nsplit(L); a.W = dW.p; a.N = E; a.K = E; a.M = NQ; a.x = (float*)dX.p; a.ldx = E;
@@ -138,11 +144,12 @@ int umgen_dbg_gemm_bench(int R, int N, int K, int mode, int iters, float* ms) {
     GemmArgs g{};
     g.P = dW.p; g.Q = dA.p; g.Mi = N; g.Nj = R; g.K = K; g.ldp = K; g.ldq = K; g.batch = 1;
     g.mode = mode & 15; g.gelu = (mode >> 4) & 1; g.out = dO.p; g.ldo = N;   // mode bit 4: erf-GELU epilogue
+    g.tile256 = (mode & 64) ? -1 : ((mode & 32) ? 1 : 0);                     // bit 5: force the 256 x 256 kernel, bit 6: 128 x 128 kernels only
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    launch_gemm_bf16_mfma(nullptr, g);
+    launch_gemm_mfma<bf16_t>(nullptr, g);
     (void)hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; ++i) launch_gemm_bf16_mfma(nullptr, g);
+    for (int i = 0; i < iters; ++i) launch_gemm_mfma<bf16_t>(nullptr, g);
     (void)hipEventRecord(e1, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
     float t = 0.f;
@@ -163,14 +170,14 @@ int umgen_dbg_gemv(int bf16, const float* x, const float* ln_w, const void* W, c
     GemvArgs a{};
     a.x = (const float*)dX.p; a.ldx = K; a.ln_w = ln_w ? (const float*)dL.p : nullptr; a.W = dW.p; a.bias = bias ? (const float*)dB.p : nullptr;
     a.N = N; a.K = K; a.M = M; a.out_mode = gelu ? GEMV_OUT_GELU : GEMV_OUT_F32; a.out = (float*)dO.p; a.ldo = N; a.E = K;
-    if (bf16) launch_gemv<bf16_t>(nullptr, a); else launch_gemv<float>(nullptr, a);
+    if (bf16 == 2) launch_gemv<f16_t>(nullptr, a); else if (bf16) launch_gemv<bf16_t>(nullptr, a); else launch_gemv<float>(nullptr, a);
     if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
     if (int rc = down(out, dO.p, (size_t)M * N * 4)) return rc;
     if (M > 1) {   // the one-row-per-workgroup form (what the engine launches for several scenes) must give the same bits
         std::vector<float> alt((size_t)M * N);
         (void)hipMemset(dO.p, 0, (size_t)M * N * 4);
         a.rows_per_block = 1;
-        if (bf16) launch_gemv<bf16_t>(nullptr, a); else launch_gemv<float>(nullptr, a);
+        if (bf16 == 2) launch_gemv<f16_t>(nullptr, a); else if (bf16) launch_gemv<bf16_t>(nullptr, a); else launch_gemv<float>(nullptr, a);
         if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
         if (int rc = down(alt.data(), dO.p, (size_t)M * N * 4)) return rc;
         if (memcmp(alt.data(), out, (size_t)M * N * 4) != 0) return UMGEN_E_STATE;

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/umgen.h"
@@ -62,7 +63,6 @@ struct umgen_engine {
     // workspace
     float *X = nullptr, *mapfeat = nullptr, *warped_last = nullptr, *cond = nullptr, *pose_diff = nullptr, *pego = nullptr;
     void *A = nullptr, *QKV = nullptr, *VT = nullptr, *Hb = nullptr;
-    float *kvnew = nullptr;
     float *xdec = nullptr, *qdec = nullptr, *part = nullptr, *hdec = nullptr, *logits = nullptr, *logits_tar = nullptr, *qkv3 = nullptr;
     void* kvcache = nullptr;
     long kv_layer_stride = 0, kv_scene_stride = 0;
@@ -107,7 +107,6 @@ struct umgen_engine {
     bool profiling = false;
     int rows_per_block = -1;              // few-row launches: rows per workgroup; -1 = by row count (1 up to 6 rows, else 2), 0 = row loop
     bool dbg_same_layer = false;          // UMGEN_DEBUG_SAME_LAYER=1: timing experiment, every decode layer reads layer 0's weights
-    bool fused_decode = false;            // UMGEN_FUSED_DECODE=1 (experiment, see oar_layers)
     // decode step graphs per (kind: fixed / map / bbox3d / image, number of attention key splits 1..8)
     hipGraphExec_t step_graph[4][kAttnSplit + 1] = {};
     int step_graph_B = 0;
@@ -115,7 +114,7 @@ struct umgen_engine {
     size_t gemm_ev_used = 0, attn_ev_used = 0, layer_ev_used = 0;
     // XCD-resident decode engine (oar_engine.hip): one launch per decode step instead of five per layer
     struct EngStream { bool ok = false; int NG = 0; unsigned char map[16]; };
-    bool eng_enabled = false;
+    bool eng_enabled = false, eng_fallback = false;   // eng_fallback: wanted, but the census failed (umgen_timings::engine_fallback)
     EngStream eng_fg, eng_full;          // census of the decode stream (CU-masked when the overlap exists) and of the unmasked stream
     OarLayerDev* d_layers = nullptr;
     unsigned long long *eng_gx = nullptr, *eng_gloc = nullptr;
@@ -266,13 +265,15 @@ template <> struct Path<float> {
     }
     static void gemm_w_f32act(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<float, float>(s, a); }
 };
-template <> struct Path<bf16_t> {
-    static void gemm(hipStream_t s, const GemmArgs& a) { launch_gemm_bf16_mfma(s, a); }
-    static void attn_spatial(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int Sp, int H) {
-        launch_attn_spatial_bf16_mfma(s, qk, vt, y, F, S, Sp, H);
+template <typename TT> struct Path16 {   // bf16_t / f16_t: the same matrix-core kernels with the other operand type
+    static void gemm(hipStream_t s, const GemmArgs& a) { launch_gemm_mfma<TT>(s, a); }
+    static void attn_spatial(hipStream_t s, const TT* qk, const TT* vt, TT* y, int F, int S, int Sp, int H) {
+        launch_attn_spatial_mfma<TT>(s, qk, vt, y, F, S, Sp, H);
     }
-    static void gemm_w_f32act(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<bf16_t, float>(s, a); }
+    static void gemm_w_f32act(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<TT, float>(s, a); }
 };
+template <> struct Path<bf16_t> : Path16<bf16_t> {};
+template <> struct Path<f16_t> : Path16<f16_t> {};
 
 template <typename T>
 void gemm_timed(umgen_engine* e, const GemmArgs& a) {
@@ -311,24 +312,37 @@ void linear_resid(umgen_engine* e, const void* W, const float* bias, int N, int 
 }
 
 // one (LayerNorm -> attention -> residual -> LayerNorm -> MLP -> residual) sub-block of BlockTAR (module.py:332-359)
+//
+// `tail`: the reference consumes only the LAST frame of every stack's output (UMGen.py:1227-1231 takes
+// [:, -1] of each TAR output, 1002 of the ego stack), the spatial attention / LayerNorm / MLPs are frame-local and the temporal
+// attention is causal (module.py:332-359) -- so in a stack's FINAL block everything behind the temporal attention's k | v rows is
+// evaluated for the last frame only: identical outputs (per-row arithmetic does not depend on which other rows are in the launch).
+//   tail 0: all rows;  tail 1 (temporal sub-block): LN + k|v of all rows, q / attention output / projection / MLP of the last frame;
+//   tail 2 (the spatial sub-block behind it): the whole sub-block on the last frame's rows.
 template <typename T>
-void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal, TemporalRange tr = TemporalRange{0, nullptr, 0, 0}) {
+void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal, TemporalRange tr = TemporalRange{0, nullptr, 0, 0}, int tail = 0) {
     const int E = e->E, H = e->H;
     const long R = (long)B * Tn * S;
     T* A = reinterpret_cast<T*>(e->A);
     T* QKV = reinterpret_cast<T*>(e->QKV);
-    launch_layernorm<T>(e->stream, e->X, E, R, E, w.ln_a, A);
-    if (temporal) {
-        linear_store<T>(e, w.attn.Wqkv, w.attn.bqkv, 3 * E, E, A, R, QKV, 3L * E, 0);
-        launch_attn_temporal<T>(e->stream, QKV, A, B, Tn, S, H, tr);
-    } else {
-        // q | k row-major, V transposed per (frame, head) for the attention kernel
-        linear_store<T>(e, w.attn.Wqkv, w.attn.bqkv, 2 * E, E, A, R, QKV, 2L * E, 0);
+    T* Hb = reinterpret_cast<T*>(e->Hb);
+    const char* Wqkv = reinterpret_cast<const char*>(w.attn.Wqkv);
+    const size_t wrow = (size_t)E * sizeof(T);                      // bytes of one weight row of c_attn
+    // row ranges the "rest" of the sub-block (projection, MLP) runs on: everything, or the last frame of each scene
+    struct Range { long row0, rows; };
+    std::vector<Range> rest;
+    if (tail == 0) rest.push_back(Range{0, R});
+    else for (int b = 0; b < B; ++b) rest.push_back(Range{((long)b * Tn + (Tn - 1)) * S, (long)S});
+    auto spatial_attention = [&](long frame0, int frames) {         // q | k row-major, V transposed per (frame, head) for the attention kernel
+        const long r0 = frame0 * S;
+        linear_store<T>(e, Wqkv, w.attn.bqkv, 2 * E, E, A + r0 * E, (long)frames * S, QKV + r0 * 2 * E, 2L * E, 0);
+        T* vt = reinterpret_cast<T*>(e->VT) + frame0 * (long)E * e->S_pad;
         GemmArgs g{};
-        g.P = A; g.Q = reinterpret_cast<const char*>(w.attn.Wqkv) + (size_t)2 * E * E * sizeof(T);
-        g.Mi = S; g.Nj = E; g.K = E; g.ldp = E; g.ldq = E; g.strideP = (long)S * E; g.strideQ = 0; g.batch = B * Tn;
-        g.mode = GEMM_VT; g.bias = w.attn.bqkv + 2 * E; g.out = e->VT; g.ldo = e->S_pad; g.H = H;
+        g.P = A + r0 * E; g.Q = Wqkv + (size_t)2 * E * wrow;
+        g.Mi = S; g.Nj = E; g.K = E; g.ldp = E; g.ldq = E; g.strideP = (long)S * E; g.strideQ = 0; g.batch = frames;
+        g.mode = GEMM_VT; g.bias = w.attn.bqkv + 2 * E; g.out = vt; g.ldo = e->S_pad; g.H = H;
         gemm_timed<T>(e, g);
+        hipEvent_t t0 = nullptr, t1 = nullptr;
         if (e->profiling) {
             if (e->attn_ev_used == e->attn_ev.size()) {
                 hipEvent_t a0, a1;
@@ -337,18 +351,39 @@ void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal
                 e->attn_ev.emplace_back(a0, a1);
             }
             auto& pr = e->attn_ev[e->attn_ev_used++];
-            hipEventRecord(pr.first, e->stream);
-            Path<T>::attn_spatial(e->stream, QKV, reinterpret_cast<const T*>(e->VT), A, B * Tn, S, e->S_pad, H);
-            hipEventRecord(pr.second, e->stream);
-            e->attn_flops_pending += 4.0 * (double)S * (double)S * kHeadDim * (double)H * (double)(B * Tn);
-        } else {
-            Path<T>::attn_spatial(e->stream, QKV, reinterpret_cast<const T*>(e->VT), A, B * Tn, S, e->S_pad, H);
+            t0 = pr.first; t1 = pr.second;
+            hipEventRecord(t0, e->stream);
+            e->attn_flops_pending += 4.0 * (double)S * (double)S * kHeadDim * (double)H * (double)frames;
+        }
+        Path<T>::attn_spatial(e->stream, QKV + r0 * 2 * E, vt, A + r0 * E, frames, S, e->S_pad, H);
+        if (t1) hipEventRecord(t1, e->stream);
+    };
+    if (temporal) {
+        launch_layernorm<T>(e->stream, e->X, E, R, E, w.ln_a, A);
+        if (tail == 0) {
+            linear_store<T>(e, Wqkv, w.attn.bqkv, 3 * E, E, A, R, QKV, 3L * E, 0);
+        } else {   // k | v rows of every frame, q rows of the last frame only (the same [R][3E] row layout)
+            linear_store<T>(e, Wqkv + (size_t)E * wrow, w.attn.bqkv + E, 2 * E, E, A, R, QKV + E, 3L * E, 0);
+            for (const Range& r : rest) linear_store<T>(e, Wqkv, w.attn.bqkv, E, E, A + r.row0 * E, r.rows, QKV + r.row0 * 3 * E, 3L * E, 0);
+            tr.q0 = tr.t0 + Tn - 1;
+        }
+        launch_attn_temporal<T>(e->stream, QKV, A, B, Tn, S, H, tr);
+    } else if (tail == 0) {
+        launch_layernorm<T>(e->stream, e->X, E, R, E, w.ln_a, A);
+        spatial_attention(0, B * Tn);
+    } else {
+        for (const Range& r : rest) {
+            launch_layernorm<T>(e->stream, e->X + r.row0 * E, E, r.rows, E, w.ln_a, A + r.row0 * E);
+            spatial_attention(r.row0 / S, 1);
         }
     }
-    linear_resid<T>(e, w.attn.Wo, w.attn.bo, E, E, A, R, e->X);
-    launch_layernorm<T>(e->stream, e->X, E, R, E, w.ln_b, A);
-    linear_store<T>(e, w.mlp.Wfc, nullptr, 4 * E, E, A, R, e->Hb, 4L * E, 1);
-    linear_resid<T>(e, w.mlp.Wproj, nullptr, E, 4 * E, e->Hb, R, e->X);
+    for (const Range& r : rest) {
+        float* X = e->X + r.row0 * E;
+        linear_resid<T>(e, w.attn.Wo, w.attn.bo, E, E, A + r.row0 * E, r.rows, X);
+        launch_layernorm<T>(e->stream, X, E, r.rows, E, w.ln_b, A + r.row0 * E);
+        linear_store<T>(e, w.mlp.Wfc, nullptr, 4 * E, E, A + r.row0 * E, r.rows, Hb + r.row0 * 4 * E, 4L * E, 1);
+        linear_resid<T>(e, w.mlp.Wproj, nullptr, E, 4 * E, Hb + r.row0 * 4 * E, r.rows, X);
+    }
 }
 
 // cache_mode: 0 = one pass over the whole window; 1 = prefix pass (slots [0, w.T), k | v appended to the slot caches);
@@ -359,12 +394,15 @@ void run_stack(umgen_engine* e, int stack, const WindowTokens& w, int cache_mode
     launch_embed_stack(e->stream, stack, e->tb, w, e->X, e->mapfeat);
     if (stack != STACK_EGO) launch_warp_map(e->stream, stack, e->tb, w.B, w.T, e->mapfeat, e->pose_diff, e->X,
                                             stack == STACK_MAP ? e->warped_last : nullptr, w.Tfull, w.t0);
+    static const bool no_tail = getenv("UMGEN_NO_TAIL") != nullptr;   // measurement: evaluate every block on every frame like the reference
     for (size_t i = 0; i < e->stk[stack].size(); ++i) {
         const TarW& blk = e->stk[stack][i];
         TemporalRange tr{w.t0, cache_mode ? e->tcache[stack][i] : nullptr, e->cfg.max_cond_frames, cache_mode == 1 ? 1 : 0};
+        // the final block's tail on the last frame only (f-3): whole-window passes with more than one slot
+        const bool last = i + 1 == e->stk[stack].size() && cache_mode == 0 && w.T > 1 && !no_tail;
         tar_sub<T>(e, blk.sub[0], w.B, w.T, S, false);
-        tar_sub<T>(e, blk.sub[1], w.B, w.T, S, true, tr);
-        tar_sub<T>(e, blk.sub[2], w.B, w.T, S, false);
+        tar_sub<T>(e, blk.sub[1], w.B, w.T, S, true, tr, last ? 1 : 0);
+        tar_sub<T>(e, blk.sub[2], w.B, w.T, S, false, TemporalRange{0, nullptr, 0, 0}, last ? 2 : 0);
     }
 }
 
@@ -425,12 +463,13 @@ void run_ego(umgen_engine* e, const WindowTokens& w, const SamplerParams& sp, in
     }
     gemv<T>(e, x, E, e->ln_ego, e->head_ego, nullptr, e->cfg.pose_vocab, E, M, GEMV_OUT_F32, e->logits, e->cfg.pose_vocab);
     if (trace_logits) hipMemcpyAsync(trace_logits, e->logits, (size_t)3 * e->cfg.pose_vocab * 4, hipMemcpyDeviceToHost, e->stream);
-    launch_sample_ego(e->stream, e->logits, e->cfg.pose_vocab, sp, e->d_seeds, frame_idx, forced ? e->d_forced : nullptr, e->d_ego_tok, B);
+    launch_sample_ego(e->stream, e->logits, e->cfg.pose_vocab, sp, e->d_seeds, frame_idx, forced ? e->d_forced : nullptr, e->d_ego_tok, B,
+                      e->d_counters + 7);
 }
 
 // one OAR decode step through the 36 BlockOAR layers (module.py:402-416) for the B scenes
 template <typename T>
-void oar_layers(umgen_engine* e, int B, int ns, int ns_cached) {
+int oar_layers(umgen_engine* e, int B, int ns) {
     const int E = e->E, H = e->H;
     const int* d_len = &e->d_state->step;
     if (const umgen_engine::EngStream* es = sizeof(T) == 2 ? e->eng_for(e->stream) : nullptr) {
@@ -449,30 +488,24 @@ void oar_layers(umgen_engine* e, int B, int ns, int ns_cached) {
         a.D = es->NG / a.R;
         memcpy(a.xcc_group, es->map, 16);
         a.stamps = e->eng_stamps;
-        (void)launch_oar_engine(e->stream, a);
-        return;
+        a.fp16 = std::is_same<T, f16_t>::value ? 1 : 0;
+        // More than 4 scenes: the systolic schedule (oar_engine.hip) -- the scenes flow through the 8 groups, group g working on layers
+        // g, g + 8, ...; up to 4 scenes keep disjoint group sets per scene (8 / 4 / 2 groups each), whose per-scene latency is lower.
+        // Measured (profiles/r03_systolic.txt): 5 scenes 704 vs 1014 us per step, 8 scenes 1034 vs 1037 us (the register file cannot
+        // keep a layer resident, so every item still streams 11 of its 14 MB).  UMGEN_ENGINE_SYSTOLIC=0/1 forces either form.
+        static const char* sys_env = getenv("UMGEN_ENGINE_SYSTOLIC");
+        a.systolic = sys_env ? (sys_env[0] == '1' && B > 1) : (B > 4);
+        if (a.systolic && B > kEngMaxSystolic) a.systolic = 0;
+        // hand-off tags of one step: (round or scene, layer, edge) must fit kEpochPerStep (umgen_create bounds n_oar_layer and max_batch)
+        const int slots = a.systolic ? B : (B + a.R - 1) / a.R;
+        if ((unsigned)(slots * 64 * 8) > kEpochPerStep) return e->fail(UMGEN_E_UNSUPPORTED, "decode engine: %d scenes need more hand-off tags than one step has", B);
+        HIPCHK(e, launch_oar_engine(e->stream, a));
+        return 0;
     }
     for (size_t li = 0; li < e->oar.size(); ++li) {
         const SubW& w = e->oar[e->dbg_same_layer ? 0 : li];
         T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
-        if (e->fused_decode) {
-            // EXPERIMENT (UMGEN_FUSED_DECODE=1): q|k|v of the new token + attention partials over the cached keys in ONE launch
-            // (attention blocks recompute their 48 q rows), self term merged in the projection.  Measured slower than the
-            // two-launch form (9.7 + 6.8 us vs 4.8 + 5.5 + 5.5 us per layer): the 74 KB of Wq per attention block is bound by
-            // per-CU load bandwidth.  Kept because it is parity-tested and is the starting point for round 2.
-            QkvAttnArgs qa{};
-            GemvArgs& a = qa.g;
-            a.x = e->xdec; a.ldx = E; a.ln_w = w.ln_a; a.W = w.attn.Wqkv; a.bias = w.attn.bqkv; a.N = 3 * E; a.K = E; a.M = B;
-            a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len;
-            a.Lmax = e->Lmax; a.E = E; a.kv_f32 = e->kvnew;
-            qa.head_stride = (long)e->Lmax * kHeadDim; qa.key_stride = kHeadDim; qa.v_off = (long)H * e->Lmax * kHeadDim; qa.H = H;
-            qa.ns = ns_cached; qa.part = e->part;
-            launch_qkv_attn<T>(e->stream, qa);
-            GemvResidArgs r{};
-            r.part = e->part; r.H = H; r.ns = ns_cached; r.self_q = e->qdec; r.self_kv = e->kvnew;
-            r.W = w.attn.Wo; r.bias = w.attn.bo; r.N = E; r.K = E; r.M = B; r.x = e->xdec; r.ldx = E;
-            launch_gemv_resid<T>(e->stream, r);
-        } else {
+        {
             GemvArgs a{};
             a.x = e->xdec; a.ldx = E; a.ln_w = w.ln_a; a.W = w.attn.Wqkv; a.bias = w.attn.bqkv; a.N = 3 * E; a.K = E; a.M = B;
             a.out_mode = GEMV_OUT_QKV; a.out = e->qdec; a.ldo = E; a.cache = cache; a.scene_stride = e->kv_scene_stride; a.d_len = d_len;
@@ -485,6 +518,7 @@ void oar_layers(umgen_engine* e, int B, int ns, int ns_cached) {
         gemv<T>(e, e->xdec, E, w.ln_b, w.mlp.Wfc, nullptr, 4 * E, E, B, GEMV_OUT_GELU, e->hdec, 4L * E);
         gemv_resid<T>(e, e->hdec, 4L * E, nullptr, w.mlp.Wproj, nullptr, E, 4 * E, B, e->xdec, E);
     }
+    return 0;
 }
 
 struct FrameIO {
@@ -532,7 +566,7 @@ void decode_pose_shift(const int* pose, const int* ego, int B, int Tn, std::vect
 
 // kernels of one decode step of kind mod (0 fixed token, 1 map, 2 bbox3d, 3 image) for B scenes
 template <typename T>
-int enqueue_step(umgen_engine* e, int B, int mod, int ns, int ns_cached, const umgen_trace* tr, int j) {
+int enqueue_step(umgen_engine* e, int B, int mod, int ns, const umgen_trace* tr, int j) {
     const int E = e->E;
     hipStream_t st = e->stream;
     const bool time_layers = e->profiling && !e->in_capture;
@@ -545,7 +579,7 @@ int enqueue_step(umgen_engine* e, int B, int mod, int ns, int ns_cached, const u
         }
         hipEventRecord(e->layer_ev[e->layer_ev_used].first, st);
     }
-    oar_layers<T>(e, B, ns, ns_cached);
+    if (int rc = oar_layers<T>(e, B, ns)) return rc;
     if (time_layers) hipEventRecord(e->layer_ev[e->layer_ev_used++].second, st);
     static FILE* dump = getenv("UMGEN_DEBUG_DUMP_X") ? fopen(getenv("UMGEN_DEBUG_DUMP_X"), "wb") : nullptr;   // debugging only (eager launches)
     if (dump && tr == nullptr && !e->cfg.use_graphs) {
@@ -812,8 +846,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         else if (j >= kBoxC0 && j < kBoxEos) mod = 2;
         else if (j >= kImgC0 && j < kImgEos) mod = 3;
         const int ns = attn_nsplit(j + 1);          // key splits over the j cached keys + the new one
-        const int ns_cached = attn_nsplit(j);       // fused-decode experiment: splits over the cached keys only
-        const int gkey = eng ? 0 : (e->fused_decode ? ns_cached : ns);   // the engine derives its key geometry from the device-side step
+        const int gkey = eng ? 0 : ns;              // the engine derives its key geometry from the device-side step
         if (graphs) {
             // With the decode engine a step is 3 kernel nodes and ~600 us, and a graph launch costs ~7 us on the device (the gap between
             // the sampler of one replay and the engine of the next, rocprofv3 kernel trace): runs of steps of the same kind are replayed
@@ -834,24 +867,27 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                 hipGraph_t g;
                 HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
                 e->in_capture = true;
-                for (int r = 0; r < run; ++r) enqueue_step<T>(e, B, mod, ns, ns_cached, nullptr, 0);
+                int crc = 0;
+                for (int r = 0; r < run && !crc; ++r) crc = enqueue_step<T>(e, B, mod, ns, nullptr, 0);
                 e->in_capture = false;
+                if (crc) return crc;   // (run_frame_any ends the open capture)
                 HIPCHK(e, hipStreamEndCapture(st, &g));
                 HIPCHK(e, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
                 HIPCHK(e, hipGraphDestroy(g));
             }
             HIPCHK(e, hipGraphLaunch(ge, st));
-            e->tm.oar_kernels += (int64_t)(run - 1) * ((eng ? 1 : (e->fused_decode ? 4 : 5) * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
+            e->tm.oar_kernels += (int64_t)(run - 1) * ((eng ? 1 : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
             j += run - 1;
-        } else if (int rc = enqueue_step<T>(e, B, mod, ns, ns_cached, tr, j)) {
+        } else if (int rc = enqueue_step<T>(e, B, mod, ns, tr, j)) {
             return rc;
         }
-        e->tm.oar_kernels += (eng ? 1 : (e->fused_decode ? 4 : 5) * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
+        e->tm.oar_kernels += (eng ? 1 : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
     }
     e->tm.oar_steps += kImgEos;
     HIPCHK(e, hipEventRecord(e->ev[3], st));
     HIPCHK(e, hipMemcpyAsync(io.out_tokens, e->d_tokens, (size_t)B * kTokPerFrame * 4, hipMemcpyDeviceToHost, st));
-    if (tr && tr->counters) HIPCHK(e, hipMemcpyAsync(tr->counters, e->d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    int counters[8] = {};
+    HIPCHK(e, hipMemcpyAsync(counters, e->d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     unsigned eng_err = 0;
     if (eng) HIPCHK(e, hipMemcpyAsync(&eng_err, e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
@@ -859,6 +895,9 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         (void)hipMemset(e->eng_err, 0, sizeof(unsigned));
         return e->fail(UMGEN_E_HIP, "decode engine gave up waiting for hand-off tag 0x%08x (is another persistent kernel using this GPU?)", eng_err);
     }
+    if (tr && tr->counters) memcpy(tr->counters, counters, sizeof(counters));
+    if (counters[7])   // (the reference's topk keeps every tie; the sampler's kept-set buffer holds 64 of them)
+        return e->fail(UMGEN_E_UNSUPPORTED, "sampler: more than 64 logits tie with the k-th largest one in %d draw(s) of this frame", counters[7]);
     float ms;
     hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->tm.ego_ms += ms;
     hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->tm.tar_ms += ms;
@@ -872,6 +911,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->tm.total_ms += ms;
     e->tm.frames += 1;
     e->tm.decode_engine = eng ? 1 : 0;
+    e->tm.engine_fallback = e->eng_fallback ? 1 : 0;
     if (use_px) e->tm.overlapped_frames += 1;
     if (e->profiling) {
         for (size_t i = 0; i < e->gemm_ev_used; ++i) {
@@ -904,17 +944,19 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         double bytes = 0;
         for (int j = 0; j < kImgEos; ++j) {
             bytes += w_oar + (double)B * (double)e->oar.size() * (double)e->tsz * 2.0 * E * (double)(j + 1);
-            const int V = (j >= kMapC0 && j < kMapEos) ? e->cfg.map_vocab : (j >= kBoxC0 && j < kBoxEos) ? 2 * e->cfg.bbox3d_vocab
+            const int V = (j >= kMapC0 && j < kMapEos) ? e->cfg.map_vocab : (j >= kBoxC0 && j < kBoxEos) ? e->cfg.bbox3d_vocab
                         : (j >= kImgC0 && j < kImgEos) ? e->cfg.img_vocab : 0;
             bytes += (double)V * E * (double)e->tsz;
         }
+        bytes += (double)e->cfg.bbox3d_vocab * E * (double)e->tsz;   // head_tar_bbox3d: one GEMM per frame (tar_head_logits), not one GEMV per bbox3d step
         e->tm.oar_bytes += bytes;
     }
     return 0;
 }
 
 int run_frame_any(umgen_engine* e, const FrameIO& io) {
-    const int rc = e->cfg.precision == UMGEN_PREC_BF16 ? run_frame<bf16_t>(e, io) : run_frame<float>(e, io);
+    const int rc = e->cfg.precision == UMGEN_PREC_BF16 ? run_frame<bf16_t>(e, io)
+                 : e->cfg.precision == UMGEN_PREC_FP16 ? run_frame<f16_t>(e, io) : run_frame<float>(e, io);
     if (rc != UMGEN_OK) {
         // A failed frame may have left a stream capture open, async copies in flight that read this call's host buffers, and a
         // background pass the next call would wait for: drain everything and forget the pass (the error message is kept).
@@ -1022,7 +1064,8 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (cfg->max_cond_frames > 64) return e->fail(UMGEN_E_UNSUPPORTED, "max_cond_frames <= 64 supported (temporal attention tile)");
     if (cfg->max_batch < 1 || cfg->max_cond_frames < 1 || cfg->max_cond_frames > cfg->max_frame_len)
         return e->fail(UMGEN_E_INVALID, "max_batch / max_cond_frames invalid");
-    if (cfg->precision != UMGEN_PREC_FP32 && cfg->precision != UMGEN_PREC_BF16) return e->fail(UMGEN_E_INVALID, "precision");
+    if (cfg->precision != UMGEN_PREC_FP32 && cfg->precision != UMGEN_PREC_BF16 && cfg->precision != UMGEN_PREC_FP16)
+        return e->fail(UMGEN_E_INVALID, "precision %d (UMGEN_PREC_FP32 / _BF16 / _FP16)", cfg->precision);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return e->fail(UMGEN_E_HIP, "no HIP device visible: libumgen_hip has no CPU fallback");
@@ -1036,9 +1079,58 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     // TAR pass behind a launch-bound loop: when the engine can be used the overlap is off unless UMGEN_OVERLAP asks for it
     // (then the decode step is the five-launch form again).
     const char* de_env = getenv("UMGEN_DECODE_ENGINE");
-    const bool engine_wanted = cfg->precision == UMGEN_PREC_BF16 && cfg->n_embd == kEngE && cfg->n_head == kEngH && !(de_env && de_env[0] == '0');
-    e->overlap = cfg->max_cond_frames >= 2 && !engine_wanted;
-    if (const char* ov = getenv("UMGEN_OVERLAP")) { e->overlap_mode = ov[0] - '0'; e->overlap = cfg->max_cond_frames >= 2 && ov[0] != '0'; }
+    const char* ov_env = getenv("UMGEN_OVERLAP");
+    // hand-off tags: (round or scene, layer, edge) of one step must fit kEpochPerStep (oar_engine.hip): <= 64 layers; up to 32 scenes flow
+    // through the systolic schedule, more run as rounds of 8 whole-scene groups (<= 32 rounds)
+    const bool engine_wanted = cfg->precision != UMGEN_PREC_FP32 && cfg->n_embd == kEngE && cfg->n_head == kEngH && cfg->n_oar_layer <= 64 &&
+                               cfg->max_batch <= 256 && !(de_env && de_env[0] == '0') && !(ov_env && ov_env[0] != '0');
+    if (engine_wanted) {
+        // Census FIRST, on the plain stream the engine would use: an engine-shaped launch (one 512-thread workgroup per CU) must put
+        // exactly 32 workgroups on each of 8 XCDs, twice in a row with the same XCD map.  Only when that holds is the overlap given
+        // up for the engine; otherwise (partitioned GPU, another SKU, CUs busy with somebody else's persistent kernel) the engine
+        // falls back to the five-launch decode layer WITH the overlapped TAR pass, and says so.
+        HIPCHK(e, hipStreamCreate(&e->stream));
+        HIPCHK(e, oar_engine_prepare());
+        unsigned* d_cnt = nullptr;
+        HIPCHK(e, hipMalloc(&d_cnt, 64));
+        umgen_engine::EngStream& es = e->eng_fg;
+        es.ok = true;
+        for (int rep = 0; rep < 2 && es.ok; ++rep) {
+            unsigned cnt[16] = {};
+            if (hipMemsetAsync(d_cnt, 0, 64, e->stream) != hipSuccess || launch_oar_engine_census(e->stream, 8, d_cnt) != hipSuccess ||
+                hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) {
+                (void)hipGetLastError();
+                es.ok = false;
+                break;
+            }
+            if (getenv("UMGEN_DEBUG_TIMING")) {
+                fprintf(stderr, "[umgen] engine census:");
+                for (int x = 0; x < 16; ++x) fprintf(stderr, " %u", cnt[x]);
+                fprintf(stderr, "\n");
+            }
+            int groups = 0;
+            unsigned char map[16];
+            for (int x = 0; x < 16; ++x) {
+                map[x] = 0xff;
+                if (cnt[x] == (unsigned)kEngGroup) map[x] = (unsigned char)groups++;
+                else if (cnt[x] != 0) es.ok = false;
+            }
+            if (groups != 8 || (rep == 1 && memcmp(map, es.map, 16))) es.ok = false;
+            memcpy(es.map, map, 16);
+        }
+        (void)hipFree(d_cnt);
+        es.NG = 8;
+        e->eng_enabled = es.ok;
+        if (!es.ok) {
+            e->eng_fallback = true;
+            fprintf(stderr, "[umgen] WARNING: the XCD-resident decode engine cannot be used on device %d (its census did not find 32 workgroups on each "
+                            "of 8 XCDs); decode steps run as five launches per layer (~30 %% slower at one scene per GPU)\n", cfg->device);
+            HIPCHK(e, hipStreamDestroy(e->stream));
+            e->stream = nullptr;
+        }
+    }
+    e->overlap = cfg->max_cond_frames >= 2 && !e->eng_enabled;
+    if (ov_env) { e->overlap_mode = ov_env[0] - '0'; e->overlap = cfg->max_cond_frames >= 2 && ov_env[0] != '0'; }
     int bg_cus = 64;   // mask bits are striped over the 8 XCDs: 64 = 8 CUs of each XCD for the background stream
     if (const char* bc = getenv("UMGEN_BG_CUS")) bg_cus = std::max(32, std::min(128, atoi(bc)));
     if (e->overlap) {
@@ -1048,7 +1140,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         if (ncu < 2 * bg_cus) e->overlap = false;
         else {
             std::vector<uint32_t> mbg((ncu + 31) / 32, 0u), mfg((ncu + 31) / 32, 0u);
-            int fg_cus = ncu - bg_cus;   // UMGEN_FG_CUS: experiment, decode loop on fewer XCDs (32 CUs each)
+            int fg_cus = ncu - bg_cus;   // UMGEN_FG_CUS: experiment, decode loop on fewer CUs
             if (const char* fc = getenv("UMGEN_FG_CUS")) fg_cus = std::max(32, std::min(ncu - bg_cus, atoi(fc)));
             e->fg_xcds = fg_cus / 32;
             for (int cu = 0; cu < ncu; ++cu) {
@@ -1071,14 +1163,13 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
             }
         }
     }
-    if (!e->overlap) HIPCHK(e, hipStreamCreate(&e->stream));
+    if (!e->stream) HIPCHK(e, hipStreamCreate(&e->stream));
     for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
     e->E = cfg->n_embd;
     e->H = cfg->n_head;
-    if (const char* fd = getenv("UMGEN_FUSED_DECODE")) e->fused_decode = fd[0] == '1';
     if (const char* sl = getenv("UMGEN_DEBUG_SAME_LAYER")) e->dbg_same_layer = sl[0] == '1';
     if (const char* rb = getenv("UMGEN_ROWS_PER_BLOCK")) e->rows_per_block = rb[0] - '0';
-    e->tsz = cfg->precision == UMGEN_PREC_BF16 ? 2 : 4;
+    e->tsz = cfg->precision == UMGEN_PREC_FP32 ? 4 : 2;
     const int64_t E = e->E;
     const std::string t = "transformer.";
     // ---- parameters (names = the reference state-dict keys, UMGen.py:176-261) ----
@@ -1191,7 +1282,6 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (int rc = dalloc(e, &e->qkv3, 3 * Bm * 3 * E)) return rc;
     if (int rc = dalloc(e, &e->part, 3 * Bm * e->H * kAttnRec)) return rc;
     HIPCHK(e, hipMemset(e->part, 0, 3 * Bm * e->H * kAttnRec * sizeof(float)));   // never-written split slots are read with weight 0
-    if (int rc = dalloc(e, &e->kvnew, Bm * 2 * E)) return rc;
     if (int rc = dalloc(e, &e->hdec, 3 * Bm * 4 * E)) return rc;
     if (int rc = dalloc(e, &e->logits, 3 * Bm * 8192)) return rc;
     if (int rc = dalloc(e, &e->logits_tar, Bm * kNBox * (size_t)cfg->bbox3d_vocab)) return rc;
@@ -1229,7 +1319,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (int rc = dalloc(e, &e->d_seeds, Bm)) return rc;
     if (int rc = dalloc(e, &e->d_state, (size_t)1)) return rc;
     // ---- XCD-resident decode engine (UMGEN_DECODE_ENGINE=0 keeps the five-launch decode layer) ----
-    if (engine_wanted) {
+    if (e->eng_enabled) {
         if (int rc = dalloc(e, &e->d_layers, (size_t)cfg->n_oar_layer)) return rc;
         std::vector<OarLayerDev> hl(cfg->n_oar_layer);
         for (int i = 0; i < cfg->n_oar_layer; ++i) {
@@ -1252,45 +1342,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         HIPCHK(e, hipMemset(e->eng_gx, 0, Bm * kEngE * 8));
         HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
         HIPCHK(e, hipMemset(e->eng_err, 0, 16));
-        // census: an engine-shaped launch (one 512-thread workgroup per CU) must put exactly 32 workgroups on each of NG XCDs
-        auto census = [&](hipStream_t s, int NG, umgen_engine::EngStream& es) -> int {
-            unsigned* d_cnt;
-            if (int rc = dalloc(e, &d_cnt, (size_t)16)) return rc;
-            es.ok = false;
-            for (int rep = 0; rep < 2; ++rep) {      // twice: the placement must be reproducible
-                HIPCHK(e, hipMemsetAsync(d_cnt, 0, 64, s));
-                HIPCHK(e, launch_oar_engine_census(s, NG, d_cnt));
-                unsigned cnt[16];
-                HIPCHK(e, hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, s));
-                HIPCHK(e, hipStreamSynchronize(s));
-                if (getenv("UMGEN_DEBUG_TIMING")) {
-                    fprintf(stderr, "[umgen] engine census (%d groups asked):", NG);
-                    for (int x = 0; x < 16; ++x) fprintf(stderr, " %u", cnt[x]);
-                    fprintf(stderr, "\n");
-                }
-                int groups = 0;
-                unsigned char map[16];
-                bool good = true;
-                for (int x = 0; x < 16; ++x) {
-                    map[x] = 0xff;
-                    if (cnt[x] == (unsigned)kEngGroup) map[x] = (unsigned char)groups++;
-                    else if (cnt[x] != 0) good = false;
-                }
-                if (!good || groups != NG) return 0;
-                if (rep == 1 && memcmp(map, es.map, 16)) return 0;
-                memcpy(es.map, map, 16);
-            }
-            es.NG = NG;
-            es.ok = true;
-            return 0;
-        };
-        // (a CU-masked decode stream never passes: its CUs are spread over all XCDs)
-        // and with the overlap on (UMGEN_OVERLAP=1) every frame runs the five-launch decode layer: one decode path per engine)
-        if (!e->overlap) { if (int rc = census(e->stream, 8, e->eng_fg)) return rc; }
-        e->eng_enabled = e->eng_fg.ok || e->eng_full.ok;
-        if (getenv("UMGEN_DEBUG_TIMING"))
-            fprintf(stderr, "[umgen] decode engine: decode stream %s (%d XCDs), unmasked stream %s\n", e->eng_fg.ok ? "ok" : "off", e->eng_fg.NG,
-                    e->eng_full.ok ? "ok" : "off");
+        if (getenv("UMGEN_DEBUG_TIMING")) fprintf(stderr, "[umgen] decode engine: on (8 XCD groups)\n");
     }
     return UMGEN_OK;
 }
@@ -1308,7 +1360,12 @@ int umgen_load_tensor(umgen_engine* e, const char* key, const void* data, int32_
     }
     if (dtype < 0 || dtype > UMGEN_DT_F64) return e->fail(UMGEN_E_INVALID, "%s: dtype %d", key, dtype);
     const bool to_bf16 = (s.kind == 2) || (s.kind == 1 && e->cfg.precision == UMGEN_PREC_BF16);
-    if (to_bf16) {
+    if (s.kind == 1 && e->cfg.precision == UMGEN_PREC_FP16) {   // round-to-nearest-even to IEEE half, like torch's .half()
+        std::vector<f16_t> h(n);
+        if (dtype == UMGEN_DT_F16) memcpy(h.data(), data, n * 2);
+        else for (size_t i = 0; i < n; ++i) h[i] = (f16_t)load_as_f32(data, dtype, i);
+        HIPCHK(e, hipMemcpy(s.dst, h.data(), n * 2, hipMemcpyHostToDevice));
+    } else if (to_bf16) {
         std::vector<bf16_t> h(n);
         if (dtype == UMGEN_DT_BF16) memcpy(h.data(), data, n * 2);
         else for (size_t i = 0; i < n; ++i) h[i] = f32_to_bf16(load_as_f32(data, dtype, i));
@@ -1368,7 +1425,8 @@ int umgen_finalize_weights(umgen_engine* e) {
                     gp[((size_t)i * 32 + j) * E + c] = f32_to_bf16(bf16_to_f32(posi[(size_t)tok[i] * E + c]) + bf16_to_f32(posi[(size_t)tok[j] * E + c]));
         HIPCHK(e, hipMemcpy(const_cast<bf16_t*>(e->tb.grid_posi), gp.data(), gp.size() * 2, hipMemcpyHostToDevice));
     }
-    const int rc = e->cfg.precision == UMGEN_PREC_BF16 ? build_tables<bf16_t>(e) : build_tables<float>(e);
+    const int rc = e->cfg.precision == UMGEN_PREC_BF16 ? build_tables<bf16_t>(e)
+                 : e->cfg.precision == UMGEN_PREC_FP16 ? build_tables<f16_t>(e) : build_tables<float>(e);
     if (rc) return rc;
     if (e->eng_enabled) { if (int rc2 = repack_mlp_proj(e)) return rc2; }
     e->finalized = true;
@@ -1556,9 +1614,15 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
 int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in, float* x_out, int32_t use_engine, int32_t unmasked) {
     if (!e || !x_in || !x_out) return UMGEN_E_INVALID;
     if (!e->finalized) return e->fail(UMGEN_E_STATE, "umgen_finalize_weights has not been called");
-    if (e->cfg.precision != UMGEN_PREC_BF16) return e->fail(UMGEN_E_UNSUPPORTED, "bf16 engines only");
+    if (e->cfg.precision == UMGEN_PREC_FP32) return e->fail(UMGEN_E_UNSUPPORTED, "16-bit engines only");
     if (B < 1 || B > e->cfg.max_batch || L < 0 || L >= e->Lmax) return e->fail(UMGEN_E_INVALID, "B=%d L=%d", B, L);
     if (use_engine && !e->eng_enabled) return e->fail(UMGEN_E_UNSUPPORTED, "decode engine not available on this engine");
+    if (e->eng_enabled && e->eng_epoch > 0xE0000000u) {   // same wrap rule as run_frame
+        HIPCHK(e, hipDeviceSynchronize());
+        HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
+        HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
+        e->eng_epoch = 16u;
+    }
     const unsigned epoch = e->eng_epoch;   // tags never repeat across calls
     e->eng_epoch += kEpochPerStep;
     hipStream_t const keep = e->stream;
@@ -1569,9 +1633,10 @@ int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in,
     const bool en = e->eng_enabled;
     e->eng_enabled = en && use_engine;
     e->stream = st;
-    oar_layers<bf16_t>(e, B, attn_nsplit(L + 1), attn_nsplit(L));
+    const int lrc = e->cfg.precision == UMGEN_PREC_FP16 ? oar_layers<f16_t>(e, B, attn_nsplit(L + 1)) : oar_layers<bf16_t>(e, B, attn_nsplit(L + 1));
     e->stream = keep;
     e->eng_enabled = en;
+    if (lrc) return lrc;
     HIPCHK(e, hipMemcpyAsync(x_out, e->xdec, (size_t)B * e->E * 4, hipMemcpyDeviceToHost, st));
     unsigned eng_err = 0;
     if (use_engine) HIPCHK(e, hipMemcpyAsync(&eng_err, e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));

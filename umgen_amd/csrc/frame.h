@@ -34,7 +34,8 @@ struct WindowTokens {
     int t0 = 0;        // first slot of the pass: tokens and tpe are indexed with t0 + t_local
 };
 
-constexpr unsigned kEpochPerStep = 4096;   // hand-off tags one decode step may use (rounds x layers x edges)
+constexpr unsigned kEpochPerStep = 16384;  // hand-off tags one decode step may use: (round or scene <= 32) x (layer <= 64) x (edge <= 8)
+constexpr int kEngMaxSystolic = 32;        // scenes one systolic engine launch can carry (tag budget)
 
 struct SamplerParams {
     int method, top_k, top_k_map, topk_image;
@@ -73,7 +74,8 @@ struct SampleArgs {
     int* n_boxes;              // [B]
     const unsigned long long* seeds;   // [B]
     const int* forced;         // [B][2199] teacher forcing (valid when st->use_forced)
-    int* counters;             // [8] debug counters (pad_avoid, control, rule_checked, rule_collision, rule_blanked)
+    int* counters;             // [8] per-frame event counters (pad_avoid, control, rule_checked, rule_collision, rule_blanked, sampled != forced,
+                               //     -, 7: sampler kept-set overflows = more than 64 ties at the k-th logit -> the host fails the frame)
 };
 
 void launch_embed_stack(hipStream_t s, int stack, const EmbedTables& tb, const WindowTokens& w, float* X, float* mapfeat);
@@ -89,7 +91,7 @@ void launch_fixed_token(hipStream_t s, const SampleArgs& a, int B);             
 void launch_sample_token(hipStream_t s, const SampleArgs& a, int B);            // sampled steps
 // ego head: sample 3 pose tokens per scene from logits [B*3][vocab]
 void launch_sample_ego(hipStream_t s, const float* logits, int vocab, SamplerParams sp, const unsigned long long* seeds, int frame_idx,
-                       const int* forced, int* out_tokens, int B);
+                       const int* forced, int* out_tokens, int B, int* overflow);
 // ego query rows: egoe[j] + spe[j] + tpe[T-1]
 void launch_ego_queries(hipStream_t s, const EmbedTables& tb, int B, int T, float* x);
 

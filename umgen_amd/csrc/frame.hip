@@ -225,7 +225,7 @@ struct SampleShared {
 // barriers); wave 0 then holds the 4k candidates one per lane and ranks them with uniform readlane loops.  The final
 // softmax / inverse-CDF walk is sequential in ascending token index (bit-for-bit the oracle's order) but runs on
 // register values fetched with v_readlane, not on LDS round trips.
-__device__ int block_sample_topk(const float* __restrict__ logits, int V, int k, float temp, float u, int mask_idx, SampleShared& sh) {
+__device__ int block_sample_topk(const float* __restrict__ logits, int V, int k, float temp, float u, int mask_idx, SampleShared& sh, int* overflow) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float v[32], v0[32];   // v is consumed by the arg-max rounds, v0 keeps the logits for the kept-set pass
 #pragma unroll
@@ -284,6 +284,7 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
         }
     }
     __syncthreads();
+    if (tid == 0 && sh.n_kept > kMaxKept && overflow) atomicAdd(overflow, 1);   // more ties than the buffer holds: the frame is failed on the host
     if (wave == 0) {
         const int n = min(sh.n_kept, kMaxKept);
         // sort the kept set by token index: rank by uniform readlane loop, scatter through LDS, read back sorted
@@ -395,8 +396,8 @@ union SamplerLds {
 };
 // dispatch on the sampling method (UMGen.py:119-126): kparam is the top-k value, pparam the nucleus mass
 __device__ inline int block_sample(const SamplerParams& sp, const float* logits, int V, int kparam, float pparam, float u, int mask_idx,
-                                   SamplerLds& sh) {
-    return sp.method == 0 ? block_sample_topk(logits, V, kparam, sp.temperature, u, mask_idx, sh.k)
+                                   SamplerLds& sh, int* overflow) {
+    return sp.method == 0 ? block_sample_topk(logits, V, kparam, sp.temperature, u, mask_idx, sh.k, overflow)
                           : block_sample_topp(logits, V, pparam, sp.temperature, u, mask_idx, sh.p);
 }
 
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
     const int topk = a.mod == 1 ? sp.top_k_map : (a.mod == 3 ? sp.topk_image : sp.top_k);
     // top-p: the image head receives topk_image as its "p" (UMGen.py:1133) => the whole distribution is kept
     const float topp = a.mod == 1 ? sp.p_map : (a.mod == 3 ? (float)sp.topk_image : sp.p);
-    int tok = block_sample(sp, lg, a.vocab, topk, topp, rng_uniform(seed, frame, pos1, DRAW_MAIN), -1, sh);
+    int tok = block_sample(sp, lg, a.vocab, topk, topp, rng_uniform(seed, frame, pos1, DRAW_MAIN), -1, sh, a.counters + 7);
     int off, k;
     if (a.mod == 1) { off = kOffMap; k = j - kMapC0; }
     else if (a.mod == 2) { off = kOffBox; k = j - kBoxC0; }
@@ -522,12 +523,12 @@ __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
         if (use_control) {   // UMGen.py:1083-1089
             const int object_id = (pos1 - 1032) / kSlotLen;
             if (object_id < kSlots && a.control_slot[b * kSlots + object_id]) {
-                tok = block_sample(sp, lt, a.vocab, sp.top_k, sp.p, rng_uniform(seed, frame, pos1, DRAW_CONTROL), a.vocab - 1, sh);
+                tok = block_sample(sp, lt, a.vocab, sp.top_k, sp.p, rng_uniform(seed, frame, pos1, DRAW_CONTROL), a.vocab - 1, sh, a.counters + 7);
                 if (threadIdx.x == 0) atomicAdd(a.counters + 1, 1);
             }
         }
         if (tok == kBoxPad && sp.merge_ar_tar && prev != kBoxPad && !sp.only_ar) {   // UMGen.py:1092-1104
-            tok = block_sample(sp, lt, a.vocab, sp.top_k, sp.p, rng_uniform(seed, frame, pos1, DRAW_PAD_AVOID), -1, sh);
+            tok = block_sample(sp, lt, a.vocab, sp.top_k, sp.p, rng_uniform(seed, frame, pos1, DRAW_PAD_AVOID), -1, sh, a.counters + 7);
             if (threadIdx.x == 0) atomicAdd(a.counters + 0, 1);
         }
         if (sp.rule_constrain && !use_forced && tok != kBoxPad && (pos1 - 1032) % kSlotLen == 0) {   // UMGen.py:1116-1123
@@ -579,17 +580,17 @@ void launch_sample_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchK
 
 __global__ __launch_bounds__(256) void sample_ego_kernel(const float* __restrict__ logits, int vocab, SamplerParams sp,
                                                          const unsigned long long* __restrict__ seeds, int frame_idx,
-                                                         const int* __restrict__ forced, int* __restrict__ out_tokens) {
+                                                         const int* __restrict__ forced, int* __restrict__ out_tokens, int* overflow) {
     __shared__ SamplerLds sh;
     const int b = blockIdx.x / 3, jq = blockIdx.x % 3;
     int tok = block_sample(sp, logits + (long)blockIdx.x * vocab, vocab, sp.top_k, sp.p,
-                           rng_uniform(seeds[b], frame_idx, kSeq + jq, DRAW_MAIN), -1, sh);
+                           rng_uniform(seeds[b], frame_idx, kSeq + jq, DRAW_MAIN), -1, sh, overflow);
     if (forced) tok = forced[(long)b * kTokPerFrame + jq];
     if (threadIdx.x == 0) out_tokens[b * 3 + jq] = tok;
 }
 void launch_sample_ego(hipStream_t s, const float* logits, int vocab, SamplerParams sp, const unsigned long long* seeds, int frame_idx,
-                       const int* forced, int* out_tokens, int B) {
-    hipLaunchKernelGGL(sample_ego_kernel, dim3(B * 3), dim3(256), 0, s, logits, vocab, sp, seeds, frame_idx, forced, out_tokens);
+                       const int* forced, int* out_tokens, int B, int* overflow) {
+    hipLaunchKernelGGL(sample_ego_kernel, dim3(B * 3), dim3(256), 0, s, logits, vocab, sp, seeds, frame_idx, forced, out_tokens, overflow);
 }
 
 }  // namespace umgen

@@ -3,6 +3,8 @@
 //     128x128x64 tiles, 4 waves (2x2) per workgroup, XOR-swizzled LDS read with ds_read_b128, register-prefetched
 //     global->LDS staging.  Epilogues fuse bias, exact GELU, the fp32 residual add and the transposed V store.
 //   * gemm_valu: exact fp32 FMA chain (parity mode and the one-off GMLP(codebook) tables).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace umgen {
@@ -50,8 +52,9 @@ constexpr int BM = 128, BN = 128, BK = 64;
 
 __device__ inline int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }  // byte offset
 
-template <int MODE>
+template <int MODE, typename TT>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a, int nI, int nJ) {
+    typedef typename Mma16<TT>::vec vec8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * BM * BK * 2];   // double buffered: [buf][P tile | Q tile]
     const int z = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,13 +73,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a, int nI,
 #endif
     if (tj >= nJ) return;
     const int i_base = ti * BM, j_base = tj * BN;
-    const bf16_t* P = reinterpret_cast<const bf16_t*>(a.P) + (long)z * a.strideP;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q) + (long)z * a.strideQ;
+    const TT* P = reinterpret_cast<const TT*>(a.P) + (long)z * a.strideP;
+    const TT* Q = reinterpret_cast<const TT*>(a.Q) + (long)z * a.strideQ;
 
     // staging assignment: 4 x 16-byte chunks per operand per thread
     const int srow = tid >> 3, schunk = tid & 7;
-    const bf16_t* pp[4];
-    const bf16_t* qq[4];
+    const TT* pp[4];
+    const TT* qq[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         int r = srow + 32 * it;
@@ -120,16 +123,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a, int nI,
         const unsigned char* ldsQ = lds[kt & 1] + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t af[4], bfr[4];
+            vec8 af[4], bfr[4];
             const int c = kk * 4 + g;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const bf16x8_t*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
+            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const vec8*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bfr[n] = *reinterpret_cast<const bf16x8_t*>(ldsQ + swz(wj * 64 + n * 16 + frow, c));
+            for (int n = 0; n < 4; ++n) bfr[n] = *reinterpret_cast<const vec8*>(ldsQ + swz(wj * 64 + n * 16 + frow, c));
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 4; ++n) acc[m][n] = Mma16<TT>::mfma(af[m], bfr[n], acc[m][n]);
         }
         // tile kt+1 (already in registers) goes to the other buffer (last read in iteration kt-1), then tile kt+2 is requested
         if (kt + 1 < nkt) {
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a, int nI,
             const int i0 = i_base + wi * 64 + m * 16 + 4 * g;
             const int j = j_base + wj * 64 + n * 16 + frow;
             float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-            epilogue4<MODE, bf16_t>(a, z, i0, j, v);
+            epilogue4<MODE, TT>(a, z, i0, j, v);
         }
 }
 
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(GemmArgs a, int nI,
 // 374 us.  `stg` is a 32 KB slab buffer nobody reads any more ([128 tokens][128 features] bf16); 8-byte granule p of token t sits at
 // p ^ (t & 15): conflict-free for the MFMA-layout writes and for the row reads.  The caller guarantees a barrier before the buffer
 // is reused.
+template <typename TT>
 __device__ __forceinline__ void store_tile_rows_bf16(const GemmArgs& a, int z, int ti, int tj, const f32x4_t (&acc)[4][2], unsigned char* stg,
                                                      int tid, int wi, int wj, int frow, int g) {
     asm volatile("" ::: "memory");
@@ -175,12 +179,12 @@ __device__ __forceinline__ void store_tile_rows_bf16(const GemmArgs& a, int z, i
             }
             const int tl = wj * 32 + n * 16 + frow;
             const int pg = (wi * 16 + m * 4 + g) ^ frow;
-            store4(reinterpret_cast<bf16_t*>(stg + tl * 256 + pg * 8), o);
+            store4(reinterpret_cast<TT*>(stg + tl * 256 + pg * 8), o);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + (long)z * a.strideO + (long)ti * BM;
+    TT* out = reinterpret_cast<TT*>(a.out) + (long)z * a.strideO + (long)ti * BM;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int idx = tid + 512 * it;
@@ -247,8 +251,9 @@ __device__ __forceinline__ void rmw_tile_rows_f32(const GemmArgs& a, int z, int 
 // instruction, no staging VGPRs, no ds_write pass).  The LDS image is lane-linear per wave instruction, so the XOR swizzle is
 // applied to the per-lane SOURCE address (chunk c' of the image holds global chunk c' ^ (row & 7)).  Two LDS buffers: the
 // loads of tile kt+1 are in flight while tile kt is multiplied; one barrier per k-tile.  Requires K % 64 == 0.
-template <int MODE>
+template <int MODE, typename TT>
 __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmArgs a, int nI, int nJ) {
+    typedef typename Mma16<TT>::vec vec8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * BM * BK * 2];
     const int z = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -266,11 +271,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
     const int ti = (xcd & 1) * hI + lb % hI, tj = (xcd >> 1) * qJ + lb / hI;
     if (ti >= nI || tj >= nJ || ti >= ((xcd & 1) + 1) * hI || tj >= ((xcd >> 1) + 1) * qJ) return;
     const int i_base = ti * BM, j_base = tj * BN;
-    const bf16_t* P = reinterpret_cast<const bf16_t*>(a.P) + (long)z * a.strideP;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q) + (long)z * a.strideQ;
+    const TT* P = reinterpret_cast<const TT*>(a.P) + (long)z * a.strideP;
+    const TT* Q = reinterpret_cast<const TT*>(a.Q) + (long)z * a.strideQ;
     // wave w fills the 1 KB segments w, w+8 (8 rows each) of both operand images
-    const bf16_t* pp[2];
-    const bf16_t* qq[2];
+    const TT* pp[2];
+    const TT* qq[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int r = (wave + 8 * it) * 8 + (lane >> 3);
@@ -301,21 +306,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
         const unsigned char* ldsQ = lds[kt & 1] + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t af[4], bfr[2];
+            vec8 af[4], bfr[2];
             const int c = kk * 4 + g;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const bf16x8_t*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
+            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const vec8*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const bf16x8_t*>(ldsQ + swz(wj * 32 + n * 16 + frow, c));
+            for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const vec8*>(ldsQ + swz(wj * 32 + n * 16 + frow, c));
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 2; ++n) acc[m][n] = Mma16<TT>::mfma(af[m], bfr[n], acc[m][n]);
         }
         __syncthreads();
     }
     if (MODE == GEMM_STORE && a.Mi % BM == 0) {
-        store_tile_rows_bf16(a, z, ti, tj, acc, lds[0], tid, wi, wj, frow, g);   // (the loop's last barrier has retired every slab read)
+        store_tile_rows_bf16<TT>(a, z, ti, tj, acc, lds[0], tid, wi, wj, frow, g);   // (the loop's last barrier has retired every slab read)
         return;
     }
     if (MODE == GEMM_RESID && a.Mi % BM == 0) {
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
             const int i0 = i_base + wi * 64 + m * 16 + 4 * g;
             const int j = j_base + wj * 32 + n * 16 + frow;
             float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-            epilogue4<MODE, bf16_t>(a, z, i0, j, v);
+            epilogue4<MODE, TT>(a, z, i0, j, v);
         }
 }
 
@@ -338,16 +343,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds_kernel(GemmArgs a, int nI,
 // requested during the last k-step of the current one, so the epilogue (bias / GELU / residual read-modify-write) overlaps that
 // load instead of being followed by a cold HBM round trip.  At K = 768 a tile is only 12 k-steps, and the cold start was as long
 // as the whole MFMA loop.
-template <int MODE>
+template <int MODE, typename TT>
 __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI, int nJ) {
+    typedef typename Mma16<TT>::vec vec8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * BM * BK * 2];
     const int z = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 2, wj = wave & 3;
     const int hI = (nI + 1) >> 1, qJ = (nJ + 3) >> 2;
     const int total = 8 * hI * qJ;
-    const bf16_t* P = reinterpret_cast<const bf16_t*>(a.P) + (long)z * a.strideP;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q) + (long)z * a.strideQ;
+    const TT* P = reinterpret_cast<const TT*>(a.P) + (long)z * a.strideP;
+    const TT* Q = reinterpret_cast<const TT*>(a.Q) + (long)z * a.strideQ;
     auto decode = [&](int b, int& ti, int& tj) {   // false: id b names no tile (padding of the 2 x 4 XCD partition)
         const int xcd = b & 7, lb = b >> 3;
         ti = (xcd & 1) * hI + lb % hI;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI,
         while (b < total && !decode(b, ti, tj)) b += gridDim.x;
         return b;
     };
-    struct Src { const bf16_t* pp[2]; const bf16_t* qq[2]; };
+    struct Src { const TT* pp[2]; const TT* qq[2]; };
     auto sources = [&](int b) {
         int ti, tj;
         decode(b, ti, tj);
@@ -406,16 +412,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI,
             const unsigned char* ldsQ = lds[gs & 1] + BM * BK * 2;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t af[4], bfr[2];
+                vec8 af[4], bfr[2];
                 const int c = kk * 4 + g;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const bf16x8_t*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
+                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const vec8*>(ldsP + swz(wi * 64 + m * 16 + frow, c));
 #pragma unroll
-                for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const bf16x8_t*>(ldsQ + swz(wj * 32 + n * 16 + frow, c));
+                for (int n = 0; n < 2; ++n) bfr[n] = *reinterpret_cast<const vec8*>(ldsQ + swz(wj * 32 + n * 16 + frow, c));
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < 2; ++n) acc[m][n] = Mma16<TT>::mfma(af[m], bfr[n], acc[m][n]);
             }
             ++gs;
             if (kt + 1 < nkt) __syncthreads();   // (the last k-step's barrier is the one at the top of the next tile)
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI,
         if (MODE == GEMM_STORE && a.Mi % BM == 0) {
             // the staging tile is the slab buffer the last k-step just finished with (the other one already receives the next tile's
             // first slab)
-            store_tile_rows_bf16(a, z, ti, tj, acc, lds[(gs - 1) & 1], tid, wi, wj, frow, g);
+            store_tile_rows_bf16<TT>(a, z, ti, tj, acc, lds[(gs - 1) & 1], tid, wi, wj, frow, g);
         } else if (MODE == GEMM_RESID && a.Mi % BM == 0) {
             rmw_tile_rows_f32(a, z, ti, tj, acc, lds[(gs - 1) & 1], tid, wi, wj, frow, g);
         } else {
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI,
                     const int i0 = ti * BM + wi * 64 + m * 16 + 4 * g;
                     const int j = tj * BN + wj * 32 + n * 16 + frow;
                     float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-                    epilogue4<MODE, bf16_t>(a, z, i0, j, v);
+                    epilogue4<MODE, TT>(a, z, i0, j, v);
                 }
         }
         tile = nxt;
@@ -444,7 +450,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI,
     }
 }
 
-void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a) {
+template <typename TT>
+void launch_gemm_mfma(hipStream_t s, const GemmArgs& a) {
+    // large launches: the 256 x 256 deep-pipelined kernel (gemm256.hip); it needs >= 1.5 tiles per CU to fill the chip
+    static const int min_tiles256 = getenv("UMGEN_GEMM256_MIN_TILES") ? atoi(getenv("UMGEN_GEMM256_MIN_TILES")) : 384;
+    if (a.tile256 >= 0 && gemm256_supported(a) && (a.tile256 > 0 || (long)(a.Mi / 256) * ((a.Nj + 255) / 256) >= min_tiles256)) {
+        launch_gemm256<TT>(s, a);
+        return;
+    }
     const int nI = (a.Mi + BM - 1) / BM, nJ = (a.Nj + BN - 1) / BN;
     dim3 grid(((nJ + 7) / 8) * 8 * nI, 1, a.batch), block(256);
 #ifndef UMGEN_NO_PERSISTENT_GEMM
@@ -457,9 +470,9 @@ void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a) {
         }
         const dim3 pg(2 * n_cu, 1, 1), block8(512);   // 2 workgroups (64 KB of LDS each) per CU; 2 * n_cu is a multiple of 8
         switch (a.mode) {
-            case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_pers_kernel<GEMM_STORE>, pg, block8, 0, s, a, nI, nJ); break;
-            case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_pers_kernel<GEMM_RESID>, pg, block8, 0, s, a, nI, nJ); break;
-            default: hipLaunchKernelGGL(gemm_bf16_pers_kernel<GEMM_STORE_F32>, pg, block8, 0, s, a, nI, nJ); break;
+            case GEMM_STORE: hipLaunchKernelGGL((gemm_bf16_pers_kernel<GEMM_STORE, TT>), pg, block8, 0, s, a, nI, nJ); break;
+            case GEMM_RESID: hipLaunchKernelGGL((gemm_bf16_pers_kernel<GEMM_RESID, TT>), pg, block8, 0, s, a, nI, nJ); break;
+            default: hipLaunchKernelGGL((gemm_bf16_pers_kernel<GEMM_STORE_F32, TT>), pg, block8, 0, s, a, nI, nJ); break;
         }
         return;
     }
@@ -468,20 +481,22 @@ void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a) {
         grid = dim3(8 * ((nI + 1) / 2) * ((nJ + 3) / 4), 1, a.batch);
         const dim3 block8(512);
         switch (a.mode) {
-            case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_STORE>, grid, block8, 0, s, a, nI, nJ); break;
-            case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_RESID>, grid, block8, 0, s, a, nI, nJ); break;
-            case GEMM_STORE_F32: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_STORE_F32>, grid, block8, 0, s, a, nI, nJ); break;
-            default: hipLaunchKernelGGL(gemm_bf16_glds_kernel<GEMM_VT>, grid, block8, 0, s, a, nI, nJ); break;
+            case GEMM_STORE: hipLaunchKernelGGL((gemm_bf16_glds_kernel<GEMM_STORE, TT>), grid, block8, 0, s, a, nI, nJ); break;
+            case GEMM_RESID: hipLaunchKernelGGL((gemm_bf16_glds_kernel<GEMM_RESID, TT>), grid, block8, 0, s, a, nI, nJ); break;
+            case GEMM_STORE_F32: hipLaunchKernelGGL((gemm_bf16_glds_kernel<GEMM_STORE_F32, TT>), grid, block8, 0, s, a, nI, nJ); break;
+            default: hipLaunchKernelGGL((gemm_bf16_glds_kernel<GEMM_VT, TT>), grid, block8, 0, s, a, nI, nJ); break;
         }
         return;
     }
     switch (a.mode) {
-        case GEMM_STORE: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_STORE>, grid, block, 0, s, a, nI, nJ); break;
-        case GEMM_RESID: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_RESID>, grid, block, 0, s, a, nI, nJ); break;
-        case GEMM_STORE_F32: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_STORE_F32>, grid, block, 0, s, a, nI, nJ); break;
-        default: hipLaunchKernelGGL(gemm_bf16_mfma_kernel<GEMM_VT>, grid, block, 0, s, a, nI, nJ); break;
+        case GEMM_STORE: hipLaunchKernelGGL((gemm_bf16_mfma_kernel<GEMM_STORE, TT>), grid, block, 0, s, a, nI, nJ); break;
+        case GEMM_RESID: hipLaunchKernelGGL((gemm_bf16_mfma_kernel<GEMM_RESID, TT>), grid, block, 0, s, a, nI, nJ); break;
+        case GEMM_STORE_F32: hipLaunchKernelGGL((gemm_bf16_mfma_kernel<GEMM_STORE_F32, TT>), grid, block, 0, s, a, nI, nJ); break;
+        default: hipLaunchKernelGGL((gemm_bf16_mfma_kernel<GEMM_VT, TT>), grid, block, 0, s, a, nI, nJ); break;
     }
 }
+template void launch_gemm_mfma<bf16_t>(hipStream_t, const GemmArgs&);
+template void launch_gemm_mfma<f16_t>(hipStream_t, const GemmArgs&);
 
 // ---------------------------------------------------------------------------------------------------------
 // VALU fp32 (exact): 64x64 tile, 16-deep k-slab, each thread a 4(i) x 4(j) micro-tile; k ascending fmaf chain
@@ -544,5 +559,7 @@ void launch_gemm_valu(hipStream_t s, const GemmArgs& a) {
 template void launch_gemm_valu<float, float>(hipStream_t, const GemmArgs&);
 template void launch_gemm_valu<bf16_t, float>(hipStream_t, const GemmArgs&);   // bf16 weights x fp32 activations (tables)
 template void launch_gemm_valu<bf16_t, bf16_t>(hipStream_t, const GemmArgs&);
+template void launch_gemm_valu<f16_t, float>(hipStream_t, const GemmArgs&);
+template void launch_gemm_valu<f16_t, f16_t>(hipStream_t, const GemmArgs&);
 
 }  // namespace umgen

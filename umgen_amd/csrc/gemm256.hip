@@ -1,0 +1,332 @@
+// 256 x 256 x 64 MFMA GEMM for the TAR / ego prefill stacks (replaces F.linear at module.py:184-190, 236-242 on [B*T*S, E] rows):
+//     C[i][j] = sum_k P[i][k] Q[j][k]      P = weights [N features][K], Q = activations [R tokens][K], both K-contiguous, 16-bit
+// Round 2's 128 x 128 kernels (gemm.hip) reach 700-800 TFLOP/s on these shapes: one barrier per k-tile with a full vmcnt(0) drain,
+// operand feed saturated (TA busy 72-81 %).  This kernel is the deep-pipelined form of MI355X's playbook:
+//   * one 512-thread workgroup per CU (persistent, walks its XCD's tile list), 8 waves = 2 (features) x 4 (tokens), each wave a
+//     128 x 64 sub-tile = 8 x 4 MFMA tiles of v_mfma_f32_16x16x32 (128 accumulator VGPRs): twice the flops per LDS byte of the
+//     128 x 128 form;
+//   * operands go HBM -> LDS with global_load_lds (no staging registers), into a RING of 8 half-tile slots (128 rows x 64 k = 16 KB
+//     each, XOR-swizzled on the source side so that ds_read_b128 fragment reads are conflict-free): 2 k-tiles x {P half 0/1, Q half 0/1};
+//   * a k-tile is 4 phases of 16 MFMAs (one quadrant of the wave's sub-tile x the whole k-tile).  Every phase issues ONE half-tile
+//     refill into the slot whose last reader retired a phase earlier: the P halves of k-tile kt+1 in phases 0 / 1, the Q halves of
+//     k-tile kt+2 in phases 2 / 3 -- every load has >= 3 phases (~1.5k cycles) to land, and the loads of an output tile's first
+//     k-tiles are issued during the previous tile's last ones (the ring runs on across output tiles);
+//   * ONE counted wait per k-tile (phase 3: s_waitcnt vmcnt(4) = "everything but the two newest refills has landed"), raw
+//     s_barriers (no vmcnt(0) drain), fragment reads of phase p issued before the barrier that starts p's MFMA block;
+//   * epilogues (bias, erf-GELU, 16-bit / fp32 store, fp32 residual read-modify-write) go through a private 4 KB LDS strip per
+//     wave so that global memory sees whole 256-byte token-row pieces; no workgroup barrier inside the epilogue.
+// Accumulation order of every output element: k ascending in steps of 32 inside the MFMA, the same for every tile position, so
+// results do not depend on which other rows are in the launch (scenes stay batch-invariant).
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace umgen {
+
+namespace {
+
+constexpr int TM = 256, HK = 64;
+constexpr int kSlot = 128 * HK * 2;        // one half-tile: 128 rows x 64 k x 2 B = 16 KB
+constexpr int kRing = 8 * kSlot;           // 128 KB
+constexpr int kStage = 4096;               // epilogue strip per wave
+constexpr int kLds256 = kRing + 8 * kStage;   // 160 KB: one workgroup per CU
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }   // byte offset in a slot
+
+struct Src { unsigned p[2][2], q[2][2]; };   // element offsets of this lane's 16-byte pieces: [half][segment group]
+
+template <int MODE, typename TT>
+__global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int nJ, int splitI) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    typedef typename Mma16<TT>::vec vec8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 2, wj = wave & 3;
+    const int frow = lane & 15, g = lane >> 4;
+    const TT* P = reinterpret_cast<const TT*>(a.P);
+    const TT* Q = reinterpret_cast<const TT*>(a.Q);
+    const int nkt = a.K / HK;                 // even (launcher)
+    // ---- this XCD's tile list (block b runs on XCD b % 8): splitI feature groups x (8 / splitI) token groups; inside a group the
+    //      feature tiles of one token tile are consecutive, so the 32 workgroups of the XCD share activation tiles through its L2
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int gJ = 8 / splitI;
+    const int hI = (nI + splitI - 1) / splitI, qJ = (nJ + gJ - 1) / gJ;
+    const int i0 = (xcd % splitI) * hI, j0 = (xcd / splitI) * qJ;
+    const int ni = max(0, min(nI, i0 + hI) - i0), nj = max(0, min(nJ, j0 + qJ) - j0);
+    const int count = ni * nj;
+    int t = lb;
+    if (t >= count) return;
+    auto make_src = [&](int tt) {
+        const int ti = i0 + tt % ni, tj = j0 + tt / ni;
+        Src s;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+                const int row = (wave + 8 * sg) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (row & 7);
+                s.p[h][sg] = (unsigned)((long)(ti * TM + h * 128 + row) * a.ldp + c * 8);
+                s.q[h][sg] = (unsigned)((long)min(tj * TM + h * 128 + row, a.Nj - 1) * a.ldq + c * 8);
+            }
+        return s;
+    };
+    auto issue = [&](int slot, const TT* base, const unsigned (&off)[2], int k0) {
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+            __builtin_amdgcn_global_load_lds((const void*)(base + off[sg] + k0),
+                                             (__attribute__((address_space(3))) void*)(lds + slot * kSlot + (wave + 8 * sg) * 1024), 16, 0, 0);
+    };
+    // ring slot of (k-tile parity, kind): kind 0 / 1 = P half 0 / 1, 2 / 3 = Q half 0 / 1
+    Src cur = make_src(t);
+    // prologue: k-tile 0 entirely, the Q halves of k-tile 1 (its P halves follow in phases 0 / 1 of k-tile 0)
+    issue(2, Q, cur.q[0], 0);
+    issue(3, Q, cur.q[1], 0);
+    issue(0, P, cur.p[0], 0);
+    issue(1, P, cur.p[1], 0);
+    issue(4 + 2, Q, cur.q[0], HK);
+    issue(4 + 3, Q, cur.q[1], HK);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    unsigned char* stage = lds + kRing + wave * kStage;
+    while (true) {
+        const int tn = t + nloc;
+        const bool has_next = tn < count;
+        Src nxt = cur;
+        if (has_next) nxt = make_src(tn);
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int par = kt & 1;
+            const unsigned char* sP = lds + (par * 4 + wi) * kSlot;                      // this wave's P half (128 features)
+            const unsigned char* sQ = lds + (par * 4 + 2 + (wj >> 1)) * kSlot + (wj & 1) * 64 * 128;   // its 64 tokens inside a Q half
+            // refills of this k-tile: P halves of k-tile kt + 1 (phases 0, 1), Q halves of k-tile kt + 2 (phases 2, 3)
+            const bool in1 = kt + 1 < nkt, in2 = kt + 2 < nkt;
+            const bool do1 = in1 || has_next, do2 = in2 || has_next;
+            const Src& s1 = in1 ? cur : nxt;
+            const Src& s2 = in2 ? cur : nxt;
+            const int k1 = (in1 ? kt + 1 : kt + 1 - nkt) * HK, k2 = (in2 ? kt + 2 : kt + 2 - nkt) * HK;
+            const int par1 = par ^ 1;
+            vec8 fa[4][2], fb0[2][2], fb1[2][2];
+            // ---------------- phase 0: quadrant (features 0..63, tokens 0..31) ----------------
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fb0[n][kk] = *reinterpret_cast<const vec8*>(sQ + swz(n * 16 + frow, kk * 4 + g));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *reinterpret_cast<const vec8*>(sP + swz(m * 16 + frow, kk * 4 + g));
+            if (do1) issue(par1 * 4 + 0, P, s1.p[0], k1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = Mma16<TT>::mfma(fa[m][kk], fb0[n][kk], acc[m][n]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- phase 1: quadrant (features 0..63, tokens 32..63) ----------------
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fb1[n][kk] = *reinterpret_cast<const vec8*>(sQ + swz((2 + n) * 16 + frow, kk * 4 + g));
+            if (do1) issue(par1 * 4 + 1, P, s1.p[1], k1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][2 + n] = Mma16<TT>::mfma(fa[m][kk], fb1[n][kk], acc[m][2 + n]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- phase 2: quadrant (features 64..127, tokens 32..63) ----------------
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *reinterpret_cast<const vec8*>(sP + swz((4 + m) * 16 + frow, kk * 4 + g));
+            if (do2) issue(par * 4 + 2, Q, s2.q[0], k2);       // (the Q slots of this k-tile: their last reads were phase 1's)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[4 + m][2 + n] = Mma16<TT>::mfma(fa[m][kk], fb1[n][kk], acc[4 + m][2 + n]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- phase 3: quadrant (features 64..127, tokens 0..31); the k-tile's one counted wait ----------------
+            if (do2) {
+                issue(par * 4 + 3, Q, s2.q[1], k2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all of k-tile kt + 1 has landed (only this k-tile's two Q refills may be in flight)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[4 + m][n] = Mma16<TT>::mfma(fa[m][kk], fb0[n][kk], acc[4 + m][n]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        // ---------------- epilogue of this wave's 128 features x 64 tokens (private LDS strip, no workgroup barrier) ----------------
+        const int ti = i0 + t % ni, tj = j0 + t / ni;
+        const int fbase = ti * TM + wi * 128;            // first feature of the wave
+        const int tbase = tj * TM + wj * 64;             // first token of the wave
+        // bias of this lane's 32 features (the fragment registers are free now); one wait for all eight loads
+        float bv[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (a.bias) load4(a.bias + fbase + m * 16 + 4 * g, bv[m]);
+            else { bv[m][0] = 0.f; bv[m][1] = 0.f; bv[m][2] = 0.f; bv[m][3] = 0.f; }
+        }
+        if (MODE == GEMM_STORE) {
+            TT* out = reinterpret_cast<TT*>(a.out);
+            auto run = [&](auto gelu_tag) {
+                constexpr bool GELU = decltype(gelu_tag)::value;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[m][n][r] + bv[m][r];
+                            o[r] = GELU ? gelu_erf(v) : v;
+                        }
+                        store4(reinterpret_cast<TT*>(stage + frow * 256 + (((m * 4 + g) ^ frow) << 3)), o);   // 8-byte granule p of token t at p ^ t
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int tl = it * 4 + (lane >> 4), q = lane & 15;
+                        const int pos = ((2 * q) ^ tl) & ~1;
+                        uint4 v = *reinterpret_cast<const uint4*>(stage + tl * 256 + pos * 8);
+                        if (tl & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+                        const int token = tbase + n * 16 + tl;
+                        if (token < a.Nj) {
+                            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                            __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(out + (long)token * a.ldo + fbase + 8 * q));
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next n overwrites it
+                }
+            };
+            if (a.gelu) run(std::true_type{}); else run(std::false_type{});
+        } else {   // GEMM_RESID (x += acc + bias) / GEMM_STORE_F32: fp32 rows, 64 features per pass
+            float* out = reinterpret_cast<float*>(a.out);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                // the read-modify-write's loads of both 64-feature passes go out first: one memory round trip per 16 tokens
+                float4 xo[2][4];
+                if (MODE == GEMM_RESID) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int token = min(tbase + n * 16 + it * 4 + (lane >> 4), a.Nj - 1);
+                            xo[hf][it] = *reinterpret_cast<const float4*>(out + (long)token * a.ldo + fbase + hf * 64 + 4 * (lane & 15));
+                        }
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm) {
+                        const int m = hf * 4 + mm;
+                        const float4 o = make_float4(acc[m][n][0] + bv[m][0], acc[m][n][1] + bv[m][1], acc[m][n][2] + bv[m][2], acc[m][n][3] + bv[m][3]);
+                        *reinterpret_cast<float4*>(stage + frow * 256 + (((mm * 4 + g) ^ frow) << 4)) = o;   // 16-byte granule p of token t at p ^ t
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int tl = it * 4 + (lane >> 4), q = lane & 15;
+                        const float4 v = *reinterpret_cast<const float4*>(stage + tl * 256 + ((q ^ tl) << 4));
+                        const int token = tbase + n * 16 + tl;
+                        if (token < a.Nj) {
+                            float* x = out + (long)token * a.ldo + fbase + hf * 64 + 4 * q;
+                            if (MODE == GEMM_RESID) {
+                                const float4 c = xo[hf][it];
+                                *reinterpret_cast<float4*>(x) = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);   // x + (acc + bias), as every other residual epilogue
+                            } else {
+                                *reinterpret_cast<float4*>(x) = v;
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        }
+        if (!has_next) break;
+        t = tn;
+        cur = nxt;
+    }
+}
+
+}  // namespace
+
+size_t gemm256_lds_bytes() { return (size_t)kLds256; }
+
+// true when the 256-tile kernel can run this GEMM (otherwise the caller keeps the 128-tile kernels of gemm.hip)
+bool gemm256_supported(const GemmArgs& a) {
+    if (a.batch != 1 || (a.mode != GEMM_STORE && a.mode != GEMM_RESID && a.mode != GEMM_STORE_F32)) return false;
+    if (a.Mi % TM != 0 || a.K % (2 * HK) != 0 || a.K < 2 * HK) return false;
+    if ((long)a.Nj * a.ldq >= (1L << 32) / 2 || (long)a.Mi * a.ldp >= (1L << 32) / 2) return false;   // 32-bit element offsets
+    return true;
+}
+
+hipError_t gemm256_prepare() {
+    const void* fns[] = {
+        reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE, bf16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_RESID, bf16_t>),
+        reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE_F32, bf16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE, f16_t>),
+        reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_RESID, f16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE_F32, f16_t>)};
+    for (const void* f : fns) {
+        hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLds256);
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+}
+
+template <typename TT>
+void launch_gemm256(hipStream_t s, const GemmArgs& a) {
+    static int n_cu = 0;
+    static bool prepared = false;
+    if (!prepared) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        n_cu = (n_cu / 8) * 8;
+        (void)gemm256_prepare();
+        prepared = true;
+    }
+    const int nI = a.Mi / TM, nJ = (a.Nj + TM - 1) / TM;
+    // feature split over the XCDs only when the weight matrix would not stay in one 4 MB L2 and the feature tiles divide evenly
+    const int splitI = (nI % 2 == 0 && (size_t)a.Mi * a.K * 2 > (size_t)(3u << 20)) ? 2 : 1;
+    const dim3 grid(n_cu), block(512);
+    switch (a.mode) {
+        case GEMM_STORE: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE, TT>), grid, block, kLds256, s, a, nI, nJ, splitI); break;
+        case GEMM_RESID: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_RESID, TT>), grid, block, kLds256, s, a, nI, nJ, splitI); break;
+        default: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE_F32, TT>), grid, block, kLds256, s, a, nI, nJ, splitI); break;
+    }
+}
+template void launch_gemm256<bf16_t>(hipStream_t, const GemmArgs&);
+template void launch_gemm256<f16_t>(hipStream_t, const GemmArgs&);
+
+}  // namespace umgen

@@ -15,6 +15,7 @@ namespace umgen {
 
 template <typename T> struct WChunk;                      // 8 consecutive weights of one row
 template <> struct WChunk<bf16_t> { uint4 v; };
+template <> struct WChunk<f16_t> { uint4 v; };
 template <> struct WChunk<float> { float4 a, b; };
 
 // weights are streamed exactly once per launch: non-temporal loads (MI355X_MICROARCH.md "nt-weights": issue->landed -18 %)
@@ -31,6 +32,12 @@ __device__ inline void wload(WChunk<bf16_t>& w, const bf16_t* p) {
     }
 #endif
     w.v = *reinterpret_cast<const uint4*>(p);
+}
+template <bool NT = true>
+__device__ inline void wload(WChunk<f16_t>& w, const f16_t* p) {
+    WChunk<bf16_t> t;
+    wload<NT>(t, reinterpret_cast<const bf16_t*>(p));
+    w.v = t.v;
 }
 template <bool NT = true>
 __device__ inline void wload(WChunk<float>& w, const float* p) {
@@ -56,12 +63,18 @@ __device__ inline void tile_row_of_block(int bid, int rows, int& tile, int& row)
 }
 inline int tile_row_grid(int tiles, int rows) { return ((tiles + 7) / 8) * 8 * rows; }
 __device__ inline void wzero(WChunk<bf16_t>& w) { w.v = make_uint4(0, 0, 0, 0); }
+__device__ inline void wzero(WChunk<f16_t>& w) { w.v = make_uint4(0, 0, 0, 0); }
 __device__ inline void wzero(WChunk<float>& w) { w.a = make_float4(0, 0, 0, 0); w.b = w.a; }
 __device__ inline void wunpack(const WChunk<bf16_t>& w, float (&o)[8]) {
     o[0] = __uint_as_float(w.v.x << 16); o[1] = __uint_as_float(w.v.x & 0xffff0000u);
     o[2] = __uint_as_float(w.v.y << 16); o[3] = __uint_as_float(w.v.y & 0xffff0000u);
     o[4] = __uint_as_float(w.v.z << 16); o[5] = __uint_as_float(w.v.z & 0xffff0000u);
     o[6] = __uint_as_float(w.v.w << 16); o[7] = __uint_as_float(w.v.w & 0xffff0000u);
+}
+__device__ inline void wunpack(const WChunk<f16_t>& w, float (&o)[8]) {
+    const f16x8_t h = __builtin_bit_cast(f16x8_t, w.v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)h[e];
 }
 __device__ inline void wunpack(const WChunk<float>& w, float (&o)[8]) {
     o[0] = w.a.x; o[1] = w.a.y; o[2] = w.a.z; o[3] = w.a.w; o[4] = w.b.x; o[5] = w.b.y; o[6] = w.b.z; o[7] = w.b.w;
@@ -175,7 +188,6 @@ __device__ __forceinline__ void gemv_ln_body(const GemvArgs& a, int bid) {
                                 const long H = a.E / kHeadDim;
                                 reinterpret_cast<T*>(a.cache)[(long)mm * a.scene_stride + ((kvsel * H + hc / kHeadDim) * a.Lmax + pos) * kHeadDim +
                                                               hc % kHeadDim] = Cvt<T>::from_f(v);
-                                if (a.kv_f32) a.kv_f32[(long)mm * 2 * a.E + c] = v;
                             }
                         } else {
                             // (head logits are read by ONE workgroup right away: a plain store keeps them in the L2)
@@ -220,6 +232,7 @@ void launch_gemv(hipStream_t s, const GemvArgs& a) {
 }
 template void launch_gemv<float>(hipStream_t, const GemvArgs&);
 template void launch_gemv<bf16_t>(hipStream_t, const GemvArgs&);
+template void launch_gemv<f16_t>(hipStream_t, const GemvArgs&);
 
 // ---------------------------------------------------------------------------------------------------------
 // x[m][n] += (sum_k a[m][k] W[n][k]) + bias[n]    one weight row per wave; K = n_embd or 4 n_embd (NCH chunks)
@@ -243,7 +256,6 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a_in) {
         a.x += (long)mb * a.ldx;
         if (a.a) a.a += (long)mb * a.lda;
         if (a.part) a.part += (long)mb * a.H * kAttnRec;
-        if (a.self_q) { a.self_q += (long)mb * a.K; a.self_kv += (long)mb * 2 * a.K; }
     }
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
@@ -297,32 +309,13 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a_in) {
             float mx = -INFINITY;
 #pragma unroll
             for (int sp = 0; sp < kAttnPad; ++sp) { if (sp >= ns) pm[sp] = -INFINITY; mx = fmaxf(mx, pm[sp]); }
-            // the new token's own key (fused decode attention): one more softmax term with l = 1, stored in the last pad slot
-            float s_self = -INFINITY;
-            if (a.self_q) {
-                const int m = tid / a.H, h = tid % a.H;
-                const float* qs = a.self_q + (long)m * K + h * kHeadDim;
-                const float* ks = a.self_kv + (long)m * 2 * K + h * kHeadDim;
-                float d = 0.f;
-#pragma unroll
-                for (int e4 = 0; e4 < kHeadDim; e4 += 4) {
-                    float q4[4], k4[4];
-                    load4(qs + e4, q4);
-                    load4(ks + e4, k4);
-                    d = fmaf(q4[0], k4[0], d); d = fmaf(q4[1], k4[1], d); d = fmaf(q4[2], k4[2], d); d = fmaf(q4[3], k4[3], d);
-                }
-                s_self = d * 0.14433756729740643f;
-                mx = fmaxf(mx, s_self);
-            }
             float l = 0.f;
 #pragma unroll
             for (int sp = 0; sp < kAttnPad; ++sp) { pm[sp] = expf(pm[sp] - mx); l = fmaf(pm[sp], (sp < ns) ? pl[sp] : 0.f, l); }
-            const float w_self = a.self_q ? expf(s_self - mx) : 0.f;
-            l += w_self;
             const float inv = 1.0f / l;
 #pragma unroll
             for (int sp = 0; sp < kAttnPad - 1; ++sp) s_w[tid * kAttnPad + sp] = pm[sp] * inv;
-            s_w[tid * kAttnPad + kAttnPad - 1] = w_self * inv;     // kAttnSplit <= kAttnPad - 1, so this slot is never a split
+            s_w[tid * kAttnPad + kAttnPad - 1] = 0.f;              // kAttnSplit <= kAttnPad - 1, so this slot is never a split
         }
         __syncthreads();
         // 3. fold, 768 columns at a time
@@ -342,7 +335,6 @@ __global__ __launch_bounds__(256) void gemv_resid_kernel(GemvResidArgs a_in) {
                         o = fmaf(w[4 * i + 2], ov[it][i].z, o);
                         if (4 * i + 3 < kAttnPad - 1) o = fmaf(w[4 * i + 3], ov[it][i].w, o);
                     }
-                    if (a.self_q) o = fmaf(w[kAttnPad - 1], a.self_kv[(long)m * 2 * K + K + col], o);
                     as[e] = o;
                 }
             }
@@ -423,7 +415,6 @@ void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a0) {
             b.M = min(8, a0.M - m);
             b.part = a0.part + (long)m * a0.H * kAttnRec;
             b.x = a0.x + (long)m * a0.ldx;
-            if (a0.self_q) { b.self_q = a0.self_q + (long)m * a0.K; b.self_kv = a0.self_kv + (long)m * 2 * a0.K; }
             launch_gemv_resid<T>(s, b);
         }
         return;
@@ -442,6 +433,7 @@ void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a0) {
 }
 template void launch_gemv_resid<float>(hipStream_t, const GemvResidArgs&);
 template void launch_gemv_resid<bf16_t>(hipStream_t, const GemvResidArgs&);
+template void launch_gemv_resid<f16_t>(hipStream_t, const GemvResidArgs&);
 
 // ---------------------------------------------------------------------------------------------------------
 // few-query attention, partial pass over one slice of <= kAttnChunk keys (OAR decode step; ego-decoder self/cross attention).
@@ -453,40 +445,25 @@ constexpr float kScale = 0.14433756729740643f;   // float32(1/sqrt(48)), module.
 constexpr int kKeyPass = kAttnChunk / 32;        // keys per thread (32 keys per pass of the 256 threads)
 
 struct AttnGeom {
-    const float* q;            // [NQ][E] (nullptr when the block computes q itself)
+    const float* q;            // [NQ][E]
     const void* kv_base; long scene_stride, head_stride, key_stride, v_off;
     int q_per_scene, H;
     const int* d_len; int len_add, kmax;
     float* part;
 };
 
-// One (head h, key split, query qi) block.  FUSEQ: q_h = (LN(x[qi]) . Wq[h*48 .. h*48+47] + bq) is computed here (wave w
-// owns rows 12w .. 12w+11; every weight byte is requested up front together with the K/V rows).
-template <typename T, bool FUSEQ, int NCH>
-__device__ __forceinline__ void attn_body(const AttnGeom& g, const GemvArgs* ga, int h, int split, int qi) {
+// One (head h, key split, query qi) block.
+template <typename T>
+__device__ __forceinline__ void attn_body(const AttnGeom& g, int h, int split, int qi) {
     __shared__ float s_max[4];
     __shared__ float s_sum[16];
     __shared__ float s_o[16][kHeadDim];          // one partial per (wave, row of 16 lanes)
-    __shared__ __attribute__((aligned(16))) float s_q[kHeadDim];
     const int H = g.H;
     const int E = H * kHeadDim;
     const int k0 = split * kAttnChunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int piece = tid & 7, kg = tid >> 3;        // 32 key groups
     const bool pact = piece < 6;
-    WChunk<T> wq[FUSEQ ? 12 : 1][FUSEQ ? NCH : 1];
-    if (FUSEQ) {
-        const T* W = reinterpret_cast<const T*>(ga->W);
-#pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            const T* wr = W + (long)(h * kHeadDim + wave * 12 + r) * E;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = lane * 8 + 512 * i;
-                if (c < E) wload(wq[r][i], wr + c); else wzero(wq[r][i]);
-            }
-        }
-    }
     const T* base = reinterpret_cast<const T*>(g.kv_base) + (long)(qi / g.q_per_scene) * g.scene_stride + h * g.head_stride + piece * 8;
     float kf[kKeyPass][8], vf[kKeyPass][8];
 #pragma unroll
@@ -504,68 +481,10 @@ __device__ __forceinline__ void attn_body(const AttnGeom& g, const GemvArgs* ga,
         }
     }
     float q8[8];
-    if (FUSEQ) {
-        // LayerNorm of x[qi] in registers (chunk layout of the dot products), redundantly per wave
-        float xv[NCH][8], lw[NCH][8];
-        const float* xr = ga->x + (long)qi * ga->ldx;
+    if (pact) load8(g.q + (long)qi * E + h * kHeadDim + piece * 8, q8);
+    else {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane * 8 + 512 * i;
-            if (c < E) { load8(xr + c, xv[i]); load8(ga->ln_w + c, lw[i]); }
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xv[i][e] = 0.f; lw[i][e] = 0.f; }
-            }
-        }
-        float bq = 0.f;
-        if (lane < 12) bq = ga->bias[h * kHeadDim + wave * 12 + lane];
-        float sx = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sx += xv[i][e];
-        const float mean = wave_sum(sx) / (float)E;
-        float sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-            if (lane * 8 + 512 * i < E) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; sq += d * d; }
-            }
-        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)E + 1e-5f);
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-            if (lane * 8 + 512 * i < E) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[i][e] = (xv[i][e] - mean) * rstd * lw[i][e];
-            }
-        float qr = 0.f;   // lane r (< 12) ends up holding row r's dot product
-#pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                float w8[8];
-                wunpack(wq[r][i], w8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc = fmaf(w8[e], xv[i][e], acc);
-            }
-            acc = wave_sum(acc);
-            if (lane == r) qr = acc;
-        }
-        if (lane < 12) s_q[wave * 12 + lane] = qr + bq;
-        __syncthreads();
-        if (pact) load8(s_q + piece * 8, q8);
-        else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) q8[e] = 0.f;
-        }
-    } else {
-        if (pact) load8(g.q + (long)qi * E + h * kHeadDim + piece * 8, q8);
-        else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) q8[e] = 0.f;
-        }
+        for (int e = 0; e < 8; ++e) q8[e] = 0.f;
     }
     const int L = (g.d_len ? *g.d_len : 0) + g.len_add;
     const int k1 = min(L, k0 + kAttnChunk);
@@ -630,44 +549,8 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(AttnGeom g) {
 #ifdef UMGEN_DRY_DECODE
     return;
 #endif
-    attn_body<T, false, 1>(g, nullptr, blockIdx.x, blockIdx.y, blockIdx.z);
+    attn_body<T>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
-
-// fused decode kernel: blocks [0, nA) = role A (LN + c_attn GEMV of the new token), the rest = role B (attention partials over
-// the cached keys with q recomputed per block)
-template <typename T, int MB, int NCH, int RPW>
-__global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a, AttnGeom g, int nA) {
-#ifdef UMGEN_DRY_DECODE
-    return;
-#endif
-    if ((int)blockIdx.x < nA) {
-        gemv_ln_body<T, MB, NCH, RPW>(a.g, blockIdx.x);
-    } else {
-        const int bid = blockIdx.x - nA;
-        const int h = bid % a.H, split = (bid / a.H) % a.ns, qi = bid / (a.H * a.ns);
-        attn_body<T, true, NCH>(g, &a.g, h, split, qi);
-    }
-}
-
-template <typename T, int NCH>
-static void launch_qkv_attn_nch(hipStream_t s, const QkvAttnArgs& a) {
-    constexpr int RPW = 2;
-    const int nA = (a.g.N + 4 * RPW - 1) / (4 * RPW);
-    AttnGeom g{nullptr, a.g.cache, a.g.scene_stride, a.head_stride, a.key_stride, a.v_off, 1, a.H, a.g.d_len, 0,
-               kAttnSplit * kAttnChunk, a.part};
-    const int grid = nA + a.H * a.ns * a.g.M;
-    if (a.g.M == 1) hipLaunchKernelGGL((qkv_attn_kernel<T, 1, NCH, RPW>), dim3(grid), dim3(256), 0, s, a, g, nA);
-    else if (a.g.M == 2) hipLaunchKernelGGL((qkv_attn_kernel<T, 2, NCH, RPW>), dim3(grid), dim3(256), 0, s, a, g, nA);
-    else hipLaunchKernelGGL((qkv_attn_kernel<T, 4, NCH, RPW>), dim3(grid), dim3(256), 0, s, a, g, nA);
-}
-template <typename T>
-void launch_qkv_attn(hipStream_t s, const QkvAttnArgs& a) {
-    if (a.g.K <= 512) launch_qkv_attn_nch<T, 1>(s, a);
-    else if (a.g.K <= 1024) launch_qkv_attn_nch<T, 2>(s, a);
-    else launch_qkv_attn_nch<T, 3>(s, a);
-}
-template void launch_qkv_attn<float>(hipStream_t, const QkvAttnArgs&);
-template void launch_qkv_attn<bf16_t>(hipStream_t, const QkvAttnArgs&);
 
 template <typename T>
 void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long scene_stride, long head_stride, long key_stride, long v_off,
@@ -679,5 +562,6 @@ void launch_attn_partial(hipStream_t s, const float* q, const T* kv_base, long s
 }
 template void launch_attn_partial<float>(hipStream_t, const float*, const float*, long, long, long, long, int, int, int, const int*, int, int, float*);
 template void launch_attn_partial<bf16_t>(hipStream_t, const float*, const bf16_t*, long, long, long, long, int, int, int, const int*, int, int, float*);
+template void launch_attn_partial<f16_t>(hipStream_t, const float*, const f16_t*, long, long, long, long, int, int, int, const int*, int, int, float*);
 
 }  // namespace umgen

@@ -29,8 +29,12 @@ struct GemmArgs {
     long ldo;
     long strideO;            // per batch z (GEMM_STORE/RESID/F32 only)
     int H;                   // heads (GEMM_VT)
+    int tile256;             // 0: the launcher picks the kernel; 1: force the 256 x 256 kernel when it supports the shape; -1: never use it
 };
-void launch_gemm_bf16_mfma(hipStream_t s, const GemmArgs& a);               // P,Q bf16, MFMA 16x16x32
+// gemm256.hip: 256 x 256 x 64 deep-pipelined kernel (GEMM_STORE / RESID / STORE_F32, batch 1, Mi % 256 == 0, K % 128 == 0)
+bool gemm256_supported(const GemmArgs& a);
+template <typename TT> void launch_gemm256(hipStream_t s, const GemmArgs& a);
+template <typename TT> void launch_gemm_mfma(hipStream_t s, const GemmArgs& a);   // P, Q of the 16-bit type TT (bf16_t / f16_t), MFMA 16x16x32
 template <typename TP, typename TQ> void launch_gemm_valu(hipStream_t s, const GemmArgs& a);  // exact fp32 FMA chain
 
 // ------------------------------------------------------------------------------------------------
@@ -43,12 +47,12 @@ template <typename T> void launch_layernorm(hipStream_t s, const float* x, long 
 // attention (head_dim 48)
 // ------------------------------------------------------------------------------------------------
 // spatial (non-causal) attention inside each frame: qk [F*S][2E] row-major (q | k), vt [F][H][48][S_pad], y [F*S][E]
-void launch_attn_spatial_bf16_mfma(hipStream_t s, const bf16_t* qk, const bf16_t* vt, bf16_t* y, int F, int S, int S_pad, int H);
+template <typename TT> void launch_attn_spatial_mfma(hipStream_t s, const TT* qk, const TT* vt, TT* y, int F, int S, int S_pad, int H);   // TT = bf16_t / f16_t
 template <typename T> void launch_attn_spatial_valu(hipStream_t s, const T* qk, const T* vt, T* y, int F, int S, int S_pad, int H);
 // temporal causal attention over T frames per spatial position: qkv [B*T*S][3E] row-major, y [B*T*S][E]
 // Temporal attention over history slots [t0, t0 + Tn) held in the qkv rows; k | v of slots [0, t0) are read from `cache`
 // ([B][Tcap][S][2E], dtype T) and, when write != 0, the k | v rows of the new slots are appended to it (attn.hip).
-struct TemporalRange { int t0; void* cache; int Tcap; int write; };
+struct TemporalRange { int t0; void* cache; int Tcap; int write; int q0 = 0; };   // q0: only query slots >= q0 are evaluated / written
 template <typename T> void launch_attn_temporal(hipStream_t s, const T* qkv, T* y, int B, int Tn, int S, int H,
                                                 TemporalRange tr = TemporalRange{0, nullptr, 0, 0});
 
@@ -85,7 +89,6 @@ struct GemvArgs {
     float* out; long ldo;
     void* cache; long scene_stride; const int* d_len; int Lmax;   // GEMV_OUT_QKV
     int rows_per_block;            // 0: a workgroup loops over all M rows; 1: one (feature tile, row) per workgroup (set by the launcher)
-    float* kv_f32;                 // GEMV_OUT_QKV, optional: fp32 copy [M][2E] of the new k | v rows (self term of the fused decode attention)
     int E;
 };
 template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
@@ -95,25 +98,11 @@ template <typename T> void launch_gemv(hipStream_t s, const GemvArgs& a);
 struct GemvResidArgs {
     const float* a; long lda; const float* part; int H;
     int ns;                          // number of attention splits to merge (attn_nsplit of the key count)
-    const float* self_q;             // optional [M][E]: the current token attends to itself with these q / k|v rows (fp32), merged as one
-    const float* self_kv;            // more softmax term (the fused decode attention only covers the cached keys)  [M][2E]
     const void* W; const float* bias; int N, K, M;
     float* x; long ldx;
     int rows_per_block;              // as in GemvArgs
 };
 template <typename T> void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a);
-
-// Fused decode kernel: ONE launch computes q | k | v of the new token (role A: the LN + c_attn GEMV, K/V appended to the cache)
-// and, concurrently, the attention partials of every (scene, head, key split) over the cached keys < *d_len (role B: those
-// blocks recompute their own 48 rows of q from x -- 74 KB of weights -- instead of waiting for role A).  The new token's
-// self-attention term is merged by launch_gemv_resid (self_q / self_kv).
-struct QkvAttnArgs {
-    GemvArgs g;            // role A: out_mode GEMV_OUT_QKV, M scenes
-    long head_stride, key_stride, v_off;   // cache geometry (see launch_attn_partial)
-    int H, ns;             // heads, key splits to launch (attn_nsplit of the cached length)
-    float* part;
-};
-template <typename T> void launch_qkv_attn(hipStream_t s, const QkvAttnArgs& a);
 
 // ------------------------------------------------------------------------------------------------
 // XCD-resident decode engine (oar_engine.hip): all BlockOAR layers of one decode step in one launch, bf16 weights, n_embd 768
@@ -141,8 +130,11 @@ struct OarEngineArgs {
     int B, NG, R, D;                           // scenes; groups; scenes per round; groups per scene (NG == R * D)
     unsigned char xcc_group[16];               // physical XCC id -> group index (0xff: not taking part)
     unsigned long long* stamps;                // optional [8]: 100 MHz ticks per phase + item count, accumulated by rank 0 of group 0
+    int fp16;                                  // 0: weights and K/V cache hold bfloat16 bits, 1: IEEE half (UMGEN_PREC_FP16)
+    int systolic;                              // 1: layer-resident groups, the scenes flow through all NG groups (R, D unused); B * 64 * 8 tags
 };
 size_t oar_engine_lds_bytes();
+hipError_t oar_engine_prepare();                // per device, before the first launch / census (dynamic-LDS attribute)
 hipError_t launch_oar_engine(hipStream_t s, const OarEngineArgs& a);
 hipError_t launch_oar_engine_census(hipStream_t s, int n_groups, unsigned int* d_counts16);
 

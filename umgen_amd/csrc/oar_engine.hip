@@ -123,6 +123,8 @@ __device__ inline void gather(Ctx& c, int tid, const u64* g, int n, u32 tag, flo
 __device__ inline u32x4_t ldwu(const bf16_t* ubase, u32 off) {
     return __builtin_nontemporal_load((const UMGEN_GLOBAL u32x4_t*)(ubase + off));
 }
+// the same with the default cache policy: rows that are read again from this XCD's L2 (the systolic schedule's q|k|v rows)
+__device__ inline u32x4_t ldwk(const bf16_t* ubase, u32 off) { return *(const UMGEN_GLOBAL u32x4_t*)(ubase + off); }
 __device__ inline float ldg(const float* p) { return *(const UMGEN_GLOBAL float*)p; }
 __device__ inline void ldg8(const float* p, float (&o)[8]) {
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -130,23 +132,33 @@ __device__ inline void ldg8(const float* p, float (&o)[8]) {
     const f4v y = *(const UMGEN_GLOBAL f4v*)(p + 4);
     o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w; o[4] = y.x; o[5] = y.y; o[6] = y.z; o[7] = y.w;
 }
-__device__ inline void unpack8(const u32x4_t& w, float (&o)[8]) {
-    o[0] = __uint_as_float(w.x << 16); o[1] = __uint_as_float(w.x & 0xffff0000u);
-    o[2] = __uint_as_float(w.y << 16); o[3] = __uint_as_float(w.y & 0xffff0000u);
-    o[4] = __uint_as_float(w.z << 16); o[5] = __uint_as_float(w.z & 0xffff0000u);
-    o[6] = __uint_as_float(w.w << 16); o[7] = __uint_as_float(w.w & 0xffff0000u);
-}
-// 8 bf16 weights x 8 fp32 activations on the packed fp32 FMA (v_pk_fma_f32: two MACs per instruction): the even / odd elements
-// accumulate in the two halves of acc
+// 8 16-bit weights (TT = bf16_t: raw bfloat16 bits widened by a shift / mask; TT = f16_t: IEEE half through v_cvt_f32_f16) x 8 fp32
+// activations on the packed fp32 FMA (v_pk_fma_f32: two MACs per instruction): the even / odd elements accumulate in the two
+// halves of acc
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ inline f32x2_t up2(u32 w) { return f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+template <typename TT> __device__ inline f32x2_t up2(u32 w);
+template <> __device__ inline f32x2_t up2<bf16_t>(u32 w) { return f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+template <> __device__ inline f32x2_t up2<f16_t>(u32 w) {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, w);
+    return f32x2_t{(float)h.x, (float)h.y};
+}
+template <typename TT>
+__device__ inline void unpack8(const u32x4_t& w, float (&o)[8]) {
+    const f32x2_t a = up2<TT>(w.x), b = up2<TT>(w.y), c = up2<TT>(w.z), d = up2<TT>(w.w);
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y; o[6] = d.x; o[7] = d.y;
+}
+template <typename TT>
 __device__ inline f32x2_t dot8(const u32x4_t& w, const f32x2_t (&x)[4], f32x2_t acc) {
-    acc = __builtin_elementwise_fma(up2(w.x), x[0], acc);
-    acc = __builtin_elementwise_fma(up2(w.y), x[1], acc);
-    acc = __builtin_elementwise_fma(up2(w.z), x[2], acc);
-    acc = __builtin_elementwise_fma(up2(w.w), x[3], acc);
+    acc = __builtin_elementwise_fma(up2<TT>(w.x), x[0], acc);
+    acc = __builtin_elementwise_fma(up2<TT>(w.y), x[1], acc);
+    acc = __builtin_elementwise_fma(up2<TT>(w.z), x[2], acc);
+    acc = __builtin_elementwise_fma(up2<TT>(w.w), x[3], acc);
     return acc;
 }
+// value as the 16-bit K/V cache will hold it, and its raw bits
+template <typename TT> __device__ inline float round16(float v) { return Cvt<TT>::to_f(Cvt<TT>::from_f(v)); }
+template <typename TT> __device__ inline bf16_t bits16(float v) { return __builtin_bit_cast(bf16_t, Cvt<TT>::from_f(v)); }
 __device__ inline void load8p(const float* p, f32x2_t (&o)[4]) {
     const float4 a = *reinterpret_cast<const float4*>(p);
     const float4 b = *reinterpret_cast<const float4*>(p + 4);
@@ -160,25 +172,27 @@ struct Rows768 {
     u32x4_t a[R];
     u32x4_t b[(R + 1) / 2];
 };
-template <int R>
+template <int R, bool KEEP = false>
 __device__ inline void req768(Rows768<R>& w, const bf16_t* W, int row0, int lane) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) w.a[r] = ldwu(W + (long)(row0 + r) * E, (u32)lane * 8u);
+    for (int r = 0; r < R; ++r) w.a[r] = KEEP ? ldwk(W + (long)(row0 + r) * E, (u32)lane * 8u) : ldwu(W + (long)(row0 + r) * E, (u32)lane * 8u);
 #pragma unroll
     for (int j = 0; j < (R + 1) / 2; ++j) {
         const bool both = 2 * j + 1 < R;   // odd R: the upper half-wave re-reads the last row's tail, its copy is ignored
-        w.b[j] = ldwu(W + (long)(row0 + 2 * j) * E + 512, (u32)(lane & 31) * 8u + (both ? (u32)(lane >> 5) * (u32)E : 0u));
+        const bf16_t* base = W + (long)(row0 + 2 * j) * E + 512;
+        const u32 off = (u32)(lane & 31) * 8u + (both ? (u32)(lane >> 5) * (u32)E : 0u);
+        w.b[j] = KEEP ? ldwk(base, off) : ldwu(base, off);
     }
 }
-template <int R>
+template <typename TT, int R>
 __device__ inline void dot768(const Rows768<R>& w, const f32x2_t (&x1)[4], const f32x2_t (&x2)[4], int lane, float (&out)[R]) {
     const f32x2_t zero = {0.f, 0.f};
     f32x2_t acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = dot8(w.a[r], x1, zero);
+    for (int r = 0; r < R; ++r) acc[r] = dot8<TT>(w.a[r], x1, zero);
 #pragma unroll
     for (int j = 0; j < (R + 1) / 2; ++j) {
-        const f32x2_t p = dot8(w.b[j], x2, zero);
+        const f32x2_t p = dot8<TT>(w.b[j], x2, zero);
         acc[2 * j] += (lane < 32) ? p : zero;
         if (2 * j + 1 < R) acc[2 * j + 1] += (lane >= 32) ? p : zero;
     }
@@ -212,17 +226,31 @@ __device__ inline void ln768(const float* xs, const float* lnw, int lane, f32x2_
     for (int e = 0; e < 4; ++e) { x1[e] = (x1[e] - mean2) * rstd2 * l1[e]; x2[e] = (x2[e] - mean2) * rstd2 * l2[e]; }
 }
 
-__device__ inline float bf16_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
 }  // namespace
 
+// systolic schedule: which matrices stay in registers over the scenes of a layer (the others are requested again by every item)
+// (measured with -Rpass-analysis=kernel-resource-usage: the 512-thread kernel sits at 254 of 256 VGPRs; keeping the c_proj rows costs 8
+//  spilled VGPRs, the c_fc rows 58, both 77 -- the rows the compiler cannot hold are then reloaded from scratch memory every item)
+#ifndef UMGEN_SYS_KEEP_WO
+#define UMGEN_SYS_KEEP_WO 0
+#endif
+#ifndef UMGEN_SYS_KEEP_WF
+#define UMGEN_SYS_KEEP_WF 0
+#endif
+constexpr bool kSysKeepWo = UMGEN_SYS_KEEP_WO, kSysKeepWf = UMGEN_SYS_KEEP_WF;
 #ifndef UMGEN_ENG_STAGGER_US
 #define UMGEN_ENG_STAGGER_US 10
 #endif
 constexpr int kStaggerTicks = UMGEN_ENG_STAGGER_US * 100;   // wall_clock64 ticks (100 MHz)
 
 // STAMPS: per-phase 100 MHz time stamps of (group 0, rank 0) into OarEngineArgs::stamps (UMGEN_DEBUG_TIMING); compiled out otherwise
-template <bool STAMPS>
+// SYS (systolic schedule, several scenes): group g keeps layers g, g + 8, ... RESIDENT -- their weights are requested once per step
+// and layer, into the same registers / parked LDS rows -- and the B scenes of the batch flow through the eight groups one behind
+// the other (item (layer l, scene s) on group l % 8 needs x of (l - 1, s) from group (l - 1) % 8).  A step costs
+// (n_layers + B - 1) item times instead of B x n_layers / 8 x (item + weight stream): with one scene per XCD (round 2) every
+// group streamed all 36 layers, 8x the algorithmic weight traffic through the fabric, and waited 11 of 29 us per item for it.
+template <bool STAMPS, typename TT, bool SYS>
 __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid0 = threadIdx.x;
@@ -258,21 +286,34 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
         a.stamps[12] += t - t_entry;
         t_entry = t;
     }
-    const int R = a.R, D = a.D;
+    const int R = SYS ? 1 : a.R, D = SYS ? a.NG : a.D;
     const int rounds = (a.B + R - 1) / R;
     const int pipe = g / D, q = g % D;      // pipeline (scene slot of the round) and position in it
     float* xs = lds + L_XS;
     float* xb = lds + L_XB;
     float* as = lds + L_AS;
+    // the weight rows of a wave (requested at the start of an item).  SYS: c_proj / c_fc rows and the parked mlp rows at the first
+    // scene of a layer only -- they stay in their registers / LDS rows for the other scenes; the q|k|v rows (56 VGPRs, dead after P1)
+    // do not fit beside them through the attention (142 spilled VGPRs when kept), so every item requests them again, with the
+    // default cache policy: after the layer's first scene they come out of this XCD's L2
+    Rows768<RO> wo;
+    Rows768<RF> wf;
 
-    for (int rd = 0; rd < rounds; ++rd) {
+    // items of this group in the order it works through them: (round rd, layer l) -- scene rd * R + pipe.
+    //   !SYS: rounds outside, this pipeline's layers (q, q + D, ...) inside;  SYS: layers outside, every scene of the batch inside
+    const int n_lay = (a.n_layers - q + D - 1) / D;
+    const int n_items = n_lay > 0 ? n_lay * rounds : 0;
+    for (int item = 0; item < n_items; ++item) {
+        const int rd = SYS ? item % rounds : item / n_lay;
+        const int l = q + D * (SYS ? item / rounds : item % n_lay);
         const int s = rd * R + pipe;
+        const bool load_w = !SYS || rd == 0;          // this item requests the layer's weights
         if (s >= a.B) continue;
-        for (int l = q; l < a.n_layers; l += D) {
+        {
             // Launch-time stagger: every group would request its first layer's 14 MB at kernel entry -- 114 MB at once, HBM-bound, and
             // the one stream that is on the critical path (group 0, layer 0: nothing to hide it behind) took 19 us instead of the
             // 11 us of its XCD port.  Group q's first request waits q x UMGEN_ENG_STAGGER_US: its x is q layers away anyway.
-            if (rd == 0 && l == q && q > 0 && D > 1) {
+            if (item == 0 && q > 0 && D > 1) {
                 const unsigned long long until = t_k0 + (unsigned long long)(q * kStaggerTicks);
                 while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
             }
@@ -288,8 +329,6 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             u64* gpy = gxb + E;                      // mlp partial sums [32 producers][768 rows]
             u64* gxl = gpy + CU * E;                 // in-group x edge (D == 1)
             Rows768<RQ> wq;
-            Rows768<RO> wo;
-            Rows768<RF> wf;
             u32x4_t wpl[6];                          // units 12..17 of the mlp c_proj slice (requested after the attention)
             const int rowq = (w * NW + wave) * RQ, rowo = (w * NW + wave) * RO, rowf = (w * NW + wave) * RF;
             const OarLayerDev lw = a.layers[l];
@@ -302,8 +341,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // first is requested first -- x, the LN weights and biases, then the q|k|v rows -- so that P1 starts after ~6 MB of the
             // stream instead of behind all of it (measured: 18 us from kernel entry to the start of P1 with the weights requested first).
             float lnr[3];   // ln_1 | ln_2 weights (1536 floats over 512 threads), staged through LDS once x is here
+            if (load_w) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) lnr[k] = ldg((tid + k * NT < E ? lw.ln_a : lw.ln_b - E) + tid + k * NT);
+                for (int k = 0; k < 3; ++k) lnr[k] = ldg((tid + k * NT < E ? lw.ln_a : lw.ln_b - E) + tid + k * NT);
+            }
             float bq = 0.f, bo = 0.f;
             if (lane < RQ) bq = ldg(lw.bqkv + rowq + lane);
             if (lane < RO) bo = ldg(lw.bo + rowo + lane);
@@ -312,7 +353,23 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 x_first[0] = ldg(a.xdec + (long)s * E + tid);
                 if (tid + NT < E) x_first[1] = ldg(a.xdec + (long)s * E + tid + NT);
             }
-            {
+            if (SYS) {
+                // layer switch of a resident group (once per layer and step): the parked mlp rows go through 6 staging registers at a
+                // time BEFORE anything else is requested (the q|k|v rows, c_proj / c_fc rows and K/V buffers then fill the registers)
+                if (load_w) {
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        u32x4_t wp[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) wp[j] = ldwu(wp2 + (long)(6 * hb + j) * NT * 8, (u32)tid * 8u);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) w2p[(6 * hb + j) * NT] = wp[j];
+                    }
+                }
+                req768<RQ, true>(wq, lw.Wqkv, rowq, lane);
+                if (load_w || !kSysKeepWo) req768<RO, !kSysKeepWo>(wo, lw.Wo, rowo, lane);
+                if (load_w || !kSysKeepWf) req768<RF, !kSysKeepWf>(wf, lw.Wfc, rowf, lane);
+            } else {
                 u32x4_t wp[12];
                 req768(wq, lw.Wqkv, rowq, lane);
 #pragma unroll
@@ -346,7 +403,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // (Not on layer 0: a launch's first item has no idle wait, and the touch loop consumes its loads -- which return behind the whole
             //  weight stream, a wave's loads being in order: P1 started 6.6 us late.)
             u32 touched = 0;
-            if (D > 1 && l != 0) {
+            if (!SYS && D > 1 && l != 0) {
                 const int n_lines = ((kb - ka) * kHeadDim * 2 + 127) >> 7;
                 const char* k0p = reinterpret_cast<const char*>(kbase + (long)ka * kHeadDim);
                 const char* v0p = reinterpret_cast<const char*>(vbase + (long)ka * kHeadDim);
@@ -364,8 +421,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             } else {
                 gather<2>(c, tid, D == 1 ? gxl : a.gx + (long)s * E, E, tg + 0, xs);
             }
+            if (load_w) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) lnw[tid + k * NT] = lnr[k];
+                for (int k = 0; k < 3; ++k) lnw[tid + k * NT] = lnr[k];
+            }
             wg_barrier();
             stamp(0);   // waited for x
 #ifndef UMGEN_ENG_NB
@@ -389,7 +448,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 f32x2_t x1[4], x2[4];
                 float out[RQ];
                 ln768(xs, lnw, lane, x1, x2);
-                dot768<RQ>(wq, x1, x2, lane, out);
+                dot768<TT, RQ>(wq, x1, x2, lane, out);
                 float v = 0.f;
 #pragma unroll
                 for (int r = 0; r < RQ; ++r) v = (lane == r) ? out[r] : v;
@@ -400,7 +459,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     if (n >= E) {   // K / V rows of the new token: bf16 into the cache (head-major [2][H][Lmax][48])
                         const int cc = n - E, kvsel = cc / E, hc = cc % E;
                         (a.kvcache + (long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride)[
-                            (u32)(((kvsel * H + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim)] = f32_to_bf16(v);
+                            (u32)(((kvsel * H + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim)] = bits16<TT>(v);
                     }
                 }
             }
@@ -440,10 +499,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     for (int i = 0; i < KP; ++i) {
                         const int k = k0 + 8 * i + kg;
                         float kf[8];
-                        unpack8(kcb[i], kf);
+                        unpack8<TT>(kcb[i], kf);
                         if (k == Lk) {   // the new token's own k, as the cache will hold it (bf16)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) kf[e] = pact ? bf16_round(qs[kHeadDim + piece * 8 + e]) : 0.f;
+                            for (int e = 0; e < 8; ++e) kf[e] = pact ? round16<TT>(qs[kHeadDim + piece * 8 + e]) : 0.f;
                         }
                         float d = 0.f;
 #pragma unroll
@@ -465,10 +524,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         for (int i = 0; i < KP; ++i) {
                             const int k = k0 + 8 * i + kg;
                             float vf[8];
-                            unpack8(vcb[i], vf);
+                            unpack8<TT>(vcb[i], vf);
                             if (k == Lk) {
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) vf[e] = pact ? bf16_round(qs[2 * kHeadDim + piece * 8 + e]) : 0.f;
+                                for (int e = 0; e < 8; ++e) vf[e] = pact ? round16<TT>(qs[2 * kHeadDim + piece * 8 + e]) : 0.f;
                             }
                             const float p = __expf(sc[i] - m_new);
                             l_run += p;
@@ -555,7 +614,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 float out[RO];
                 load8p(as + lane * 8, x1);
                 load8p(as + 512 + (lane & 31) * 8, x2);
-                dot768<RO>(wo, x1, x2, lane, out);
+                dot768<TT, RO>(wo, x1, x2, lane, out);
                 float v = 0.f;
 #pragma unroll
                 for (int r = 0; r < RO; ++r) v = (lane == r) ? out[r] : v;
@@ -575,7 +634,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 f32x2_t x1[4], x2[4];
                 float out[RF];
                 ln768(xb, lnw + E, lane, x1, x2);
-                dot768<RF>(wf, x1, x2, lane, out);
+                dot768<TT, RF>(wf, x1, x2, lane, out);
                 float v = 0.f;
 #pragma unroll
                 for (int r = 0; r < RF; ++r) v = (lane == r) ? out[r] : v;
@@ -592,14 +651,17 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 for (int j = 0; j < 12; ++j) {
                     f32x2_t xv[4];
                     load8p(hsl + 8 * j, xv);
-                    accA = dot8(w2p[j * NT], xv, accA);
+                    accA = dot8<TT>(w2p[j * NT], xv, accA);
+                    // SYS keeps the c_proj / c_fc rows (92 VGPRs) live through this phase: stop the scheduler from hoisting all 36 LDS
+                    // reads (144 VGPRs) to the front, which pushed those rows out to scratch memory
+                    if (SYS && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
                 const int cb = 6 * (tid >> 8);
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     f32x2_t xv[4];
                     load8p(hsl + 8 * (cb + j), xv);
-                    accB = dot8(wpl[j], xv, accB);
+                    accB = dot8<TT>(wpl[j], xv, accB);
                 }
                 const float yA = accA.x + accA.y;
                 float yB = accB.x + accB.y;
@@ -663,24 +725,34 @@ size_t oar_engine_lds_bytes() {
 }
 
 hipError_t launch_oar_engine_census(hipStream_t s, int n_groups, unsigned int* d_counts16) {
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(oar_engine_census_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)oar_engine_lds_bytes());
-    if (rc != hipSuccess) return rc;
     hipLaunchKernelGGL(oar_engine_census_kernel, dim3(n_groups * kEngGroup), dim3(kEngThreads), oar_engine_lds_bytes(), s, d_counts16);
     return hipGetLastError();
 }
 
-hipError_t launch_oar_engine(hipStream_t s, const OarEngineArgs& a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(oar_engine_kernel<false>), reinterpret_cast<const void*>(oar_engine_kernel<true>)}) {
-            hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oar_engine_lds_bytes());
-            if (rc != hipSuccess) return rc;
-        }
-        attr_set = true;
+// once per device (umgen_create): the engine's dynamic LDS exceeds the default limit
+hipError_t oar_engine_prepare() {
+    for (const void* f : {reinterpret_cast<const void*>(oar_engine_kernel<false, bf16_t, false>), reinterpret_cast<const void*>(oar_engine_kernel<true, bf16_t, false>),
+                          reinterpret_cast<const void*>(oar_engine_kernel<false, f16_t, false>), reinterpret_cast<const void*>(oar_engine_kernel<true, f16_t, false>),
+                          reinterpret_cast<const void*>(oar_engine_kernel<false, bf16_t, true>), reinterpret_cast<const void*>(oar_engine_kernel<true, bf16_t, true>),
+                          reinterpret_cast<const void*>(oar_engine_kernel<false, f16_t, true>), reinterpret_cast<const void*>(oar_engine_kernel<true, f16_t, true>),
+                          reinterpret_cast<const void*>(oar_engine_census_kernel)}) {
+        hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oar_engine_lds_bytes());
+        if (rc != hipSuccess) return rc;
     }
-    if (a.stamps) hipLaunchKernelGGL(oar_engine_kernel<true>, dim3(a.NG * kEngGroup), dim3(kEngThreads), oar_engine_lds_bytes(), s, a);
-    else hipLaunchKernelGGL(oar_engine_kernel<false>, dim3(a.NG * kEngGroup), dim3(kEngThreads), oar_engine_lds_bytes(), s, a);
+    return hipSuccess;
+}
+
+template <typename TT, bool SYS>
+static void launch_engine_t(hipStream_t s, const OarEngineArgs& a) {
+    const dim3 grid(a.NG * kEngGroup), block(kEngThreads);
+    const size_t shm = oar_engine_lds_bytes();
+    if (a.stamps) hipLaunchKernelGGL((oar_engine_kernel<true, TT, SYS>), grid, block, shm, s, a);
+    else hipLaunchKernelGGL((oar_engine_kernel<false, TT, SYS>), grid, block, shm, s, a);
+}
+
+hipError_t launch_oar_engine(hipStream_t s, const OarEngineArgs& a) {
+    if (a.fp16) { if (a.systolic) launch_engine_t<f16_t, true>(s, a); else launch_engine_t<f16_t, false>(s, a); }
+    else { if (a.systolic) launch_engine_t<bf16_t, true>(s, a); else launch_engine_t<bf16_t, false>(s, a); }
     return hipGetLastError();
 }
 

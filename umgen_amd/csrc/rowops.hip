@@ -44,5 +44,6 @@ void launch_layernorm(hipStream_t s, const float* x, long row_stride, long n_row
 }
 template void launch_layernorm<float>(hipStream_t, const float*, long, long, int, const float*, float*);
 template void launch_layernorm<bf16_t>(hipStream_t, const float*, long, long, int, const float*, bf16_t*);
+template void launch_layernorm<f16_t>(hipStream_t, const float*, long, long, int, const float*, f16_t*);
 
 }  // namespace umgen

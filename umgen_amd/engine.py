@@ -23,7 +23,8 @@ def _p64(a: Optional[np.ndarray]):
 
 
 class Engine:
-    """One engine = one GPU, one HIP stream.  ``precision``: "bf16" (production) or "fp32" (parity mode)."""
+    """One engine = one GPU, one HIP stream.  ``precision``: "bf16" (production), "fp16" (the same kernels with IEEE-half operands:
+    the reference's own autocast arithmetic) or "fp32" (exact parity mode)."""
 
     def __init__(self, cfg: RolloutConfig, precision: str = "bf16", max_batch: int = 1, max_cond_frames: int = 20,
                  device: int = 0, use_graphs: bool = True):
@@ -39,7 +40,7 @@ class Engine:
             map_vocab=cfg.map_vocab_size, bbox3d_vocab=cfg.bbox3d_vocab_size, img_vocab=cfg.img_vocab_size,
             aux_vocab=cfg.aux_vocab_size, n_map_embd=cfg.n_map_embd, n_img_embd=cfg.n_img_embd,
             max_frame_len=cfg.max_frame_len, task_num=cfg.task_num, task_id=cfg.task_id,
-            precision={"fp32": _lib.PREC_FP32, "bf16": _lib.PREC_BF16}[precision], max_batch=max_batch,
+            precision={"fp32": _lib.PREC_FP32, "bf16": _lib.PREC_BF16, "fp16": _lib.PREC_FP16}[precision], max_batch=max_batch,
             max_cond_frames=max_cond_frames, device=device, use_graphs=int(use_graphs))
         self._h = C.c_void_p()
         rc = self.lib.umgen_create(C.byref(c), C.byref(self._h))

@@ -53,7 +53,8 @@ def build_parser():
     # build-side additions
     p.add_argument("--data_test_root", type=str, default=None, help="directory of token-dict scenes (*.npz / *.pkl)")
     p.add_argument("--synthetic", type=int, default=0, help="generate N synthetic scenes instead of reading files")
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+                   help="bf16: production; fp16: the reference's own autocast arithmetic; fp32: exact parity mode")
     p.add_argument("--batch", type=int, default=1, help="scenes rolled out together per GPU")
     p.add_argument("--seed", type=int, default=0)
     return p
@@ -89,15 +90,17 @@ def load_scene(path, block_size=42, sampling_gap=4, start_index=10):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    import torch
     import torch.distributed as dist
 
     from .engine import Engine
-    from .shard import scene_partition, scene_seed
+    from .shard import scene_partition, sharded_rollout
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1:
-        dist.init_process_group("nccl")
+    if world > 1:   # one process per GPU: bind the device BEFORE the RCCL communicator exists
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     cfg, new_frames, input_cond = resolve(args)
     control = "control" in args.infer_task
     T_hist = min(20, cfg.max_frame_len - 1)
@@ -111,30 +114,54 @@ def main(argv=None):
         # dataset_block_size = set_num_new_frames + cond_frames (infer_fun.py:176-186), sampling_gap 4, start_index 10 (evaluate.py:157)
         block = (args.set_num_new_frames if args.infer_task == "video" else max(new_frames, 0)) + 20
         scenes = [(os.path.basename(f)[:-4],) + load_scene(f, block_size=block) for f in files]
+    save_dir = os.path.join(args.output_path, "saved_token")
+    os.makedirs(save_dir, exist_ok=True)
+    # skip-if-exists stays per scene (model_pl.py:215-216); every rank takes the same decision before anybody writes
+    todo = []
+    for sid, (name, _, _) in enumerate(scenes):
+        if os.path.exists(os.path.join(save_dir, name + "_tokens.pkl")):
+            if rank == 0:
+                print(name, " has been processed")
+        else:
+            todo.append(sid)
+    if world > 1:
+        dist.barrier()
+    if not todo:
+        if world > 1:
+            dist.destroy_process_group()
+        return
     eng = Engine(cfg, precision=args.precision, max_batch=args.batch, max_cond_frames=T_hist, device=local_rank)
     if args.debug:
         for key, shape in expected_keys(cfg).items():
             eng.load_tensor(key, synth_tensor(key, shape, seed=0))
     else:
-        import torch
         ckpt = torch.load(args.ckpt_dir, map_location="cpu")
         sd = ckpt["model_state"] if "model_state" in ckpt else ckpt          # infer_fun.py:43-50
         for k, v in sd["module"].items():
             eng.load_tensor(k, v.float().numpy() if v.dtype != torch.bfloat16 else v.view(torch.int16).numpy().view(np.uint16))
     eng.finalize()
-    save_dir = os.path.join(args.output_path, "saved_token")
-    os.makedirs(save_dir, exist_ok=True)
-    for sid in scene_partition(len(scenes), world, rank):
-        name, toks, ctl = scenes[sid]
-        path = os.path.join(save_dir, name + "_tokens.pkl")
-        if os.path.exists(path):                                              # model_pl.py:215-216
-            print(name, " has been processed")
-            continue
+    # Scenes that can share a batch: same history length, same number of new frames, same kind of control tokens.  Each group goes
+    # through umgen_amd.shard.sharded_rollout -- THE multi-scene / multi-GPU implementation (scene i -> rank i mod P, `--batch`
+    # scenes per engine call, one all-gather of the sampled tokens at the end) that bench.py and the tests use too.
+    groups = {}
+    for sid in todo:
+        _, toks, ctl = scenes[sid]
         icf = min(input_cond, toks["pose"].shape[1])
-        out = eng.rollout(toks, new_frames if new_frames >= 0 else toks["pose"].shape[1] - icf, cond_frames=T_hist,
-                          input_cond_frames=icf, init_tokens=ctl, control_test=control and ctl is not None and "bbox3d" in ctl,
-                          seeds=[scene_seed(args.seed, sid)])
-        print("saved", save_tokens(out, args.output_path, name))
+        nf = new_frames if new_frames >= 0 else toks["pose"].shape[1] - icf
+        key = (icf, nf, tuple(sorted((k, v.shape[1:]) for k, v in ctl.items())) if ctl else None)
+        groups.setdefault(key, []).append(sid)
+    for (icf, nf, _), sids in groups.items():
+        def rollout_fn(toks, seeds, scene_ids):
+            ctls = [scenes[s][2] for s in scene_ids]
+            init = {k: np.concatenate([c[k] for c in ctls]) for k in ctls[0]} if ctls[0] else None
+            return eng.rollout(toks, nf, cond_frames=T_hist, input_cond_frames=icf, init_tokens=init,
+                               control_test=control and init is not None and "bbox3d" in init, seeds=seeds)
+        out = sharded_rollout(rollout_fn, [scenes[s][1] for s in sids], base_seed=args.seed, batch=args.batch,
+                              device="cuda" if world > 1 else "cpu", scene_ids=sids, pass_ids=True)
+        for pos in scene_partition(len(sids), world, rank):                   # every rank writes the scenes it rolled out
+            name = scenes[sids[pos]][0]
+            print("saved", save_tokens({m: out[m][pos:pos + 1] for m in MOD_ORDER}, args.output_path, name))
+    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

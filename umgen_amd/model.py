@@ -9,6 +9,7 @@ fallback -- constructing the engine without a GPU / without libumgen_hip.so rais
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Dict, Optional
 
 import numpy as np
@@ -18,7 +19,7 @@ from torch import nn
 from .config import MOD_ORDER, RolloutConfig
 from .engine import Engine, UMGenError
 from .registry import MODELS
-from .weights import OPTIONAL_KEYS, expected_keys
+from .weights import OPTIONAL_KEYS, expected_keys, is_matrix_weight
 
 
 @MODELS.register_module()
@@ -45,19 +46,32 @@ class UMGen(nn.Module):
             self._engine = Engine(self.rcfg, max_cond_frames=min(20, self.rcfg.max_frame_len), **self._engine_args)
             if self._state is not None:      # re-created on another device / with a larger batch: reload the weights
                 for k, arr in self._state.items():
-                    self._engine.load_tensor(k, arr)
-                self._engine.finalize()
+                    if not self._engine.load_tensor(k, arr) and k not in OPTIONAL_KEYS:
+                        raise UMGenError(f"re-created engine refused state-dict entry {k!r}")
+                if self._loaded:             # (a partial load_state_dict was never finalized: nothing to finalize now either)
+                    self._engine.finalize()
         return self._engine
+
+    def _host_copy(self, key: str, arr: np.ndarray) -> np.ndarray:
+        """Host copy kept so that the engine can move to another GPU / grow its scene batch: nn.Linear weights in the engine's own
+        16-bit storage type (what umgen_load_tensor rounds them to anyway: half the host memory), everything else as given."""
+        if arr.dtype == np.float32 and is_matrix_weight(key):
+            if self.precision == "bf16":
+                return torch.from_numpy(arr).bfloat16().view(torch.int16).numpy().view(np.uint16)
+            if self.precision == "fp16":
+                return arr.astype(np.float16)
+        return arr
 
     def _recreate(self, **changes):
         """The weights live in the engine's HBM: a new device or a larger scene batch means a new engine."""
         new = dict(self._engine_args, **changes)
         if new == self._engine_args:
             return
-        self._engine_args = new
         if self._engine is not None:
+            warnings.warn(f"umgen_amd.UMGen: engine re-created ({self._engine_args} -> {new}); the weights are uploaded again", stacklevel=3)
             self._engine.close()
             self._engine = None
+        self._engine_args = new
 
     def load_state_dict(self, state_dict, strict: bool = False):
         """infer_fun.load_model_paramter (infer_fun.py:43-50) calls this with ckpt["module"], strict=False."""
@@ -77,7 +91,7 @@ class UMGen(nn.Module):
             if not eng.load_tensor(k, arr) and k not in OPTIONAL_KEYS:
                 unexpected.append(k)
             elif k in want or k in OPTIONAL_KEYS:
-                kept[k] = arr
+                kept[k] = self._host_copy(k, arr)
         self._state = kept
         if strict and (missing or unexpected):
             raise RuntimeError(f"missing keys {missing[:5]}..., unexpected keys {unexpected[:5]}...")

@@ -7,7 +7,7 @@ Per-scene RNG seeds are keyed by scene id, so results are invariant to P and to 
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -64,15 +64,22 @@ def gather_scene_tokens(local_out: Dict[str, np.ndarray], local_ids: Sequence[in
 
 
 def sharded_rollout(rollout_fn, scenes: Sequence[Dict[str, np.ndarray]], base_seed: int, batch: int = 1,
-                    device: str = "cpu", **kw) -> Dict[str, np.ndarray]:
-    """Runs ``rollout_fn(tokens[B,...], seeds=[...], **kw)`` on this rank's scenes in batches and gathers all scenes."""
+                    device: str = "cpu", scene_ids: Optional[Sequence[int]] = None, pass_ids: bool = False, **kw) -> Dict[str, np.ndarray]:
+    """Runs ``rollout_fn(tokens[B,...], seeds=[...], **kw)`` on this rank's scenes in batches of ``batch`` and gathers all scenes.
+
+    ``scene_ids``: global ids of the entries of ``scenes`` (default 0..n-1) -- the RNG seeds are keyed by them, so a filtered
+    scene list (the CLI's skip-if-exists rule) draws the same tokens as the full one.  ``pass_ids``: also hand the chunk's
+    global ids to ``rollout_fn`` (per-scene control tokens)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    gids = list(scene_ids) if scene_ids is not None else list(range(len(scenes)))
+    assert len(gids) == len(scenes)
     ids = scene_partition(len(scenes), world, rank)
     outs = []
     for i in range(0, len(ids), batch):
         chunk = ids[i:i + batch]
         toks = {m: np.concatenate([scenes[s][m] for s in chunk]) for m in MOD_ORDER}
-        outs.append(rollout_fn(toks, seeds=[scene_seed(base_seed, s) for s in chunk], **kw))
+        extra = {"scene_ids": [gids[s] for s in chunk]} if pass_ids else {}
+        outs.append(rollout_fn(toks, seeds=[scene_seed(base_seed, gids[s]) for s in chunk], **extra, **kw))
     local = {m: np.concatenate([o[m] for o in outs]) for m in MOD_ORDER} if outs else {m: np.zeros((0, 0, CONTENT_LEN[m]), np.int64) for m in MOD_ORDER}
     return gather_scene_tokens(local, ids, len(scenes), device=device)

@@ -104,6 +104,15 @@ def expected_keys(cfg: RolloutConfig) -> "OrderedDict[str, Tuple[int, ...]]":
 OPTIONAL_KEYS = ("fouier_pe", "bbox3d_spatial_posi", "grid_center_posi_embedding")
 
 
+def is_matrix_weight(key: str) -> bool:
+    """True for the nn.Linear weights the engine stores in its precision dtype (bf16 / fp16 / fp32): every *.weight that is not an
+    embedding table, a LayerNorm weight or a codebook (those stay fp32 on the device in every mode)."""
+    if not key.endswith(".weight") or key.endswith("codebook.weight"):
+        return False
+    mod = key.split(".")[-2]
+    return not (mod.startswith("ln_") or mod in ("egoe", "axe", "be", "tpe", "spe", "tske"))
+
+
 def n_params(cfg: RolloutConfig) -> int:
     return sum(int(np.prod(s)) for s in expected_keys(cfg).values())
 
