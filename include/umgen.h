@@ -156,6 +156,34 @@ int umgen_tokenize_boxes(const float *boxes /*[n][stride], first 10 columns used
                          const int32_t *category_index /*[n], 0..2*/, int64_t *tokens /*[n][11]*/);
 int umgen_detokenize_boxes(const int64_t *slot_tokens /*[n][11]*/, int64_t n, double *boxes /*[n][10]*/);
 
+/* ---- VQ decoders: map / image tokens -> rasters, fp32 ---------------------------------------------
+ * NormVQModel.decode_code (projects/tokenizer/vq_model.py:88-103,126-150) = quantize.embedding lookup -> post_quant_conv ->
+ * Decoder.forward (projects/tokenizer/vq_modules.py:293-415), as called by Mapdecoder.decode_maps / Imagedecoder.decode_images
+ * (projects/tools/decode_map.py:110-183).  The config mirrors the `ddconfig` dicts of vq_model.py:153-202. */
+typedef struct umgen_vq umgen_vq; /* opaque */
+typedef struct umgen_vq_config {
+    int32_t n_embed, embed_dim;        /* codebook: 8192 x 16 */
+    int32_t z_channels, ch, out_ch;    /* ddconfig */
+    int32_t n_levels;                  /* len(ch_mult) */
+    int32_t ch_mult[8];
+    int32_t num_res_blocks;
+    int32_t n_attn_res;
+    int32_t attn_resolutions[4];
+    int32_t resolution;                /* ddconfig["resolution"] (only used to place the attention blocks, like the reference) */
+    int32_t post_quant_ks, post_quant_pad; /* NormVQModel(stride=..., padding=...): kernel size / padding of post_quant_conv */
+    int32_t token_h, token_w;          /* token grid of one frame: 32 x 32 (map), 16 x 32 (image) */
+    int32_t device;
+} umgen_vq_config;
+int umgen_vq_create(const umgen_vq_config *cfg, umgen_vq **out);
+/* one call per state-dict entry of the VQ checkpoint (fp32, reference key names: "decoder.conv_in.weight", "post_quant_conv.bias",
+ * "quantize.embedding.weight", ...); entries the decode path does not read (encoder.*, quant_conv.*, EMA buffers) return 1 */
+int umgen_vq_load_tensor(umgen_vq *d, const char *key, const float *data, const int64_t *shape, int32_t ndim);
+int umgen_vq_finalize(umgen_vq *d);
+/* codes [n][token_h][token_w] -> out [n][out_ch][token_h * 2^(n_levels-1)][token_w * 2^(n_levels-1)] */
+int umgen_vq_decode(umgen_vq *d, int32_t n, const int64_t *codes, float *out);
+const char *umgen_vq_last_error(const umgen_vq *d);
+int umgen_vq_destroy(umgen_vq *d);
+
 const char *umgen_last_error(const umgen_engine *e); /* never NULL */
 const char *umgen_version(void);
 int umgen_destroy(umgen_engine *e);

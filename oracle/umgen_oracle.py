@@ -41,6 +41,10 @@ Modes
 attention sums its keys in a seeded random order -- mathematically the same function, another order of the fp32 additions.  The
 spread of an ensemble of such runs is the noise floor any implementation with yet another summation order (the MFMA tiles, the
 engine's split softmax) sits in: tests/golden/make_ensemble.py records it and the -m gpu tests bound the engine by it.
+``mfma_noise``: the members additionally carry the fp32 accumulation noise of the matrix cores at every linear layer -- MEASURED on
+MI355X (tools/dbg/mfma_error.py, profiles/r03_mfma_error.txt): against the exact product of the same 16-bit operands the MFMA GEMM is
+unbiased with a relative rms error of 1.56e-7 at K = 768 and 3.39e-7 at K = 3072 (PyTorch's CPU sgemm: 1.0e-7 / 1.2e-7), i.e.
+1.56e-7 * sqrt(K / 768).  Reordering a CPU sum alone under-states what the 16-bit rounding points downstream get to amplify.
 """
 from __future__ import annotations
 
@@ -265,8 +269,10 @@ def _attention(q, k, v, n_head: int, causal: bool, round_p=None, perm: Optional[
 
 
 class OracleUMGen:
-    def __init__(self, cfg: RolloutConfig, state_dict: Dict[str, np.ndarray], weight_dtype: str = "fp32", perm_seed: Optional[int] = None):
+    def __init__(self, cfg: RolloutConfig, state_dict: Dict[str, np.ndarray], weight_dtype: str = "fp32", perm_seed: Optional[int] = None,
+                 mfma_noise: bool = False):
         self.cfg = cfg
+        self._mfma_noise = mfma_noise and perm_seed is not None
         assert weight_dtype in ("fp32", "bf16", "bf16_engine", "fp16", "fp16_engine"), weight_dtype
         self._round = _fp16 if weight_dtype.startswith("fp16") else _bf16
         self._perm_gen = torch.Generator().manual_seed(perm_seed) if perm_seed is not None else None
@@ -317,7 +323,12 @@ class OracleUMGen:
         pm = self._perm(w.shape[1])
         if pm is not None:
             x, w = x[..., pm], w[:, pm]
-        return F.linear(x, w, self.w.get(key + ".bias") if bias else None)
+        y = F.linear(x, w, None)
+        if self._mfma_noise:   # measured fp32 accumulation noise of the matrix cores (see the header), relative to the products' rms
+            eta = 1.56e-7 * math.sqrt(w.shape[1] / 768.0)
+            y = y + (eta * float(y.pow(2).mean().sqrt())) * torch.randn(y.shape, generator=self._perm_gen)
+        b = self.w.get(key + ".bias") if bias else None
+        return y if b is None else y + b
 
     def _mlp(self, x, key, tar=False):  # module.py:233-250 (exact erf GELU, no bias)
         h = F.gelu(self._lin(x, key + ".c_fc", bias=False))

@@ -18,6 +18,11 @@ PY
 run bf16_b1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline
 run bf16_b1_no256 UMGEN_GEMM256_MIN_TILES=100000000 python bench.py --steps 3 --warmup 1 --no-cpu-baseline
 run bf16_b1_notail UMGEN_NO_TAIL=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+run bf16_b1_nostage UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_nostage.so python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+run bf16_b1_stamps UMGEN_DEBUG_TIMING=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+grep "decode engine, group 0" gpurun_out/r3b_bf16_b1_stamps.err | tail -2
+run bf16_b1_stamps_nostage UMGEN_DEBUG_TIMING=1 UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_nostage.so python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+grep "decode engine, group 0" gpurun_out/r3b_bf16_b1_stamps_nostage.err | tail -2
 run bf16_b8 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 8
 run bf16_b6 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 6
 run bf16_b16 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 16

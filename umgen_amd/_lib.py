@@ -14,10 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # UMGEN_LIB_PATH selects an alternative build of the SAME library (kernel experiments with extra -D flags); never a fallback
 LIB_PATH = os.environ.get("UMGEN_LIB_PATH") or os.path.join(HERE, "libumgen_hip.so")
-SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "debug_api.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "vqdec.hip", "debug_api.hip"]
 EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen_rollout", "umgen_frame",
            "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",
            "umgen_tokenize_ego", "umgen_detokenize_ego", "umgen_tokenize_boxes", "umgen_detokenize_boxes",
+           "umgen_vq_create", "umgen_vq_load_tensor", "umgen_vq_finalize", "umgen_vq_decode", "umgen_vq_last_error", "umgen_vq_destroy",
            "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench", "umgen_dbg_oar_step"]
 
 PREC_FP32, PREC_BF16, PREC_FP16 = 0, 1, 2
@@ -30,6 +31,13 @@ class Config(C.Structure):
         "n_tar_layer", "n_oar_layer", "pose_vocab", "map_vocab", "bbox3d_vocab", "img_vocab", "aux_vocab",
         "n_map_embd", "n_img_embd", "max_frame_len", "task_num", "task_id", "precision", "max_batch",
         "max_cond_frames", "device", "use_graphs")]
+
+
+class VQConfig(C.Structure):
+    _fields_ = [("n_embed", C.c_int32), ("embed_dim", C.c_int32), ("z_channels", C.c_int32), ("ch", C.c_int32), ("out_ch", C.c_int32),
+                ("n_levels", C.c_int32), ("ch_mult", C.c_int32 * 8), ("num_res_blocks", C.c_int32), ("n_attn_res", C.c_int32),
+                ("attn_resolutions", C.c_int32 * 4), ("resolution", C.c_int32), ("post_quant_ks", C.c_int32), ("post_quant_pad", C.c_int32),
+                ("token_h", C.c_int32), ("token_w", C.c_int32), ("device", C.c_int32)]
 
 
 class Sampling(C.Structure):
@@ -99,6 +107,45 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+HOST_LIB_PATH = os.path.join(HERE, "libumgen_host.so")
+HOST_EXPORTS = ["umgen_tokenize_ego", "umgen_detokenize_ego", "umgen_tokenize_boxes", "umgen_detokenize_boxes"]
+
+
+def build_host_library(force: bool = False) -> str:
+    """The scene-format entry points of the C ABI (csrc/tokenizers.hip: plain host C++, no device code) as a small library of their
+    own, built with g++: dataset tokenisation / detokenisation (umgen_amd/scene_io.py, the reader either side of the rollout) then
+    needs neither hipcc nor a ROCm runtime.  libumgen_hip.so exports the same four functions from the same source."""
+    src = os.path.join(CSRC, "tokenizers.hip")
+    if not force and os.path.exists(HOST_LIB_PATH) and os.path.getmtime(HOST_LIB_PATH) >= os.path.getmtime(src):
+        return HOST_LIB_PATH
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no host C++ compiler (g++) found: cannot build libumgen_host.so")
+    subprocess.run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas", "-x", "c++", src,
+                    "-o", HOST_LIB_PATH], check=True)
+    return HOST_LIB_PATH
+
+
+_host = None
+
+
+def load_host_library() -> C.CDLL:
+    """Tokenizer / normaliser entry points (host only).  Built on first use when a compiler is there; fails loudly otherwise."""
+    global _host
+    if _host is not None:
+        return _host
+    lib = C.CDLL(build_host_library())
+    f64p, f32p, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    lib.umgen_tokenize_ego.argtypes = [f64p, C.c_int64, i64p]
+    lib.umgen_detokenize_ego.argtypes = [i64p, C.c_int64, f32p]
+    lib.umgen_tokenize_boxes.argtypes = [f32p, C.c_int64, C.c_int32, i32p, i64p]
+    lib.umgen_detokenize_boxes.argtypes = [i64p, C.c_int64, f64p]
+    for name in HOST_EXPORTS:
+        getattr(lib, name).restype = C.c_int
+    _host = lib
+    return lib
+
+
 _lib = None
 
 
@@ -138,8 +185,15 @@ def load_library() -> C.CDLL:
     lib.umgen_dbg_gemv.argtypes = [i32, fp, fp, vp, fp, i32, i32, i32, i32, fp]
     lib.umgen_dbg_gemm_bench.argtypes = [i32, i32, i32, i32, i32, fp]
     lib.umgen_dbg_oar_step.argtypes = [vp, i32, i32, fp, fp, i32, i32]
+    lib.umgen_vq_create.argtypes = [C.POINTER(VQConfig), C.POINTER(vp)]
+    lib.umgen_vq_load_tensor.argtypes = [vp, C.c_char_p, fp, i64p, i32]
+    lib.umgen_vq_finalize.argtypes = [vp]
+    lib.umgen_vq_decode.argtypes = [vp, i32, i64p, fp]
+    lib.umgen_vq_last_error.argtypes = [vp]
+    lib.umgen_vq_last_error.restype = C.c_char_p
+    lib.umgen_vq_destroy.argtypes = [vp]
     for name in EXPORTS:
-        if name not in ("umgen_last_error", "umgen_version"):
+        if name not in ("umgen_last_error", "umgen_version", "umgen_vq_last_error"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

@@ -130,6 +130,20 @@ __device__ inline float dpp_xor8(float v) { return __int_as_float(__builtin_amdg
 // exact GELU (nn.GELU default, module.py:239): 0.5 x (1 + erf(x / sqrt(2)))
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// GELU of the 16-bit GEMM epilogues: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute: 1 rcp + 1 exp2 + 8 FMA / mul instead
+// of erff's ~40 instructions).  The erf-GELU epilogue of the fc GEMM costs a wave 128 evaluations per 256 x 256 tile -- with erff
+// that was as long as the tile's MFMAs (fc + GELU 713 vs 942 TFLOP/s without, profiles/r03_gemm_bench_256tile_stagger.txt).  The
+// result is rounded to 16 bits right behind it (relative 2^-9 / 2^-12), so the 1.5e-7 are fp32-noise class; fp32 mode keeps erff.
+__device__ inline float gelu_fast(float x) {
+    const float z = x * 0.70710678118654752440f, az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    const float p = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
+    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
+    const float erf_abs = 1.0f - p * e;
+    return 0.5f * x * (1.0f + copysignf(erf_abs, z));
+}
+template <typename T> __device__ inline float gelu_for(float x) { return sizeof(T) == 2 ? gelu_fast(x) : gelu_erf(x); }
+
 // loads 8 consecutive elements as fp32
 __device__ inline void load8(const float* p, float (&o)[8]) {
     const float4 a = *reinterpret_cast<const float4*>(p);

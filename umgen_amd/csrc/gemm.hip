@@ -28,7 +28,7 @@ __device__ inline void epilogue4(const GemmArgs& a, int z, int i0, int j, const 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float t = v[r] + (a.bias ? a.bias[i0 + r] : 0.f);   // Mi (features) is a multiple of 4
-        if (MODE == GEMM_STORE && a.gelu) t = gelu_erf(t);
+        if (MODE == GEMM_STORE && a.gelu) t = gelu_for<TO>(t);
         o[r] = t;
     }
     if (MODE == GEMM_RESID) {
@@ -175,7 +175,7 @@ __device__ __forceinline__ void store_tile_rows_bf16(const GemmArgs& a, int z, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float t = acc[m][n][r] + bb[r];
-                o[r] = a.gelu ? gelu_erf(t) : t;
+                o[r] = a.gelu ? gelu_fast(t) : t;
             }
             const int tl = wj * 32 + n * 16 + frow;
             const int pg = (wi * 16 + m * 4 + g) ^ frow;
@@ -453,8 +453,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pers_kernel(GemmArgs a, int nI,
 template <typename TT>
 void launch_gemm_mfma(hipStream_t s, const GemmArgs& a) {
     // large launches: the 256 x 256 deep-pipelined kernel (gemm256.hip); it needs >= 1.5 tiles per CU to fill the chip
-    static const int min_tiles256 = getenv("UMGEN_GEMM256_MIN_TILES") ? atoi(getenv("UMGEN_GEMM256_MIN_TILES")) : 384;
-    if (a.tile256 >= 0 && gemm256_supported(a) && (a.tile256 > 0 || (long)(a.Mi / 256) * ((a.Nj + 255) / 256) >= min_tiles256)) {
+    // (measured, profiles/r03_gemm_bench_256tile_stagger.txt: at one scene -- 44 140 tokens -- it wins on qkv / fc / the K = 3072
+    //  projection (+4 / +10 / +16 %) and loses on the two launches with ~1000 tiles, where 256 workgroups x 1 tile quantise badly;
+    //  from two scenes on it wins everywhere, +12-20 %)
+    static const int min_tiles256 = getenv("UMGEN_GEMM256_MIN_TILES") ? atoi(getenv("UMGEN_GEMM256_MIN_TILES")) : 1100;
+    const long tiles256 = (long)(a.Mi / 256) * ((a.Nj + 255) / 256);
+    if (a.tile256 >= 0 && gemm256_supported(a) && (a.tile256 > 0 || tiles256 >= min_tiles256 || (a.K >= 2048 && tiles256 >= min_tiles256 / 3))) {
         launch_gemm256<TT>(s, a);
         return;
     }

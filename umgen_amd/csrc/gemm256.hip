@@ -35,6 +35,11 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 
 struct Src { unsigned p[2][2], q[2][2]; };   // element offsets of this lane's 16-byte pieces: [half][segment group]
 
+#ifndef UMGEN_GEMM256_STAGGER
+#define UMGEN_GEMM256_STAGGER 1
+#endif
+constexpr bool STAGGER = UMGEN_GEMM256_STAGGER;
+
 template <int MODE, typename TT>
 __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int nJ, int splitI) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -86,6 +91,11 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
     issue(4 + 3, Q, cur.q[1], HK);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // STAGGER: the waves of the second feature half (one per SIMD, like those of the first) run one barrier interval behind: while one
+    // group issues its fragment reads and its share of a refill, the other group's 16 MFMAs own the matrix pipe (MI355X playbook: the
+    // wave role split is what lets LDS reads, LDS-DMA and MFMAs overlap inside one workgroup).  Both groups pass the same number
+    // of barriers: this one here, its counterpart for the first group behind the last tile.
+    if (STAGGER && wi == 1) __builtin_amdgcn_s_barrier();
 
     unsigned char* stage = lds + kRing + wave * kStage;
     while (true) {
@@ -120,8 +130,8 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *reinterpret_cast<const vec8*>(sP + swz(m * 16 + frow, kk * 4 + g));
             if (do1) issue(par1 * 4 + 0, P, s1.p[0], k1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired BEFORE the barrier: the other wave group's next refill may target this slot
             __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -138,8 +148,8 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) fb1[n][kk] = *reinterpret_cast<const vec8*>(sQ + swz((2 + n) * 16 + frow, kk * 4 + g));
             if (do1) issue(par1 * 4 + 1, P, s1.p[1], k1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired BEFORE the barrier: the other wave group's next refill may target this slot
             __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -156,8 +166,8 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *reinterpret_cast<const vec8*>(sP + swz((4 + m) * 16 + frow, kk * 4 + g));
             if (do2) issue(par * 4 + 2, Q, s2.q[0], k2);       // (the Q slots of this k-tile: their last reads were phase 1's)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired BEFORE the barrier: the other wave group's next refill may target this slot
             __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float v = acc[m][n][r] + bv[m][r];
-                            o[r] = GELU ? gelu_erf(v) : v;
+                            o[r] = GELU ? gelu_fast(v) : v;
                         }
                         store4(reinterpret_cast<TT*>(stage + frow * 256 + (((m * 4 + g) ^ frow) << 3)), o);   // 8-byte granule p of token t at p ^ t
                     }
@@ -278,6 +288,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
         t = tn;
         cur = nxt;
     }
+    if (STAGGER && wi == 0) __builtin_amdgcn_s_barrier();
 }
 
 }  // namespace

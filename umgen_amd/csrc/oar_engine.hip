@@ -59,7 +59,18 @@ constexpr int L_SO = L_SM + 192;           // per lane-group o [64][48]         
 constexpr int L_MISC = L_SO + 64 * 48;     // rank / scratch                                                      [16]
 constexpr int L_LN = L_MISC + 16;          // ln_1 | ln_2 weights of the item                                     [1536]
 constexpr int L_W2 = L_LN + 2 * E;         // parked mlp c_proj units 0..11 of every thread: [12][512] x 16 B      [24576]
-constexpr int L_TOTAL = L_W2 + 12 * NT * 4;
+// K/V staging of the attention: UMGEN_ENG_LDS_KEYS more keys per wave in flight than the two register buffers hold, brought in by
+// LDS-DMA (global_load_lds: no VGPRs) while the group waits for x.  Private to each wave: [K rows 16 x 96 B | V rows 16 x 96 B]
+// MEASURED (profiles/r03_engine_experiments.txt): attention 3.67 vs 3.68 us per item, 561 vs 563 us per launch -- the phase is not
+// waiting for K/V (its ~100 VALU instructions per 16-key pass and their DPP / exp dependency chains are what it costs).  Off.
+#ifndef UMGEN_ENG_LDS_KEYS
+#define UMGEN_ENG_LDS_KEYS 0
+#endif
+constexpr int kStageKeys = UMGEN_ENG_LDS_KEYS;           // 0 or 16
+static_assert(kStageKeys == 0 || kStageKeys == 16, "staging is written for 16 keys (two 8-key passes)");
+constexpr int L_KV = L_W2 + 12 * NT * 4;                 // [8 waves][768 floats = 3 KB]
+constexpr int L_TOTAL = L_KV + (kStageKeys ? NW * 768 : 0);
+static_assert(L_TOTAL * 4 <= 160 * 1024, "LDS budget");
 
 __device__ inline u32 xcc_id() {
     u32 x;
@@ -184,6 +195,39 @@ __device__ inline void req768(Rows768<R>& w, const bf16_t* W, int row0, int lane
         w.b[j] = KEEP ? ldwk(base, off) : ldwu(base, off);
     }
 }
+// the same for rows that are not consecutive in W: row r of the wave is W row rowof(r)
+template <int R, bool KEEP, typename F>
+__device__ inline void req768_rows(Rows768<R>& w, const bf16_t* W, F rowof, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bf16_t* base = W + (long)rowof(r) * E;
+        w.a[r] = KEEP ? ldwk(base, (u32)lane * 8u) : ldwu(base, (u32)lane * 8u);
+    }
+#pragma unroll
+    for (int j = 0; j < (R + 1) / 2; ++j) {
+        const int r1 = 2 * j + 1 < R ? 2 * j + 1 : 2 * j;     // odd R: the upper half-wave re-reads the last row's tail, its copy is ignored
+        const bf16_t* base = W + (long)(lane < 32 ? rowof(2 * j) : rowof(r1)) * E + 512;
+        const u32 off = (u32)(lane & 31) * 8u;
+        w.b[j] = KEEP ? *(const UMGEN_GLOBAL u32x4_t*)(base + off) : __builtin_nontemporal_load((const UMGEN_GLOBAL u32x4_t*)(base + off));
+    }
+}
+// dot products of rows [R0, R1) only (a pair's shared tail chunk is multiplied by whichever range needs one of its rows)
+template <typename TT, int R, int R0, int R1>
+__device__ inline void dot768_range(const Rows768<R>& w, const f32x2_t (&x1)[4], const f32x2_t (&x2)[4], int lane, float (&out)[R1 - R0]) {
+    const f32x2_t zero = {0.f, 0.f};
+    f32x2_t acc[R1 - R0];
+#pragma unroll
+    for (int r = R0; r < R1; ++r) acc[r - R0] = dot8<TT>(w.a[r], x1, zero);
+#pragma unroll
+    for (int j = R0 / 2; j < (R1 + 1) / 2; ++j) {
+        const f32x2_t p = dot8<TT>(w.b[j], x2, zero);
+        if (2 * j >= R0 && 2 * j < R1) acc[2 * j - R0] += (lane < 32) ? p : zero;
+        if (2 * j + 1 >= R0 && 2 * j + 1 < R1) acc[2 * j + 1 - R0] += (lane >= 32) ? p : zero;
+    }
+#pragma unroll
+    for (int r = 0; r < R1 - R0; ++r) out[r] = wave_sum(acc[r].x + acc[r].y);
+}
+
 template <typename TT, int R>
 __device__ inline void dot768(const Rows768<R>& w, const f32x2_t (&x1)[4], const f32x2_t (&x2)[4], int lane, float (&out)[R]) {
     const f32x2_t zero = {0.f, 0.f};
@@ -239,6 +283,16 @@ __device__ inline void ln768(const float* xs, const float* lnw, int lane, f32x2_
 #define UMGEN_SYS_KEEP_WF 0
 #endif
 constexpr bool kSysKeepWo = UMGEN_SYS_KEEP_WO, kSysKeepWf = UMGEN_SYS_KEEP_WF;
+// q rows first: every wave owns 3 q, 3 k and 3 v rows (instead of 9 consecutive rows of the packed c_attn matrix), computes and
+// publishes its q rows, THEN its k | v rows: the latency of the q hand-off (one L2 round trip, 1.1 us) runs beside the k | v row
+// products instead of behind all nine, and the new token's own k | v -- only one more key of the softmax -- is merged after the
+// cached keys.  0: round-2 order (nine consecutive rows, one hand-off of q | k | v, the new key inside the key spans)
+// MEASURED (profiles/r03_engine_experiments.txt): wait q 1.14 -> 0.75 us, but the own key's extra poll + pass puts the head's second
+// half 1 us behind the first (wait partials 1.09 -> 2.05 us): 603 vs 565 us per launch.  Kept as a build option, off.
+#ifndef UMGEN_ENG_QFIRST
+#define UMGEN_ENG_QFIRST 0
+#endif
+constexpr bool kQFirst = UMGEN_ENG_QFIRST;
 #ifndef UMGEN_ENG_STAGGER_US
 #define UMGEN_ENG_STAGGER_US 10
 #endif
@@ -331,6 +385,9 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             Rows768<RQ> wq;
             u32x4_t wpl[6];                          // units 12..17 of the mlp c_proj slice (requested after the attention)
             const int rowq = (w * NW + wave) * RQ, rowo = (w * NW + wave) * RO, rowf = (w * NW + wave) * RF;
+            const int rq0 = (w * NW + wave) * 3;
+            // row r (0..8) of this wave in the packed q | k | v matrix
+            auto qkv_row = [&](int r) { return kQFirst ? (r / 3) * E + rq0 + r % 3 : rowq + r; };
             const OarLayerDev lw = a.layers[l];
             const u32 tg = ep + (u32)((rd * 64 + l) * 8);
             // q|k|v, attention-projection and c_fc rows of this wave are requested NOW: they are in flight while the group waits
@@ -346,7 +403,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 for (int k = 0; k < 3; ++k) lnr[k] = ldg((tid + k * NT < E ? lw.ln_a : lw.ln_b - E) + tid + k * NT);
             }
             float bq = 0.f, bo = 0.f;
-            if (lane < RQ) bq = ldg(lw.bqkv + rowq + lane);
+            if (lane < RQ) bq = ldg(lw.bqkv + qkv_row(lane));
             if (lane < RO) bo = ldg(lw.bo + rowo + lane);
             float x_first[2] = {0.f, 0.f};
             if (l == 0) {
@@ -366,12 +423,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         for (int j = 0; j < 6; ++j) w2p[(6 * hb + j) * NT] = wp[j];
                     }
                 }
-                req768<RQ, true>(wq, lw.Wqkv, rowq, lane);
+                req768_rows<RQ, true>(wq, lw.Wqkv, qkv_row, lane);
                 if (load_w || !kSysKeepWo) req768<RO, !kSysKeepWo>(wo, lw.Wo, rowo, lane);
                 if (load_w || !kSysKeepWf) req768<RF, !kSysKeepWf>(wf, lw.Wfc, rowf, lane);
             } else {
                 u32x4_t wp[12];
-                req768(wq, lw.Wqkv, rowq, lane);
+                req768_rows<RQ, false>(wq, lw.Wqkv, qkv_row, lane);
 #pragma unroll
                 for (int j = 0; j < 12; ++j) wp[j] = ldwu(wp2 + (long)j * NT * 8, (u32)tid * 8u);
 
@@ -387,11 +444,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             }
             // attention geometry of this CU: head hh, half of the L + 1 keys, split in 8 wave spans of 8-key passes
             const int hh = w >> 1, half = w & 1;
-            const int nk = Lk + 1;
+            const int nk = kQFirst ? Lk : Lk + 1;     // keys of the spans: the cached ones (the new token's own key is merged behind them) / all
             const int n0 = min(nk, (((nk + 1) >> 1) + 7) & ~7);
             const int ka = half ? n0 : 0, kb = half ? nk : n0;
             const int span = ((((kb - ka) + NW - 1) / NW) + 7) & ~7;
-            const int k_lo = ka + wave * span, k_hi = min(kb, k_lo + span);
+            const int k_lo = ka + wave * span;
+            int k_hi = min(kb, k_lo + span);
             const int piece = lane & 7, kg = lane >> 3;
             const bool pact = piece < 6;
             const bf16_t* kbase = a.kvcache + (long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride + (long)hh * a.Lmax * kHeadDim;
@@ -412,20 +470,43 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     touched ^= *(const UMGEN_GLOBAL u32*)(v0p + ((long)ln << 7));
                 }
             }
+            // 16 more keys of this wave's span (behind the 32 that the two register buffers take) go straight into its LDS strip: 4 LDS-DMA
+            // instructions, 3 KB, issued HERE -- in front of the idle wait -- because the compiler drains every load in flight
+            // (s_waitcnt vmcnt(0)) in front of the first LDS read behind an LDS-DMA.  With the two register buffers alone every later
+            // 16-key chunk waited ~0.3 us of an L2 round trip behind 0.3 us of work (attention 3.55 us at L = 1100).  Not where no idle
+            // wait follows (a launch's first item, a busy systolic group): there the drain would be the whole weight stream.
+            const bool staged = kStageKeys != 0 && !SYS && D > 1 && l != 0 && k_lo + 32 < k_hi;
+            float* kvs = lds + L_KV + wave * 768;
+            if (staged) {
+                const u32 eoff = (u32)(k_lo + 32) * (u32)kHeadDim + (u32)lane * 8u;   // element offset of this lane's 16 bytes
+                typedef __attribute__((address_space(3))) void* lds_ptr;
+                __builtin_amdgcn_global_load_lds((const UMGEN_GLOBAL void*)(kbase + eoff), (lds_ptr)kvs, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const UMGEN_GLOBAL void*)(vbase + eoff), (lds_ptr)(kvs + 384), 16, 0, 0);
+                if (lane < 32) {   // keys 10.67 .. 16 of the strip: the second half-kilobyte
+                    __builtin_amdgcn_global_load_lds((const UMGEN_GLOBAL void*)(kbase + eoff + 512), (lds_ptr)(kvs + 256), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const UMGEN_GLOBAL void*)(vbase + eoff + 512), (lds_ptr)(kvs + 384 + 256), 16, 0, 0);
+                }
+            }
+            const int kst = staged ? kStageKeys : 0;
             stamp(-1);
             // ================= P1: x -> LN -> q | k | v =================
             float* lnw = lds + L_LN;
-            if (l == 0) {
-                xs[tid] = x_first[0];
-                if (tid + NT < E) xs[tid + NT] = x_first[1];
-            } else {
-                gather<2>(c, tid, D == 1 ? gxl : a.gx + (long)s * E, E, tg + 0, xs);
-            }
-            if (load_w) {
+            if (load_w) {   // (nobody reads the previous item's LayerNorm weights any more: its last use is in front of P4's barrier)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) lnw[tid + k * NT] = lnr[k];
             }
-            wg_barrier();
+            if (l == 0) {
+                xs[tid] = x_first[0];
+                if (tid + NT < E) xs[tid + NT] = x_first[1];
+                wg_barrier();
+            } else {
+                gather<2>(c, tid, D == 1 ? gxl : a.gx + (long)s * E, E, tg + 0, xs);   // (ends with the workgroup barrier)
+            }
+            if (kStageKeys && !SYS) {
+                // the compiler drains every load in flight in front of the first LDS read behind an LDS-DMA: take that wait HERE, where
+                // everything has landed during the idle wait, and not in front of the LayerNorm's LDS reads behind the K/V requests below
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (expcnt / lgkmcnt untouched), as an instruction the wait-count pass models
+            }
             stamp(0);   // waited for x
 #ifndef UMGEN_ENG_NB
 #define UMGEN_ENG_NB 2
@@ -446,15 +527,27 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             if (k_lo + 8 * KP < k_hi) kv_req(1, k_lo + 8 * KP);
             {
                 f32x2_t x1[4], x2[4];
-                float out[RQ];
                 ln768(xs, lnw, lane, x1, x2);
-                dot768<TT, RQ>(wq, x1, x2, lane, out);
+                const int n = qkv_row(min(lane, RQ - 1));
                 float v = 0.f;
+                if (kQFirst) {
+                    float oq[3];
+                    dot768_range<TT, RQ, 0, 3>(wq, x1, x2, lane, oq);
 #pragma unroll
-                for (int r = 0; r < RQ; ++r) v = (lane == r) ? out[r] : v;
+                    for (int r = 0; r < 3; ++r) v = (lane == r) ? oq[r] : v;
+                    if (lane < 3) put_local(gqkv, (u32)n, tg + 1, v + bq);       // q rows are on their way while the k | v rows are multiplied
+                    float okv[6];
+                    dot768_range<TT, RQ, 3, 9>(wq, x1, x2, lane, okv);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) v = (lane == 3 + r) ? okv[r] : v;
+                } else {
+                    float out[RQ];
+                    dot768<TT, RQ>(wq, x1, x2, lane, out);
+#pragma unroll
+                    for (int r = 0; r < RQ; ++r) v = (lane == r) ? out[r] : v;
+                }
                 v += bq;
-                if (lane < RQ) {
-                    const int n = rowq + lane;
+                if (lane < RQ && !(kQFirst && lane < 3)) {
                     put_local(gqkv, (u32)n, tg + 1, v);
                     if (n >= E) {   // K / V rows of the new token: bf16 into the cache (head-major [2][H][Lmax][48])
                         const int cc = n - E, kvsel = cc / E, hc = cc % E;
@@ -472,20 +565,25 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             {
                 // q_h | k_h | v_h of the new token
                 float* qs = lds + L_QKV;
-                if (!c.failed) {
-                    const int src = (tid / kHeadDim) * E + hh * kHeadDim + tid % kHeadDim;
-                    for (u32 spins = 0;;) {
-                        bool ok = true;
-                        u64 v = 0;
-                        if (tid < 3 * kHeadDim) { v = get(gqkv, (u32)src); ok = (u32)(v >> 32) == tg + 1; }
-                        if (ok && tid < 3 * kHeadDim) qs[tid] = __uint_as_float((u32)v);
-                        if (!__any(!ok)) break;
-                        if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, (tg + 1) | 0x80000000u); c.failed = true; break; }
-                        if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
+                // values [lo, hi) of q_h | k_h | v_h (48 each) of this CU's head out of the group's q | k | v granules
+                auto poll_head = [&](int lo, int hi) {
+                    if (!c.failed) {
+                        const int src = (tid / kHeadDim) * E + hh * kHeadDim + tid % kHeadDim;
+                        const bool mine = tid >= lo && tid < hi;
+                        for (u32 spins = 0;;) {
+                            bool ok = true;
+                            u64 v = 0;
+                            if (mine) { v = get(gqkv, (u32)src); ok = (u32)(v >> 32) == tg + 1; }
+                            if (ok && mine) qs[tid] = __uint_as_float((u32)v);
+                            if (!__any(!ok)) break;
+                            if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, (tg + 1) | 0x80000000u); c.failed = true; break; }
+                            if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
+                        }
                     }
-                }
-                wg_barrier();
-                stamp(2);   // waited for q_h | k_h | v_h
+                    wg_barrier();
+                };
+                poll_head(0, kQFirst ? kHeadDim : 3 * kHeadDim);
+                stamp(2);   // waited for q_h (| k_h | v_h)
                 float q8[8];   // this lane's piece of q
 #pragma unroll
                 for (int e = 0; e < 8; ++e) q8[e] = pact ? qs[piece * 8 + e] : 0.f;
@@ -540,15 +638,40 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 // chunks of 8 KP keys in NB register buffers, all requested before q|k|v were exchanged; a buffer is requested again as
                 // soon as it has been consumed
                 for (int k0 = k_lo; k0 < k_hi; k0 += 8 * KP * NB) {
+                    if (k0 == k_lo + 8 * KP * NB && kst) {
+                        // the staged keys sit between the first round of the register buffers and their reloads
+                        u32x4_t kl[KP], vl[KP];
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) {
+                            const float* kr = kvs + (8 * i + kg) * 24 + piece * 4;       // key j of the strip: 96 bytes at 24 floats
+                            kl[i] = pact ? *reinterpret_cast<const u32x4_t*>(kr) : u32x4_t{0, 0, 0, 0};
+                            vl[i] = pact ? *reinterpret_cast<const u32x4_t*>(kr + 384) : u32x4_t{0, 0, 0, 0};
+                        }
+                        chunk(kl, vl, k0);
+                        k0 += kst;
+                        if (k0 >= k_hi) break;
+                    }
                     chunk(kc[0], vc[0], k0);
-                    if (k0 + 8 * KP * NB < k_hi) kv_req(0, k0 + 8 * KP * NB);
+                    if (k0 + 8 * KP * NB + (k0 == k_lo ? kst : 0) < k_hi) kv_req(0, k0 + 8 * KP * NB + (k0 == k_lo ? kst : 0));
                     if (k0 + 8 * KP < k_hi) {
                         chunk(kc[1], vc[1], k0 + 8 * KP);
-                        if (k0 + 8 * KP * (NB + 1) < k_hi) kv_req(1, k0 + 8 * KP * (NB + 1));
+                        if (k0 + 8 * KP * (NB + 1) + (k0 == k_lo ? kst : 0) < k_hi) kv_req(1, k0 + 8 * KP * (NB + 1) + (k0 == k_lo ? kst : 0));
                     }
                     if (NB > 2 && k0 + 16 * KP < k_hi) {
                         chunk(kc[NB > 2 ? 2 : 0], vc[NB > 2 ? 2 : 0], k0 + 16 * KP);
                         if (k0 + 8 * KP * (NB + 2) < k_hi) kv_req(NB > 2 ? 2 : 0, k0 + 8 * KP * (NB + 2));
+                    }
+                }
+                if (kQFirst) {
+                    // the new token's own key: k_h | v_h have been on their way since P1; one wave of the head's second half adds the
+                    // key as one more term of its online softmax (as the cache will hold it: rounded to 16 bits)
+                    poll_head(kHeadDim, 3 * kHeadDim);
+                    if (half == 1 && wave == NW - 1) {
+                        k_hi = Lk + 1;
+                        u32x4_t kz[KP], vz[KP];
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) { kz[i] = u32x4_t{0, 0, 0, 0}; vz[i] = u32x4_t{0, 0, 0, 0}; }
+                        chunk(kz, vz, Lk);
                     }
                 }
                 // 64 lane-group partials of this CU -> LDS -> one half partial (m, l, o[48]) published by wave 0
@@ -568,7 +691,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     const float M = wave_max(mg);
                     const float wg = (M > -INFINITY) ? __expf(mg - M) : 0.f;
                     const float Ls = wave_sum(wg * sm[64 + lane]);
-                    float* fold = lds + L_GP;   // (free until the P3 gather, which starts behind the barrier below)
+                    float* fold = lds + L_HS;   // (the MLP's strip: free until P4 -- so no barrier is needed between the folds' readers and P3's gather)
                     if (tid < 8 * kHeadDim) {
                         const int jg = tid / kHeadDim, d = tid % kHeadDim;
                         float o = 0.f;
@@ -588,7 +711,6 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         put_local(gp, (u32)tid, tg + 2, o);
                         if (tid == 0) { put_local(gp, 48u, tg + 2, M); put_local(gp, 49u, tg + 2, Ls); }
                     }
-                    wg_barrier();   // fold (the gather buffer) is free again
                 }
             }
             stamp(3);   // attention of this CU's half
@@ -605,7 +727,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     const float* p1 = p0 + 50;
                     const float m0 = p0[48], m1 = p1[48];
                     const float M = fmaxf(m0, m1);
-                    const float e0 = expf(m0 - M), e1 = (m1 > -INFINITY) ? expf(m1 - M) : 0.f;
+                    const float e0 = (m0 > -INFINITY) ? expf(m0 - M) : 0.f, e1 = (m1 > -INFINITY) ? expf(m1 - M) : 0.f;
                     const float Ls = fmaf(e1, p1[49], e0 * p0[49]);
                     as[col] = fmaf(e1, p1[d], e0 * p0[d]) / Ls;
                 }
@@ -720,7 +842,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_census_kernel(u32* cou
 }
 
 size_t oar_engine_lds_bytes() {
-    const size_t need = (size_t)L_TOTAL * sizeof(float);
+    const size_t need = (size_t)L_TOTAL * sizeof(float);   // (with the K/V strips: 159.2 KB of the CU's 160)
     return need > (size_t)(96 << 10) ? need : (size_t)(96 << 10);   // > 80 KB: never two engine workgroups on one CU
 }
 

@@ -87,7 +87,7 @@ def encode_ego(pose_diff: np.ndarray) -> np.ndarray:
     """Normalize_Standard(mean 0, std [10, 4, 1]) then the 1024-bin tokenizer over [-1, 1]  ->  [T, 3] tokens (native)."""
     pd = np.ascontiguousarray(pose_diff, dtype=np.float64).reshape(-1, 3)
     out = np.empty(pd.shape, dtype=np.int64)
-    _native(_lib.load_library().umgen_tokenize_ego(_ptr(pd, C.c_double), pd.shape[0], _ptr(out, C.c_int64)), "umgen_tokenize_ego")
+    _native(_lib.load_host_library().umgen_tokenize_ego(_ptr(pd, C.c_double), pd.shape[0], _ptr(out, C.c_int64)), "umgen_tokenize_ego")
     return out.reshape(np.shape(pose_diff))
 
 
@@ -95,7 +95,7 @@ def decode_ego(pose_tokens: np.ndarray) -> np.ndarray:
     """Tokens [..., 3] -> (dx, dy, dheading) float32 -- what UMGen.decode_pose returns (native)."""
     t = np.ascontiguousarray(pose_tokens, dtype=np.int64).reshape(-1, 3)
     out = np.empty(t.shape, dtype=np.float32)
-    _native(_lib.load_library().umgen_detokenize_ego(_ptr(t, C.c_int64), t.shape[0], _ptr(out, C.c_float)), "umgen_detokenize_ego")
+    _native(_lib.load_host_library().umgen_detokenize_ego(_ptr(t, C.c_int64), t.shape[0], _ptr(out, C.c_float)), "umgen_detokenize_ego")
     return out.reshape(np.shape(pose_tokens))
 
 
@@ -121,7 +121,7 @@ def decode_boxes(bbox3d_tokens: np.ndarray):
     keep = np.nonzero(~np.any(t == BBOX_PAD, axis=1))[0]
     sl = np.ascontiguousarray(t[keep])
     out = np.empty((sl.shape[0], 10), dtype=np.float64)
-    _native(_lib.load_library().umgen_detokenize_boxes(_ptr(sl, C.c_int64), sl.shape[0], _ptr(out, C.c_double)), "umgen_detokenize_boxes")
+    _native(_lib.load_host_library().umgen_detokenize_boxes(_ptr(sl, C.c_int64), sl.shape[0], _ptr(out, C.c_double)), "umgen_detokenize_boxes")
     cats = [CATEGORIES[c - 1024] if 1024 <= c < 1024 + len(CATEGORIES) else "none" for c in t[keep, 10].tolist()]
     return out, cats, keep
 
@@ -158,7 +158,7 @@ def box_tokens(b: np.ndarray, cat_index: Sequence[int]) -> np.ndarray:
     b = np.ascontiguousarray(np.atleast_2d(b), dtype=np.float32)
     ci = np.ascontiguousarray(cat_index, dtype=np.int32)
     out = np.empty((b.shape[0], SLOT_LEN), dtype=np.int64)
-    _native(_lib.load_library().umgen_tokenize_boxes(_ptr(b, C.c_float), b.shape[0], b.shape[1], _ptr(ci, C.c_int32), _ptr(out, C.c_int64)),
+    _native(_lib.load_host_library().umgen_tokenize_boxes(_ptr(b, C.c_float), b.shape[0], b.shape[1], _ptr(ci, C.c_int32), _ptr(out, C.c_int64)),
             "umgen_tokenize_boxes")
     return out
 
