@@ -55,6 +55,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from umgen_amd.weights import is_matrix_weight
 from umgen_amd.config import (BBOX_PAD, BBOX_RANGE, BOS_EOS, CONTENT_LEN, EGO_BOX, EGO_STD, MOD_ORDER, MOD_START,
                               N_SLOTS, SEQ_LEN, SLOT_LEN, TOKEN_LEN, RolloutConfig)
 
@@ -282,7 +283,11 @@ class OracleUMGen:
             t = torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v
             if t.dtype != torch.bfloat16:
                 t = t.float()
-                if weight_dtype != "fp32" and t.dim() >= 2:
+                # 16-bit modes: exactly the tensors the engine stores in 16 bits -- the nn.Linear weights (umgen_amd.weights.is_matrix_weight:
+                # attention / MLP / GMLP / head matrices).  Embedding tables, codebooks, LayerNorm weights and biases stay fp32 in the engine
+                # (and under the reference's autocast, which only casts the operands of matmuls): rounding them here as well -- rounds 1-2
+                # did -- put the oracle FURTHER from the fp32 truth than the engine is (tiny config, bf16: rms 1.8e-3 vs 1.0e-3).
+                if weight_dtype != "fp32" and is_matrix_weight(k):
                     t = self._round(t)
             self.w[k] = t
         self.engine_rounding = weight_dtype.endswith("_engine")

@@ -48,7 +48,7 @@ def test_production_decoders_match_reference_golden(name):
     assert abs(float(np.sqrt((out.astype(np.float64) ** 2).mean())) - float(g["rms"])) < 1e-5
 
 
-def test_wrappers_and_errors():
+def test_wrappers_and_errors(tmp_path):
     """Mapdecoder / Imagedecoder (decode_map.py:110-183) on the rollout's token layout; frames are independent (a batch of 3 equals
     the three single frames: the reference decodes 20 frames per call); malformed inputs fail loudly."""
     cfg = SMALL["small_image"]
@@ -69,5 +69,15 @@ def test_wrappers_and_errors():
     bare.close()
     mcfg = SMALL["small_map"]
     mdec = Mapdecoder({k: synth_vq_tensor(k, s, SEED) for k, s in decoder_keys(mcfg).items()}, cfg=mcfg)
-    rgb = mdec.decode_maps(np.random.default_rng(4).integers(0, mcfg["n_embed"], size=(1, 2, 256)), H=16, W=16)
+    mtok = np.random.default_rng(4).integers(0, mcfg["n_embed"], size=(1, 2, 256))
+    rgb = mdec.decode_maps(mtok, H=16, W=16)
     assert rgb.shape == (2, 3, 64, 64) and rgb.min() >= -1.0 - 1e-6 and rgb.max() <= 1.0 + 1e-6
+    # a checkpoint path like the reference's Mapdecoder(ckpt) (VQModel.init_from_ckpt: torch.load(path)["state_dict"], encoder keys ignored)
+    import torch
+    sdm = {k: torch.from_numpy(synth_vq_tensor(k, s, SEED)) for k, s in decoder_keys(mcfg).items()}
+    sdm["encoder.conv_in.weight"] = torch.zeros(4, 3, 3, 3)
+    torch.save({"state_dict": sdm}, tmp_path / "map_vq.pt")
+    np.testing.assert_array_equal(Mapdecoder(str(tmp_path / "map_vq.pt"), cfg=mcfg).decode_maps(mtok, H=16, W=16), rgb)
+    del sdm["decoder.conv_out.bias"]
+    with pytest.raises(VQError, match="lacks 1 decoder"):
+        Mapdecoder(sdm, cfg=mcfg)

@@ -121,7 +121,10 @@ class RolloutConfig:
         if g("bias", False):
             unsupported.append("bias=True")
         if c.no_born:
-            unsupported.append("no_born=True")
+            # [probe, round 3] the reference's own no_born branch (UMGen.py:1106-1114) cannot run: without control objects it reads the
+            # unassigned `object_id` (UnboundLocalError, line 1109); with them its 0-dim pad token breaks the torch.cat at line 1238
+            # ("Tensors must have same number of dimensions: got 4 and 1").  There is no behaviour to reproduce, so it stays refused.
+            unsupported.append("no_born=True (the reference itself raises on this branch)")
         # switches whose non-default value changes what the engine hard-codes (UMGen.py:99-172): refuse them instead of
         # silently producing other tokens
         if g("split_image_ar", False):

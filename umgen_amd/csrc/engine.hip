@@ -1007,8 +1007,8 @@ int build_tables(umgen_engine* e) {
 
 // Decode engine (oar_engine.hip): the mlp c_proj of every BlockOAR, repacked for the hidden-unit split.  CU c of a group owns
 // hidden units 96 c .. 96 c + 95; thread t of its workgroup holds, as 16-byte units of 8 bf16 in the order it requests them,
-//   unit j < 12 : W[t][96 c + 8 j .. + 7]                                  (all 96 columns of output row t)
-//   unit 12 + j : W[512 + (t & 255)][96 c + 8 (6 (t >> 8) + j) .. + 7]     (half of the columns of one of the rows 512..767)
+//   unit j < 12 : W[4 (t / 4) + j / 3][96 c + 24 (t % 4) + 8 (j % 3) .. + 7]      (four lanes share rows 4 (t / 4) .. + 3)
+//   units 12..17: 48 weights, weight i = W[512 + 4 (t / 8) + i / 12][96 c + 12 (t % 8) + i % 12]   (eight lanes share four of the rows 512..767)
 // layout [32 CUs][18 units][512 threads][8]: a wave's request of one unit is 1 KB contiguous.
 int repack_mlp_proj(umgen_engine* e) {
     const int E = e->E, F4 = 4 * E;
@@ -1025,9 +1025,15 @@ int repack_mlp_proj(umgen_engine* e) {
         for (int c = 0; c < kEngGroup; ++c)
             for (int j = 0; j < kEngWpUnits; ++j)
                 for (int t = 0; t < kEngThreads; ++t) {
-                    const int row = j < 12 ? t : 512 + (t & 255);
-                    const int col = 96 * c + 8 * (j < 12 ? j : 6 * (t >> 8) + (j - 12));
-                    memcpy(&dst[(((size_t)c * kEngWpUnits + j) * kEngThreads + t) * 8], &src[(size_t)row * F4 + col], 8 * sizeof(bf16_t));
+                    bf16_t* d8 = &dst[(((size_t)c * kEngWpUnits + j) * kEngThreads + t) * 8];
+                    if (j < 12) {
+                        memcpy(d8, &src[(size_t)(4 * (t / 4) + j / 3) * F4 + 96 * c + 24 * (t % 4) + 8 * (j % 3)], 8 * sizeof(bf16_t));
+                    } else {
+                        for (int k = 0; k < 8; ++k) {
+                            const int i = 8 * (j - 12) + k;
+                            d8[k] = src[(size_t)(512 + 4 * (t / 8) + i / 12) * F4 + 96 * c + 12 * (t % 8) + i % 12];
+                        }
+                    }
                 }
         HIPCHK(e, hipMemcpy(e->eng_wp2[li], dst.data(), dst.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
         hl[li].Wp2 = reinterpret_cast<const bf16_t*>(e->eng_wp2[li]);
@@ -1363,7 +1369,12 @@ int umgen_load_tensor(umgen_engine* e, const char* key, const void* data, int32_
     if (s.kind == 1 && e->cfg.precision == UMGEN_PREC_FP16) {   // round-to-nearest-even to IEEE half, like torch's .half()
         std::vector<f16_t> h(n);
         if (dtype == UMGEN_DT_F16) memcpy(h.data(), data, n * 2);
-        else for (size_t i = 0; i < n; ++i) h[i] = (f16_t)load_as_f32(data, dtype, i);
+        else for (size_t i = 0; i < n; ++i) {
+            const float v = load_as_f32(data, dtype, i);
+            if (std::isfinite(v) && std::fabs(v) > 65504.f)     // would become inf: refuse rather than decode garbage
+                return e->fail(UMGEN_E_INVALID, "%s[%zu] = %g does not fit fp16 (precision fp16 needs |w| <= 65504)", key, i, (double)v);
+            h[i] = (f16_t)v;
+        }
         HIPCHK(e, hipMemcpy(s.dst, h.data(), n * 2, hipMemcpyHostToDevice));
     } else if (to_bf16) {
         std::vector<bf16_t> h(n);

@@ -59,17 +59,7 @@ constexpr int L_SO = L_SM + 192;           // per lane-group o [64][48]         
 constexpr int L_MISC = L_SO + 64 * 48;     // rank / scratch                                                      [16]
 constexpr int L_LN = L_MISC + 16;          // ln_1 | ln_2 weights of the item                                     [1536]
 constexpr int L_W2 = L_LN + 2 * E;         // parked mlp c_proj units 0..11 of every thread: [12][512] x 16 B      [24576]
-// K/V staging of the attention: UMGEN_ENG_LDS_KEYS more keys per wave in flight than the two register buffers hold, brought in by
-// LDS-DMA (global_load_lds: no VGPRs) while the group waits for x.  Private to each wave: [K rows 16 x 96 B | V rows 16 x 96 B]
-// MEASURED (profiles/r03_engine_experiments.txt): attention 3.67 vs 3.68 us per item, 561 vs 563 us per launch -- the phase is not
-// waiting for K/V (its ~100 VALU instructions per 16-key pass and their DPP / exp dependency chains are what it costs).  Off.
-#ifndef UMGEN_ENG_LDS_KEYS
-#define UMGEN_ENG_LDS_KEYS 0
-#endif
-constexpr int kStageKeys = UMGEN_ENG_LDS_KEYS;           // 0 or 16
-static_assert(kStageKeys == 0 || kStageKeys == 16, "staging is written for 16 keys (two 8-key passes)");
-constexpr int L_KV = L_W2 + 12 * NT * 4;                 // [8 waves][768 floats = 3 KB]
-constexpr int L_TOTAL = L_KV + (kStageKeys ? NW * 768 : 0);
+constexpr int L_TOTAL = L_W2 + 12 * NT * 4;
 static_assert(L_TOTAL * 4 <= 160 * 1024, "LDS budget");
 
 __device__ inline u32 xcc_id() {
@@ -102,29 +92,61 @@ __device__ inline void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// Polling with TWO requests of every granule in flight, half a round trip apart.  With one (round 2) a poll that just misses the
+// producer's store costs a whole further round trip (L2: ~0.7 us, another XCD: ~1.5 us), on average half of one per hand-off and five
+// hand-offs per layer; a wave's loads return in order, so `check(older)` waits for the older request only (s_waitcnt vmcnt(PER)) and
+// the next one leaves as soon as it is back: the initial stagger sustains itself.  Loads are unconditional (granules already
+// received are simply requested again) so that the loop is straight-line code and the wait counts are exact.
+#ifndef UMGEN_ENG_POLL2
+#define UMGEN_ENG_POLL2 0
+#endif
+#ifndef UMGEN_ENG_POLL_STAGGER
+#define UMGEN_ENG_POLL_STAGGER 6      // s_sleep units of 64 clocks between the first two requests
+#endif
+// slot k of thread tid (bit k of need) waits for granule idx(k) and writes its value to dst[tid + k * NT]
+template <int PER, typename IDX>
+__device__ inline void poll_granules(Ctx& c, int tid, const u64* g, u32 need, IDX idx, u32 tag, float* dst) {
+    if (c.failed || !__any(need != 0u)) return;
+    u32 got = 0;
+    u32 ix[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) ix[k] = idx(k);
+    u64 va[PER], vb[PER];
+    auto issue = [&](u64 (&v)[PER]) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[k] = get(g, ix[k]);
+    };
+    auto check = [&](const u64 (&v)[PER]) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if ((((need & ~got) >> k) & 1u) && (u32)(v[k] >> 32) == tag) { dst[tid + k * NT] = __uint_as_float((u32)v[k]); got |= 1u << k; }
+        return !__any(got != need);
+    };
+    issue(va);
+    if (UMGEN_ENG_POLL2) __builtin_amdgcn_s_sleep(UMGEN_ENG_POLL_STAGGER);
+    for (u32 spins = 0;;) {
+        if (UMGEN_ENG_POLL2) {
+            issue(vb);
+            if (check(va)) break;
+            issue(va);
+            if (check(vb)) break;
+        } else {
+            if (check(va)) break;
+            issue(va);
+        }
+        if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, tag | 0x80000000u); c.failed = true; break; }
+        if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
+    }
+}
+
 // the workgroup gathers granules [0, n) of g into dst[0, n)
 template <int PER>
 __device__ inline void gather(Ctx& c, int tid, const u64* g, int n, u32 tag, float* dst) {
-    u32 got = 0, need = 0;
+    u32 need = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k)
         if (tid + k * NT < n) need |= 1u << k;
-    if (!c.failed) {
-        for (u32 spins = 0;;) {
-            u64 v[PER];
-#pragma unroll
-            for (int k = 0; k < PER; ++k)
-                if (((need & ~got) >> k) & 1u) v[k] = get(g, (u32)tid + (u32)(k * NT));
-#pragma unroll
-            for (int k = 0; k < PER; ++k)
-                if (((need & ~got) >> k) & 1u) {
-                    if ((u32)(v[k] >> 32) == tag) { dst[tid + k * NT] = __uint_as_float((u32)v[k]); got |= 1u << k; }
-                }
-            if (!__any(got != need)) break;
-            if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, tag | 0x80000000u); c.failed = true; break; }
-            if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
-        }
-    }
+    poll_granules<PER>(c, tid, g, need, [&](int k) { return (u32)min(tid + k * NT, n - 1); }, tag, dst);
     wg_barrier();
 }
 
@@ -159,12 +181,23 @@ __device__ inline void unpack8(const u32x4_t& w, float (&o)[8]) {
     const f32x2_t a = up2<TT>(w.x), b = up2<TT>(w.y), c = up2<TT>(w.z), d = up2<TT>(w.w);
     o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y; o[6] = d.x; o[7] = d.y;
 }
+// one weight pair x one activation pair: bf16 -> two widening instructions + one packed FMA (3 per 2 MACs); IEEE half -> two
+// v_fma_mix_f32 (the f16 -> f32 conversion is part of the FMA: 2 per 2 MACs).  The same fp32 FMAs in the same order either way.
+template <typename TT> __device__ inline f32x2_t mac2(u32 w, f32x2_t x, f32x2_t acc);
+template <> __device__ inline f32x2_t mac2<bf16_t>(u32 w, f32x2_t x, f32x2_t acc) { return __builtin_elementwise_fma(up2<bf16_t>(w), x, acc); }
+template <> __device__ inline f32x2_t mac2<f16_t>(u32 w, f32x2_t x, f32x2_t acc) {
+    // (the compiler does not form the mix instruction from fma(fpext(half), ..) on this target: written out)
+    f32x2_t d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d.x) : "v"(w), "v"(x.x), "v"(acc.x));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d.y) : "v"(w), "v"(x.y), "v"(acc.y));
+    return d;
+}
 template <typename TT>
 __device__ inline f32x2_t dot8(const u32x4_t& w, const f32x2_t (&x)[4], f32x2_t acc) {
-    acc = __builtin_elementwise_fma(up2<TT>(w.x), x[0], acc);
-    acc = __builtin_elementwise_fma(up2<TT>(w.y), x[1], acc);
-    acc = __builtin_elementwise_fma(up2<TT>(w.z), x[2], acc);
-    acc = __builtin_elementwise_fma(up2<TT>(w.w), x[3], acc);
+    acc = mac2<TT>(w.x, x[0], acc);
+    acc = mac2<TT>(w.y, x[1], acc);
+    acc = mac2<TT>(w.z, x[2], acc);
+    acc = mac2<TT>(w.w, x[3], acc);
     return acc;
 }
 // value as the 16-bit K/V cache will hold it, and its raw bits
@@ -174,6 +207,30 @@ __device__ inline void load8p(const float* p, f32x2_t (&o)[4]) {
     const float4 a = *reinterpret_cast<const float4*>(p);
     const float4 b = *reinterpret_cast<const float4*>(p + 4);
     o[0] = f32x2_t{a.x, a.y}; o[1] = f32x2_t{a.z, a.w}; o[2] = f32x2_t{b.x, b.y}; o[3] = f32x2_t{b.z, b.w};
+}
+
+// Attention lane mapping: LPK lanes per key, KPW keys per wave pass; a lane holds 12 of a key's 48 values: 16 bytes + 8 bytes
+#ifndef UMGEN_ENG_KP
+#define UMGEN_ENG_KP 1
+#endif
+#ifndef UMGEN_ENG_NB
+#define UMGEN_ENG_NB 4        // measured (profiles/r03_engine_experiments.txt): 2: 476 us per launch, 3: 476, 4: 471, 5 (15 spilled VGPRs): 504
+#endif
+#ifndef UMGEN_ENG_NB_SYS
+#define UMGEN_ENG_NB_SYS 3    // the systolic kernel keeps more of a layer live: 4 buffers spill 2-4 VGPRs there
+#endif
+constexpr int LPK = 4, KPW = 64 / LPK;
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+struct KVPiece {
+    u32x4_t a;   // dimensions 8 piece .. 8 piece + 7
+    u32x2_t b;   // dimensions 32 + 4 piece .. 32 + 4 piece + 3
+};
+__device__ inline u32x2_t ldwu2(const bf16_t* ubase, u32 off) {
+    return __builtin_nontemporal_load((const UMGEN_GLOBAL u32x2_t*)(ubase + off));
+}
+template <typename TT>
+__device__ inline void unpack12(const KVPiece& w, f32x2_t (&o)[6]) {
+    o[0] = up2<TT>(w.a.x); o[1] = up2<TT>(w.a.y); o[2] = up2<TT>(w.a.z); o[3] = up2<TT>(w.a.w); o[4] = up2<TT>(w.b.x); o[5] = up2<TT>(w.b.y);
 }
 
 // R rows of a [N][768] matrix held by one wave: chunk a[r] = k 8l..8l+7 of row r; the 256 tail columns of rows (2j, 2j+1) are
@@ -211,6 +268,52 @@ __device__ inline void req768_rows(Rows768<R>& w, const bf16_t* W, F rowof, int 
         w.b[j] = KEEP ? *(const UMGEN_GLOBAL u32x4_t*)(base + off) : __builtin_nontemporal_load((const UMGEN_GLOBAL u32x4_t*)(base + off));
     }
 }
+// Transposed wave sums of R rows (R <= 16): a[r] = this lane's partial of row r; returns, in every lane, the wave total of row
+// (lane & 15).  Instead of R independent 6-step DPP reductions (7 R instructions + R selects to put row r into lane r), each step
+// halves the number of live values: a lane keeps the rows whose index bit matches its lane bit and hands the others to its partner
+// (bit 3: row_ror:8, bit 2: row_half_mirror -- BEFORE the quad steps, as it also flips bits 0 / 1 and partners must hold the same row
+// subset -- bit 1 / 0: quad_perm), 3 instructions per row pair; the last two steps add the four 16-lane rows with gfx950's permlane swaps.
+// Lanes whose row index is >= R end with sums of other rows (never read).  Fixed order, the same for every B / D / placement.
+#ifndef UMGEN_ENG_TREDUCE
+#define UMGEN_ENG_TREDUCE 1
+#endif
+template <int CTRL> __device__ inline float dpp_mov(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int N, int R, int CTRL>   // N (power of two) slots of which R hold rows -> N / 2 slots
+__device__ inline void rows_step(float (&v)[16], bool hi) {
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) {
+        if (r + N / 2 < R) {
+            const float keep = hi ? v[r + N / 2] : v[r], send = hi ? v[r] : v[r + N / 2];
+            v[r] = keep + dpp_mov<CTRL>(send);
+        } else if (r < R) {
+            v[r] = v[r] + dpp_mov<CTRL>(v[r]);
+        }
+    }
+}
+__device__ inline float sum_rows16(float v) {   // lane-wise sum of the wave's four 16-lane rows, in every lane
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <int R>
+__device__ inline float rows_sum(const f32x2_t (&acc)[R], int lane) {
+    static_assert(R <= 16, "rows_sum");
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = acc[r].x + acc[r].y;
+    constexpr int R8 = R > 8 ? 8 : R, R4 = R > 4 ? 4 : R, R2 = R > 2 ? 2 : R;
+    if (R > 8) rows_step<16, R, 0x128>(v, (lane & 8) != 0);          // row_ror:8: lane i <-> i ^ 8
+    if (R > 4) rows_step<8, R8, 0x141>(v, (lane & 4) != 0);          // row_half_mirror: i <-> 7 - i (flips bits 0..2: before the quad steps)
+    if (R > 2) rows_step<4, R4, 0x4E>(v, (lane & 2) != 0);           // quad_perm [2,3,0,1]
+    else { v[0] += dpp_mov<0x4E>(v[0]); if (R > 1) v[1] += dpp_mov<0x4E>(v[1]); }
+    if (R > 1) rows_step<2, R2, 0xB1>(v, (lane & 1) != 0);           // quad_perm [1,0,3,2]
+    else v[0] += dpp_mov<0xB1>(v[0]);
+    if (R <= 4) v[0] += dpp_mov<0x124>(v[0]);                        // row_ror:4 (every quad holds the same rows)
+    if (R <= 8) v[0] += dpp_mov<0x128>(v[0]);                        // row_ror:8
+    return sum_rows16(v[0]);
+}
+
 // dot products of rows [R0, R1) only (a pair's shared tail chunk is multiplied by whichever range needs one of its rows)
 template <typename TT, int R, int R0, int R1>
 __device__ inline void dot768_range(const Rows768<R>& w, const f32x2_t (&x1)[4], const f32x2_t (&x2)[4], int lane, float (&out)[R1 - R0]) {
@@ -225,26 +328,58 @@ __device__ inline void dot768_range(const Rows768<R>& w, const f32x2_t (&x1)[4],
         if (2 * j + 1 >= R0 && 2 * j + 1 < R1) acc[2 * j + 1 - R0] += (lane >= 32) ? p : zero;
     }
 #pragma unroll
-    for (int r = 0; r < R1 - R0; ++r) out[r] = wave_sum(acc[r].x + acc[r].y);
+    for (int r = 0; r < R1 - R0; ++r) out[r] = wave_sum(acc[r].x + acc[r].y);      // (only the q-first experiment: one reduction per row)
 }
 
 template <typename TT, int R>
 __device__ inline void dot768(const Rows768<R>& w, const f32x2_t (&x1)[4], const f32x2_t (&x2)[4], int lane, float (&out)[R]) {
     const f32x2_t zero = {0.f, 0.f};
+    // the shared tail chunk of a row pair goes to the lower / upper half-wave's row through a 1 / 0 multiplier: one packed FMA per
+    // row (p x 1 + acc == acc + p exactly) instead of two selects and a packed add
+    const float flo = lane < 32 ? 1.f : 0.f;
+    const f32x2_t mlo = {flo, flo}, mhi = {1.f - flo, 1.f - flo};
     f32x2_t acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = dot8<TT>(w.a[r], x1, zero);
 #pragma unroll
     for (int j = 0; j < (R + 1) / 2; ++j) {
         const f32x2_t p = dot8<TT>(w.b[j], x2, zero);
-        acc[2 * j] += (lane < 32) ? p : zero;
-        if (2 * j + 1 < R) acc[2 * j + 1] += (lane >= 32) ? p : zero;
+        acc[2 * j] = __builtin_elementwise_fma(p, mlo, acc[2 * j]);
+        if (2 * j + 1 < R) acc[2 * j + 1] = __builtin_elementwise_fma(p, mhi, acc[2 * j + 1]);
     }
+    if (UMGEN_ENG_TREDUCE) {
+        const float t = rows_sum<R>(acc, lane);
 #pragma unroll
-    for (int r = 0; r < R; ++r) out[r] = wave_sum(acc[r].x + acc[r].y);
+        for (int r = 0; r < R; ++r) out[r] = t;            // (lane r of every 16 holds row r: the callers pick out[r] in lane r)
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[r] = wave_sum(acc[r].x + acc[r].y);
+    }
 }
 
-// LayerNorm (weight only, eps 1e-5, module.py:26-37) of the 768-vector in LDS, in the lane's dot-product layout
+// wave total in every lane: four fused DPP adds inside the 16-lane rows (quad_perm x 2, row_half_mirror, row_mirror), then the four
+// rows through the permlane swaps -- 10 instructions and no readlane, against 6 DPP steps of mov + add + wait states (common.h wave_sum)
+__device__ inline float wave_max_all(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));       // (bound_ctrl zero fill never applies: these controls are permutations)
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ inline float wave_sum_all(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return sum_rows16(v);
+}
+
+// LayerNorm (weight only, eps 1e-5, module.py:26-37) of the 768-vector in LDS, in the lane's dot-product layout.  1 / 768 as a
+// multiplication and the hardware's reciprocal square root (1 ulp): the IEEE division / square-root sequences were ~50 dependent
+// instructions on every wave's critical path, twice per layer
 __device__ inline void ln768(const float* xs, const float* lnw, int lane, f32x2_t (&x1)[4], f32x2_t (&x2)[4]) {
     f32x2_t l1[4], l2[4];
     load8p(lnw + lane * 8, l1);
@@ -255,7 +390,7 @@ __device__ inline void ln768(const float* xs, const float* lnw, int lane, f32x2_
     f32x2_t s2 = (x2[0] + x2[1]) + (x2[2] + x2[3]);
     float s = s1.x + s1.y;
     s += (lane < 32) ? (s2.x + s2.y) : 0.f;
-    const float mean = wave_sum(s) / (float)E;
+    const float mean = wave_sum_all(s) * (1.0f / (float)E);
     const f32x2_t mean2 = {mean, mean};
     f32x2_t q1 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
@@ -264,7 +399,7 @@ __device__ inline void ln768(const float* xs, const float* lnw, int lane, f32x2_
     for (int e = 0; e < 4; ++e) { const f32x2_t d = x2[e] - mean2; q2 = __builtin_elementwise_fma(d, d, q2); }
     float q = q1.x + q1.y;
     q += (lane < 32) ? (q2.x + q2.y) : 0.f;
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(wave_sum_all(q), 1.0f / (float)E, 1e-5f));
     const f32x2_t rstd2 = {rstd, rstd};
 #pragma unroll
     for (int e = 0; e < 4; ++e) { x1[e] = (x1[e] - mean2) * rstd2 * l1[e]; x2[e] = (x2[e] - mean2) * rstd2 * l2[e]; }
@@ -273,14 +408,17 @@ __device__ inline void ln768(const float* xs, const float* lnw, int lane, f32x2_
 
 }  // namespace
 
-// systolic schedule: which matrices stay in registers over the scenes of a layer (the others are requested again by every item)
-// (measured with -Rpass-analysis=kernel-resource-usage: the 512-thread kernel sits at 254 of 256 VGPRs; keeping the c_proj rows costs 8
-//  spilled VGPRs, the c_fc rows 58, both 77 -- the rows the compiler cannot hold are then reloaded from scratch memory every item)
+// systolic schedule: which matrices stay in registers over the scenes of a layer (the others are requested again by every item).
+// Round 3 history (-Rpass-analysis=kernel-resource-usage): with the 8-lane attention and the one-row-per-thread mlp phase the kernel sat
+// at 254 of 256 VGPRs and keeping the c_proj rows cost 8 spilled VGPRs, the c_fc rows 58, both 77 (slower than re-requesting them).
+// With 12-VGPR K/V pieces and the four-rows-per-four-lanes mlp phase both fit (252 VGPRs, no spill, 3 K/V buffers): a layer's c_proj,
+// c_fc and parked mlp rows are requested ONCE per step; only the q|k|v rows (3.5 MB, out of this XCD's L2 after the first scene)
+// are requested per item.  8 scenes: 961 -> 739 us per launch, 16 scenes: 1916 -> 1377 (profiles/r03_systolic.txt).
 #ifndef UMGEN_SYS_KEEP_WO
-#define UMGEN_SYS_KEEP_WO 0
+#define UMGEN_SYS_KEEP_WO 1
 #endif
 #ifndef UMGEN_SYS_KEEP_WF
-#define UMGEN_SYS_KEEP_WF 0
+#define UMGEN_SYS_KEEP_WF 1
 #endif
 constexpr bool kSysKeepWo = UMGEN_SYS_KEEP_WO, kSysKeepWf = UMGEN_SYS_KEEP_WF;
 // q rows first: every wave owns 3 q, 3 k and 3 v rows (instead of 9 consecutive rows of the packed c_attn matrix), computes and
@@ -354,14 +492,36 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
     Rows768<RF> wf;
 
     // items of this group in the order it works through them: (round rd, layer l) -- scene rd * R + pipe.
-    //   !SYS: rounds outside, this pipeline's layers (q, q + D, ...) inside;  SYS: layers outside, every scene of the batch inside
+    //   !SYS: rounds outside, this pipeline's layers (q, q + D, ...) inside;
+    //    SYS: layers outside, every scene of the batch inside.  The layers that do not fill a whole round of the D groups (36 = 4 x 8 + 4)
+    //         are SHARED: with `rem` such layers, D / rem groups hold layer D n_full + q % rem each and take B rem / D of the scenes
+    //         (36 layers: groups g and g + 4 both keep layer 32 + g, one for the first half of the batch, one for the second), so
+    //         that every group works through 4.5 B items instead of 5 B / 4 B (the step was as long as the 5 B groups' work)
     const int n_lay = (a.n_layers - q + D - 1) / D;
-    const int n_items = n_lay > 0 ? n_lay * rounds : 0;
+    int n_items = n_lay > 0 ? n_lay * rounds : 0;
+    int n_full = 0, tail_l = -1, ts0 = 0, ts1 = 0;
+    if (SYS) {
+        n_full = a.n_layers / D;
+        const int rem = a.n_layers - n_full * D;
+        if (rem > 0) {
+            if (D % rem == 0) {
+                const int share = D / rem, part = q / rem;
+                tail_l = n_full * D + q % rem;
+                ts0 = part * a.B / share;
+                ts1 = (part + 1) * a.B / share;
+            } else if (q < rem) {
+                tail_l = n_full * D + q;
+                ts1 = a.B;
+            }
+        }
+        n_items = n_full * a.B + (ts1 - ts0);
+    }
     for (int item = 0; item < n_items; ++item) {
-        const int rd = SYS ? item % rounds : item / n_lay;
-        const int l = q + D * (SYS ? item / rounds : item % n_lay);
+        const bool tail = SYS && item >= n_full * a.B;
+        const int rd = SYS ? (tail ? ts0 + item - n_full * a.B : item % a.B) : item / n_lay;
+        const int l = SYS ? (tail ? tail_l : q + D * (item / a.B)) : q + D * (item % n_lay);
         const int s = rd * R + pipe;
-        const bool load_w = !SYS || rd == 0;          // this item requests the layer's weights
+        const bool load_w = !SYS || rd == (tail ? ts0 : 0);          // this item requests the layer's weights
         if (s >= a.B) continue;
         {
             // Launch-time stagger: every group would request its first layer's 14 MB at kernel entry -- 114 MB at once, HBM-bound, and
@@ -442,16 +602,15 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 req768(wf, lw.Wfc, rowf, lane);
                 if (STAMPS && timer && first_item) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a.stamps[13] += wall_clock64() - t_k0; }
             }
-            // attention geometry of this CU: head hh, half of the L + 1 keys, split in 8 wave spans of 8-key passes
+            // attention geometry of this CU: head hh, half of the L + 1 keys, split in 8 wave spans of 16-key passes (4 lanes per key)
             const int hh = w >> 1, half = w & 1;
             const int nk = kQFirst ? Lk : Lk + 1;     // keys of the spans: the cached ones (the new token's own key is merged behind them) / all
-            const int n0 = min(nk, (((nk + 1) >> 1) + 7) & ~7);
+            const int n0 = min(nk, (((nk + 1) >> 1) + KPW - 1) & ~(KPW - 1));
             const int ka = half ? n0 : 0, kb = half ? nk : n0;
-            const int span = ((((kb - ka) + NW - 1) / NW) + 7) & ~7;
+            const int span = ((((kb - ka) + NW - 1) / NW) + KPW - 1) & ~(KPW - 1);
             const int k_lo = ka + wave * span;
             int k_hi = min(kb, k_lo + span);
-            const int piece = lane & 7, kg = lane >> 3;
-            const bool pact = piece < 6;
+            const int piece = lane & (LPK - 1), kg = lane / LPK;
             const bf16_t* kbase = a.kvcache + (long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride + (long)hh * a.Lmax * kHeadDim;
             const bf16_t* vbase = kbase + (long)H * a.Lmax * kHeadDim;
             // With D > 1 this group now waits for the other groups: pull this CU's share of the cached K / V rows (two contiguous
@@ -470,24 +629,6 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     touched ^= *(const UMGEN_GLOBAL u32*)(v0p + ((long)ln << 7));
                 }
             }
-            // 16 more keys of this wave's span (behind the 32 that the two register buffers take) go straight into its LDS strip: 4 LDS-DMA
-            // instructions, 3 KB, issued HERE -- in front of the idle wait -- because the compiler drains every load in flight
-            // (s_waitcnt vmcnt(0)) in front of the first LDS read behind an LDS-DMA.  With the two register buffers alone every later
-            // 16-key chunk waited ~0.3 us of an L2 round trip behind 0.3 us of work (attention 3.55 us at L = 1100).  Not where no idle
-            // wait follows (a launch's first item, a busy systolic group): there the drain would be the whole weight stream.
-            const bool staged = kStageKeys != 0 && !SYS && D > 1 && l != 0 && k_lo + 32 < k_hi;
-            float* kvs = lds + L_KV + wave * 768;
-            if (staged) {
-                const u32 eoff = (u32)(k_lo + 32) * (u32)kHeadDim + (u32)lane * 8u;   // element offset of this lane's 16 bytes
-                typedef __attribute__((address_space(3))) void* lds_ptr;
-                __builtin_amdgcn_global_load_lds((const UMGEN_GLOBAL void*)(kbase + eoff), (lds_ptr)kvs, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const UMGEN_GLOBAL void*)(vbase + eoff), (lds_ptr)(kvs + 384), 16, 0, 0);
-                if (lane < 32) {   // keys 10.67 .. 16 of the strip: the second half-kilobyte
-                    __builtin_amdgcn_global_load_lds((const UMGEN_GLOBAL void*)(kbase + eoff + 512), (lds_ptr)(kvs + 256), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const UMGEN_GLOBAL void*)(vbase + eoff + 512), (lds_ptr)(kvs + 384 + 256), 16, 0, 0);
-                }
-            }
-            const int kst = staged ? kStageKeys : 0;
             stamp(-1);
             // ================= P1: x -> LN -> q | k | v =================
             float* lnw = lds + L_LN;
@@ -502,29 +643,22 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             } else {
                 gather<2>(c, tid, D == 1 ? gxl : a.gx + (long)s * E, E, tg + 0, xs);   // (ends with the workgroup barrier)
             }
-            if (kStageKeys && !SYS) {
-                // the compiler drains every load in flight in front of the first LDS read behind an LDS-DMA: take that wait HERE, where
-                // everything has landed during the idle wait, and not in front of the LayerNorm's LDS reads behind the K/V requests below
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (expcnt / lgkmcnt untouched), as an instruction the wait-count pass models
-            }
             stamp(0);   // waited for x
-#ifndef UMGEN_ENG_NB
-#define UMGEN_ENG_NB 2
-#endif
-            // 8-key passes per register buffer, buffers (NB * KP * 8 keys of a wave in flight).  NB = 3 costs 30 spilled VGPRs whose
-            // reloads (s_waitcnt vmcnt(0)) also wait for every request in flight; with the K/V rows already in the L2 two suffice
-            constexpr int KP = 2, NB = UMGEN_ENG_NB;
-            u32x4_t kc[NB][KP], vc[NB][KP];
+            // 16-key passes per register buffer, buffers (NB * KP * 16 keys of a wave in flight; a key's 96 bytes over 4 lanes: 16 + 8 each)
+            constexpr int KP = UMGEN_ENG_KP, NB = SYS ? UMGEN_ENG_NB_SYS : UMGEN_ENG_NB;
+            KVPiece kc[NB][KP], vc[NB][KP];
             auto kv_req = [&](int buf, int k0) {
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
-                    const u32 off = (u32)min(k0 + 8 * i + kg, a.Lmax - 1) * (u32)kHeadDim + (u32)piece * 8u;
-                    if (pact) { kc[buf][i] = ldwu(kbase, off); vc[buf][i] = ldwu(vbase, off); }
-                    else { kc[buf][i] = u32x4_t{0, 0, 0, 0}; vc[buf][i] = u32x4_t{0, 0, 0, 0}; }
+                    const u32 off = (u32)min(k0 + KPW * i + kg, a.Lmax - 1) * (u32)kHeadDim;
+                    kc[buf][i].a = ldwu(kbase, off + (u32)piece * 8u);
+                    kc[buf][i].b = ldwu2(kbase, off + 32u + (u32)piece * 4u);
+                    vc[buf][i].a = ldwu(vbase, off + (u32)piece * 8u);
+                    vc[buf][i].b = ldwu2(vbase, off + 32u + (u32)piece * 4u);
                 }
             };
             if (k_lo < k_hi) kv_req(0, k_lo);
-            if (k_lo + 8 * KP < k_hi) kv_req(1, k_lo + 8 * KP);
+            if (NB > 1 && k_lo + KPW * KP < k_hi) kv_req(NB > 1 ? 1 : 0, k_lo + KPW * KP);
             {
                 f32x2_t x1[4], x2[4];
                 ln768(xs, lnw, lane, x1, x2);
@@ -556,7 +690,9 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     }
                 }
             }
-            if (NB > 2 && k_lo + 16 * KP < k_hi) kv_req(NB > 2 ? 2 : 0, k_lo + 16 * KP);   // (the q|k|v rows' registers are free now)
+#pragma unroll
+            for (int bfr = 2; bfr < NB; ++bfr)     // (the q|k|v rows' registers are free now: these fly while q | k | v are exchanged)
+                if (k_lo + bfr * KPW * KP < k_hi) kv_req(bfr, k_lo + bfr * KPW * KP);
             stamp(1);   // LN + q|k|v rows
             // (never true for bf16 K/V bit patterns XORed; keeps the L2 touch loads alive.  Consumed HERE, not before P1: a wave's loads return
             //  in order, so on a launch's first item the touches arrive behind the whole weight stream -- P1 waited 6.6 us for them)
@@ -567,47 +703,45 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 float* qs = lds + L_QKV;
                 // values [lo, hi) of q_h | k_h | v_h (48 each) of this CU's head out of the group's q | k | v granules
                 auto poll_head = [&](int lo, int hi) {
-                    if (!c.failed) {
-                        const int src = (tid / kHeadDim) * E + hh * kHeadDim + tid % kHeadDim;
-                        const bool mine = tid >= lo && tid < hi;
-                        for (u32 spins = 0;;) {
-                            bool ok = true;
-                            u64 v = 0;
-                            if (mine) { v = get(gqkv, (u32)src); ok = (u32)(v >> 32) == tg + 1; }
-                            if (ok && mine) qs[tid] = __uint_as_float((u32)v);
-                            if (!__any(!ok)) break;
-                            if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, (tg + 1) | 0x80000000u); c.failed = true; break; }
-                            if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
-                        }
-                    }
+                    const u32 src = (u32)((min(tid, 3 * kHeadDim - 1) / kHeadDim) * E + hh * kHeadDim + tid % kHeadDim);
+                    poll_granules<1>(c, tid, gqkv, (tid >= lo && tid < hi) ? 1u : 0u, [&](int) { return src; }, tg + 1, qs);
                     wg_barrier();
                 };
                 poll_head(0, kQFirst ? kHeadDim : 3 * kHeadDim);
                 stamp(2);   // waited for q_h (| k_h | v_h)
-                float q8[8];   // this lane's piece of q
+                // this lane's 12 of the head's 48 dimensions: 8 piece .. 8 piece + 7 and 32 + 4 piece .. + 3, as 6 packed pairs
+                auto dim_of = [&](int j) { return j < 4 ? piece * 8 + 2 * j : 32 + piece * 4 + 2 * (j - 4); };
+                auto own16 = [&](const float* src, f32x2_t (&o)[6]) {   // the new token's own k / v, as the cache will hold it (16 bits)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) q8[e] = pact ? qs[piece * 8 + e] : 0.f;
-                float m_run = -INFINITY, l_run = 0.f, o8[8];
+                    for (int j = 0; j < 6; ++j) o[j] = f32x2_t{round16<TT>(src[dim_of(j)]), round16<TT>(src[dim_of(j) + 1])};
+                };
+                f32x2_t q2[6];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o8[e] = 0.f;
-                auto chunk = [&](const u32x4_t (&kcb)[KP], const u32x4_t (&vcb)[KP], int k0) {
+                for (int j = 0; j < 6; ++j) q2[j] = f32x2_t{qs[dim_of(j)], qs[dim_of(j) + 1]};
+                float m_run = -INFINITY, l_run = 0.f;
+                f32x2_t o2[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) o2[j] = f32x2_t{0.f, 0.f};
+                auto chunk = [&](const KVPiece (&kcb)[KP], const KVPiece (&vcb)[KP], int k0) {
                     float sc[KP];
                     float mc = -INFINITY;
 #pragma unroll
                     for (int i = 0; i < KP; ++i) {
-                        const int k = k0 + 8 * i + kg;
-                        float kf[8];
-                        unpack8<TT>(kcb[i], kf);
-                        if (k == Lk) {   // the new token's own k, as the cache will hold it (bf16)
+                        const int k = k0 + KPW * i + kg;
+                        const u32 kw[6] = {kcb[i].a.x, kcb[i].a.y, kcb[i].a.z, kcb[i].a.w, kcb[i].b.x, kcb[i].b.y};
+                        f32x2_t acc = {0.f, 0.f};
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) kf[e] = pact ? round16<TT>(qs[kHeadDim + piece * 8 + e]) : 0.f;
+                        for (int j = 0; j < 6; ++j) acc = mac2<TT>(kw[j], q2[j], acc);
+                        if (k == Lk) {   // the new token's own key is not in the cache yet: from the head's q | k | v exchange
+                            f32x2_t kf[6];
+                            own16(qs + kHeadDim, kf);
+                            acc = f32x2_t{0.f, 0.f};
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) acc = __builtin_elementwise_fma(kf[j], q2[j], acc);
                         }
-                        float d = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) d = fmaf(q8[e], kf[e], d);
+                        float d = acc.x + acc.y;
                         d += dpp_xor1(d);
                         d += dpp_xor2(d);
-                        d += dpp_half_mirror(d);
                         d = (k < k_hi) ? d * kScaleQK : -INFINITY;
                         sc[i] = d;
                         mc = fmaxf(mc, d);
@@ -615,51 +749,40 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     const float m_new = fmaxf(m_run, mc);
                     if (m_new > -INFINITY) {
                         const float scale = __expf(m_run - m_new);   // exp(-inf) = 0 on the first chunk
+                        const f32x2_t scale2 = {scale, scale};
                         l_run *= scale;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o8[e] *= scale;
+                        for (int j = 0; j < 6; ++j) o2[j] *= scale2;
 #pragma unroll
                         for (int i = 0; i < KP; ++i) {
-                            const int k = k0 + 8 * i + kg;
-                            float vf[8];
-                            unpack8<TT>(vcb[i], vf);
-                            if (k == Lk) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) vf[e] = pact ? round16<TT>(qs[2 * kHeadDim + piece * 8 + e]) : 0.f;
-                            }
+                            const int k = k0 + KPW * i + kg;
+                            const u32 vw[6] = {vcb[i].a.x, vcb[i].a.y, vcb[i].a.z, vcb[i].a.w, vcb[i].b.x, vcb[i].b.y};
                             const float p = __expf(sc[i] - m_new);
+                            const f32x2_t p2 = {p, p};
                             l_run += p;
+                            if (k == Lk) {
+                                f32x2_t vf[6];
+                                own16(qs + 2 * kHeadDim, vf);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) o8[e] = fmaf(p, vf[e], o8[e]);
+                                for (int j = 0; j < 6; ++j) o2[j] = __builtin_elementwise_fma(p2, vf[j], o2[j]);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 6; ++j) o2[j] = mac2<TT>(vw[j], p2, o2[j]);
+                            }
                         }
                         m_run = m_new;
                     }
                 };
-                // chunks of 8 KP keys in NB register buffers, all requested before q|k|v were exchanged; a buffer is requested again as
+                // chunks of KPW * KP keys in NB register buffers, all requested before q|k|v were exchanged; a buffer is requested again as
                 // soon as it has been consumed
-                for (int k0 = k_lo; k0 < k_hi; k0 += 8 * KP * NB) {
-                    if (k0 == k_lo + 8 * KP * NB && kst) {
-                        // the staged keys sit between the first round of the register buffers and their reloads
-                        u32x4_t kl[KP], vl[KP];
+                constexpr int CK = KPW * KP;
+                for (int k0 = k_lo; k0 < k_hi; k0 += CK * NB) {
 #pragma unroll
-                        for (int i = 0; i < KP; ++i) {
-                            const float* kr = kvs + (8 * i + kg) * 24 + piece * 4;       // key j of the strip: 96 bytes at 24 floats
-                            kl[i] = pact ? *reinterpret_cast<const u32x4_t*>(kr) : u32x4_t{0, 0, 0, 0};
-                            vl[i] = pact ? *reinterpret_cast<const u32x4_t*>(kr + 384) : u32x4_t{0, 0, 0, 0};
+                    for (int bfr = 0; bfr < NB; ++bfr) {
+                        if (k0 + CK * bfr < k_hi) {
+                            chunk(kc[bfr], vc[bfr], k0 + CK * bfr);
+                            if (k0 + CK * (NB + bfr) < k_hi) kv_req(bfr, k0 + CK * (NB + bfr));
                         }
-                        chunk(kl, vl, k0);
-                        k0 += kst;
-                        if (k0 >= k_hi) break;
-                    }
-                    chunk(kc[0], vc[0], k0);
-                    if (k0 + 8 * KP * NB + (k0 == k_lo ? kst : 0) < k_hi) kv_req(0, k0 + 8 * KP * NB + (k0 == k_lo ? kst : 0));
-                    if (k0 + 8 * KP < k_hi) {
-                        chunk(kc[1], vc[1], k0 + 8 * KP);
-                        if (k0 + 8 * KP * (NB + 1) + (k0 == k_lo ? kst : 0) < k_hi) kv_req(1, k0 + 8 * KP * (NB + 1) + (k0 == k_lo ? kst : 0));
-                    }
-                    if (NB > 2 && k0 + 16 * KP < k_hi) {
-                        chunk(kc[NB > 2 ? 2 : 0], vc[NB > 2 ? 2 : 0], k0 + 16 * KP);
-                        if (k0 + 8 * KP * (NB + 2) < k_hi) kv_req(NB > 2 ? 2 : 0, k0 + 8 * KP * (NB + 2));
                     }
                 }
                 if (kQFirst) {
@@ -668,29 +791,51 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     poll_head(kHeadDim, 3 * kHeadDim);
                     if (half == 1 && wave == NW - 1) {
                         k_hi = Lk + 1;
-                        u32x4_t kz[KP], vz[KP];
+                        KVPiece kz[KP], vz[KP];
 #pragma unroll
-                        for (int i = 0; i < KP; ++i) { kz[i] = u32x4_t{0, 0, 0, 0}; vz[i] = u32x4_t{0, 0, 0, 0}; }
+                        for (int i = 0; i < KP; ++i) { kz[i] = KVPiece{u32x4_t{0, 0, 0, 0}, u32x2_t{0, 0}}; vz[i] = kz[i]; }
                         chunk(kz, vz, Lk);
                     }
                 }
-                // 64 lane-group partials of this CU -> LDS -> one half partial (m, l, o[48]) published by wave 0
+                // the wave's 16 lane groups fold to 8 (group kg + 8 into group kg: lanes l + 32 into l, fixed order), then the 64 partials
+                // of this CU -> LDS -> one half partial (m, l, o[48]) published by wave 0
+                {
+                    // v_permlane32_swap of a value with itself: (the lower half-wave's values, the upper half-wave's) in every lane
+                    auto halves = [](float v, float& lo, float& hi) {
+                        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                        lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+                    };
+                    float m_a, m_b, l_a, l_b;
+                    halves(m_run, m_a, m_b);
+                    halves(l_run, l_a, l_b);
+                    const float M2 = fmaxf(m_a, m_b);
+                    const float e_a = (M2 > -INFINITY) ? __expf(m_a - M2) : 0.f, e_b = (M2 > -INFINITY) ? __expf(m_b - M2) : 0.f;
+                    l_run = fmaf(e_b, l_b, e_a * l_a);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        float xa, xb2, ya, yb;
+                        halves(o2[j].x, xa, xb2);
+                        halves(o2[j].y, ya, yb);
+                        o2[j] = f32x2_t{fmaf(e_b, xb2, e_a * xa), fmaf(e_b, yb, e_a * ya)};
+                    }
+                    m_run = M2;
+                }
                 float* sm = lds + L_SM;
                 float* so = lds + L_SO;
-                const int gi = wave * 8 + kg;
-                if (piece == 0) { sm[gi] = m_run; sm[64 + gi] = l_run; }
-                if (pact) {
+                const int gi = wave * 8 + (kg & 7);
+                if (lane < 32) {
+                    if (piece == 0) { sm[gi] = m_run; sm[64 + gi] = l_run; }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) so[gi * kHeadDim + piece * 8 + e] = o8[e];
+                    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2_t*>(so + gi * kHeadDim + dim_of(j)) = o2[j];
                 }
                 wg_barrier();
                 {
                     // every wave recomputes the 64 merge weights (cheap), then thread (jg, d) folds 8 of the 64 partial rows of
                     // column d; 48 threads add the 8 folds in a fixed order and publish the half partial (m, l, o[48])
                     const float mg = sm[lane];
-                    const float M = wave_max(mg);
+                    const float M = wave_max_all(mg);
                     const float wg = (M > -INFINITY) ? __expf(mg - M) : 0.f;
-                    const float Ls = wave_sum(wg * sm[64 + lane]);
+                    const float Ls = wave_sum_all(wg * sm[64 + lane]);
                     float* fold = lds + L_HS;   // (the MLP's strip: free until P4 -- so no barrier is needed between the folds' readers and P3's gather)
                     if (tid < 8 * kHeadDim) {
                         const int jg = tid / kHeadDim, d = tid % kHeadDim;
@@ -727,9 +872,9 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     const float* p1 = p0 + 50;
                     const float m0 = p0[48], m1 = p1[48];
                     const float M = fmaxf(m0, m1);
-                    const float e0 = (m0 > -INFINITY) ? expf(m0 - M) : 0.f, e1 = (m1 > -INFINITY) ? expf(m1 - M) : 0.f;
+                    const float e0 = (m0 > -INFINITY) ? __expf(m0 - M) : 0.f, e1 = (m1 > -INFINITY) ? __expf(m1 - M) : 0.f;
                     const float Ls = fmaf(e1, p1[49], e0 * p0[49]);
-                    as[col] = fmaf(e1, p1[d], e0 * p0[d]) / Ls;
+                    as[col] = fmaf(e1, p1[d], e0 * p0[d]) * __builtin_amdgcn_rcpf(Ls);
                 }
                 wg_barrier();
                 f32x2_t x1[4], x2[4];
@@ -765,66 +910,76 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             wg_barrier();
             stamp(11);  // LN + c_fc rows + GELU
             {
-                // thread t: all 96 columns of output row t (units 0..11, parked in LDS) + half of the columns of row 512 + (t & 255)
-                // (units 12..17: columns 48 (t >> 8) .. +47); every lane reads the same h values (LDS broadcast)
+                // this CU's partial sums of the 768 mlp c_proj outputs over its 96 hidden units.  Four lanes share four rows: thread t
+                // multiplies rows 4 (t / 4) .. + 3 by columns 24 (t % 4) .. + 23 (units 0..11, parked in LDS) and -- eight lanes per four
+                // rows -- rows 512 + 4 (t / 8) .. + 3 by columns 12 (t % 8) .. + 11 (units 12..17); transposed quad sums leave row t's
+                // total in thread t.  (Round 2: thread t = all 96 columns of row t.  Every lane then read all 96 h values -- 36
+                // broadcast ds_read_b128 per wave, 8 clocks each whatever the addresses: ~1 us of LDS time per item; now 9.)
                 const f32x2_t zero = {0.f, 0.f};
-                f32x2_t accA = zero, accB = zero;
+                float ya[16], yb[16];
+                {
+                    f32x2_t hq[3][4];
 #pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    f32x2_t xv[4];
-                    load8p(hsl + 8 * j, xv);
-                    accA = dot8<TT>(w2p[j * NT], xv, accA);
-                    // SYS keeps the c_proj / c_fc rows (92 VGPRs) live through this phase: stop the scheduler from hoisting all 36 LDS
-                    // reads (144 VGPRs) to the front, which pushed those rows out to scratch memory
-                    if (SYS && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-                const int cb = 6 * (tid >> 8);
+                    for (int cc = 0; cc < 3; ++cc) load8p(hsl + 24 * (tid & 3) + 8 * cc, hq[cc]);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    f32x2_t xv[4];
-                    load8p(hsl + 8 * (cb + j), xv);
-                    accB = dot8<TT>(wpl[j], xv, accB);
+                    for (int r = 0; r < 4; ++r) {
+                        f32x2_t acc = zero;
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) acc = dot8<TT>(w2p[(3 * r + cc) * NT], hq[cc], acc);
+                        ya[r] = acc.x + acc.y;
+                        // SYS keeps the c_proj / c_fc rows (92 VGPRs) live through this phase: stop the scheduler from hoisting all the LDS
+                        // reads to the front, which pushed those rows out to scratch memory
+                        if (SYS) __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                const float yA = accA.x + accA.y;
-                float yB = accB.x + accB.y;
-                if (tid >= 256) hrow[tid - 256] = yB;
-                wg_barrier();
+                {
+                    f32x2_t h2[6], wv[24];
+                    const float4* hp = reinterpret_cast<const float4*>(hsl + 12 * (tid & 7));
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { const float4 v = hp[i]; h2[2 * i] = f32x2_t{v.x, v.y}; h2[2 * i + 1] = f32x2_t{v.z, v.w}; }
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        wv[4 * j] = up2<TT>(wpl[j].x); wv[4 * j + 1] = up2<TT>(wpl[j].y); wv[4 * j + 2] = up2<TT>(wpl[j].z); wv[4 * j + 3] = up2<TT>(wpl[j].w);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        f32x2_t acc = zero;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) acc = __builtin_elementwise_fma(wv[6 * r + i], h2[i], acc);
+                        yb[r] = acc.x + acc.y;
+                    }
+                }
+                rows_step<4, 4, 0x4E>(ya, (tid & 2) != 0);
+                rows_step<2, 2, 0xB1>(ya, (tid & 1) != 0);
+                rows_step<4, 4, 0x4E>(yb, (tid & 2) != 0);
+                rows_step<2, 2, 0xB1>(yb, (tid & 1) != 0);
+                const float yB = yb[0] + dpp_mov<0x104>(yb[0]);     // row_shl:4: lane i + 4 (same row of the group's other four lanes)
                 u64* mine = gpy + (long)w * E;
-                put_local(mine, (u32)tid, tg + 4, yA);
-                if (tid < 256) put_local(mine, 512u + (u32)tid, tg + 4, yB + hrow[tid]);
+                put_local(mine, (u32)tid, tg + 4, ya[0]);
+                if ((tid & 7) < 4) put_local(mine, 512u + 4u * (u32)(tid >> 3) + (u32)(tid & 7), tg + 4, yB);
             }
             stamp(7);   // LN + c_fc rows + partial sums
             // ================= P5: the 32 partial sums of this CU's 24 rows -> x'' (next layer's x) =================
-            if (!c.failed) {
-                // producer p's partials of rows 24 w .. 24 w + 23 sit at gpy[p * 768 + 24 w + r]: 768 granules in 32 runs of 192 B
-                u32 got = 0;
-                const u32 need = (tid < 256) ? 3u : 1u;
-                for (u32 spins = 0;;) {
-                    u64 v[2];
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (((need & ~got) >> k) & 1u) { const u32 i = (u32)tid + (u32)(k * NT); v[k] = get(gpy + 24 * w, (i / 24u) * (u32)E + i % 24u); }
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (((need & ~got) >> k) & 1u) {
-                            if ((u32)(v[k] >> 32) == tg + 4) { part[tid + k * NT] = __uint_as_float((u32)v[k]); got |= 1u << k; }
-                        }
-                    if (!__any(got != need)) break;
-                    if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, (tg + 4) | 0x80000000u); c.failed = true; break; }
-                    if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
-                }
-            }
+            // producer p's partials of rows 24 w .. 24 w + 23 sit at gpy[p * 768 + 24 w + r]: 768 granules in 32 runs of 192 B
+            poll_granules<2>(c, tid, gpy + 24 * w, (tid < 256) ? 3u : 1u,
+                             [&](int k) { const u32 i = (u32)min(tid + k * NT, E - 1); return (i / 24u) * (u32)E + i % 24u; }, tg + 4, part);
             wg_barrier();
             stamp(8);   // waited for the partial sums
-            if (tid < 24) {
+            if (tid < 96) {
+                // row tid / 4: four lanes add 8 producers each (producer 8 j, ..., 8 j + 7), then the quad (fixed order)
+                const int row = tid >> 2, j8 = (tid & 3) * 8;
                 float sum = 0.f;
 #pragma unroll
-                for (int p = 0; p < CU; ++p) sum += part[p * 24 + tid];      // fixed order: producer 0, 1, ..., 31
-                const int n = 24 * w + tid;
+                for (int p = 0; p < 8; ++p) sum += part[(j8 + p) * 24 + row];
+                sum += dpp_xor1(sum);
+                sum += dpp_xor2(sum);
+                const int n = 24 * w + row;
                 const float xn = xb[n] + sum;
+                if ((tid & 3) == 0) {
                 if (l + 1 == a.n_layers) (a.xdec + (long)s * E)[(u32)n] = xn;
                 else if (D == 1) put_local(gxl, (u32)n, tg + 8, xn);
                 else put_far(a.gx + (long)s * E, (u32)n, tg + 8, xn);
+                }
             }
             stamp(9);   // mlp c_proj rows
             if (STAMPS && timer) a.stamps[10] += 1;

@@ -170,10 +170,13 @@ class Mapdecoder:
     """decode_map.py:110-148: map tokens [1, T, 1024] (or [T, 1024]) -> reconstructions [T, 5, 256, 256] (``decode_maps`` of the
     reference additionally projects them to RGB with a seeded random 1x1 conv for visualisation: ``to_rgb`` below)."""
 
-    def __init__(self, state_dict=None, device: int = 0, cfg: dict = MAP_VQ):
+    def __init__(self, ckpt=None, device: int = 0, cfg: dict = MAP_VQ):
         self.dec = VQDecoder(cfg, device=device)
-        if state_dict is not None:
-            self.dec.load_state_dict(state_dict)
+        sd = _state_dict_of(ckpt)
+        if sd is not None:
+            missing, _ = self.dec.load_state_dict(sd)
+            if missing:
+                raise VQError(f"map VQ checkpoint lacks {len(missing)} decoder tensors, e.g. {missing[:3]}")
 
     def decode_maps(self, map_tokens, H: int = 32, W: int = 32, rgb: bool = True) -> np.ndarray:
         t = np.asarray(map_tokens)
@@ -187,10 +190,13 @@ class Mapdecoder:
 class Imagedecoder:
     """decode_map.py:151-183: image tokens [1, T, 512] -> images [T, 3, 256, 512] in [-1, 1]."""
 
-    def __init__(self, state_dict=None, device: int = 0, cfg: dict = IMAGE_VQ):
+    def __init__(self, ckpt=None, device: int = 0, cfg: dict = IMAGE_VQ):
         self.dec = VQDecoder(cfg, device=device)
-        if state_dict is not None:
-            self.dec.load_state_dict(state_dict)
+        sd = _state_dict_of(ckpt)
+        if sd is not None:
+            missing, _ = self.dec.load_state_dict(sd)
+            if missing:
+                raise VQError(f"image VQ checkpoint lacks {len(missing)} decoder tensors, e.g. {missing[:3]}")
 
     def decode_images(self, image_tokens, H: int = 16, W: int = 32) -> np.ndarray:
         t = np.asarray(image_tokens)
@@ -198,6 +204,19 @@ class Imagedecoder:
             t = t[None]
         t = t.reshape(-1, t.shape[-1]).reshape(-1, H, W)
         return np.concatenate([self.dec.decode_code(t[i:i + 20]) for i in range(0, t.shape[0], 20)])
+
+
+def _state_dict_of(ckpt):
+    """``ckpt``: a path (VQModel.init_from_ckpt, vq_model.py:65-73: ``torch.load(path)["state_dict"]``), a loaded checkpoint dict
+    holding ``state_dict``, or the state dict itself."""
+    if ckpt is None:
+        return None
+    if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
+        import torch
+        ckpt = torch.load(ckpt, map_location="cpu")
+    if hasattr(ckpt, "keys") and "state_dict" in ckpt and not any(str(k).startswith("decoder.") for k in ckpt.keys()):
+        ckpt = ckpt["state_dict"]
+    return ckpt
 
 
 def to_rgb(x: np.ndarray, seed: int = 0) -> np.ndarray:
