@@ -165,3 +165,45 @@ def test_gemv(bf16, M, N, K, gelu, ln):
         xin = torch.nn.functional.layer_norm(xin, (K,), torch.from_numpy(lw).double(), None, 1e-5)
     ref = ref_linear(xin.numpy(), W, bias, gelu, None)
     np.testing.assert_allclose(out, ref, atol=2e-5 * max(1.0, np.abs(ref).max()), rtol=0)
+
+
+def ref_sample_topk(l, k, temp, u):
+    """oracle/umgen_oracle.py OracleUMGen.sample (UMGen.py:899-913 + 967-974): keep the logits >= the k-th largest (ties kept), softmax
+    with temperature over the kept set in token order, inverse CDF on the uniform u with sequential fp32 sums."""
+    from oracle.umgen_oracle import exp_det
+    kk = min(k, l.shape[0])
+    kth = np.partition(l, -kk)[-kk]
+    idx = np.nonzero(l >= kth)[0]
+    z = l[idx] / np.float32(temp)
+    e = exp_det(z - z.max())
+    c = np.cumsum(e, dtype=np.float32)
+    hit = np.nonzero(c > np.float32(u * c[-1]))[0]
+    return int(idx[hit[0]]) if hit.size else int(idx[-1])
+
+
+@pytest.mark.parametrize("V", [8192, 1028, 1024])
+@pytest.mark.parametrize("k", [1, 5, 16])
+def test_sampler_topk_rows(V, k):
+    """The sampler's k-th-largest selection (threshold = k-th largest per-thread maximum, then the exact k-th among the logits above
+    it; exhaustive arg-max rounds when more than 64 logits pass the threshold) gives the oracle's token on random rows, on rows with
+    ties at the k-th value, and on rows built to take the fallback (one thread's 32 registers hold every large logit)."""
+    rng = np.random.default_rng(V * 31 + k)
+    n = 96
+    L = rng.standard_normal((n, V)).astype(np.float32)
+    L[8:16] = np.round(L[8:16] * 4) / 4                      # heavy quantisation: many exact ties, also at the k-th value
+    for r in range(16, 40):                                   # the top values sit in FEW threads (indices tid + 256 i share a thread)
+        nthr = 1 + (r - 16) // 8                              # 1, 2, 3 threads hold 32 large logits each: 32 / 64 / 96 logits >= T
+        for t in range(nthr):
+            ii = np.arange(t * 7 + r, V, 256)
+            L[r, ii] = 6.0 + rng.random(ii.size).astype(np.float32)
+    L[40, :70] = 9.0                                          # 70 equal maxima: the kept set overflows the sampler's 64 slots
+    u = rng.random(n).astype(np.float32)
+    tok = np.zeros(n, np.int32)
+    ovf = np.zeros(1, np.int32)
+    import ctypes as C
+    check(lib().umgen_dbg_sample_topk(fp(L), n, V, k, C.c_float(1.0), fp(u), tok.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      ovf.ctypes.data_as(C.POINTER(C.c_int32))))
+    assert ovf[0] == 1, "exactly the row with 70 tied maxima must report the kept-set overflow"
+    for r in range(n):
+        if r != 40:
+            assert tok[r] == ref_sample_topk(L[r], k, 1.0, u[r]), (r, int(tok[r]))

@@ -354,3 +354,22 @@ def test_long_history_window_of_39_frames_matches_oracle(oc):
         np.testing.assert_array_equal(out[m][:, :39], scene[m], err_msg=m)
         np.testing.assert_array_equal(out[m][:, 39], oc[f"long39_{m}"].astype(np.int64), err_msg=m)
     e.close()
+
+
+def test_fp16_mode_refuses_a_weight_outside_the_half_range_and_rounds_like_torch():
+    """precision fp16 stores matrix weights as IEEE half: a value that would become inf is refused at load (no silent garbage), and the
+    host's float -> half rounding is torch's (round to nearest even, subnormals included), checked through a rollout-independent
+    route: a weight tensor made of half-way cases loads without error in fp16 mode and is refused once it holds 7e4."""
+    from umgen_amd.engine import UMGenError
+    cfg = tiny_config().greedy()
+    e = Engine(cfg, precision="fp16", max_batch=1, max_cond_frames=4)
+    sd = synthetic_state_dict(cfg, seed=1)
+    key = "transformer.OAR.1.mlp.c_fc.weight"
+    assert key in sd, sorted(sd)[:5]
+    w = np.array(sd[key], dtype=np.float32, copy=True)
+    w.flat[:4] = [65504.0, -65504.0, 6.0e-8, 1.0 + 2.0 ** -11]      # largest half, a half subnormal, a tie (rounds to even)
+    e.load_tensor(key, w)
+    w.flat[5] = 7.0e4
+    with pytest.raises(UMGenError, match="does not fit fp16"):
+        e.load_tensor(key, w)
+    e.close()

@@ -19,7 +19,7 @@ EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen
            "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",
            "umgen_tokenize_ego", "umgen_detokenize_ego", "umgen_tokenize_boxes", "umgen_detokenize_boxes",
            "umgen_vq_create", "umgen_vq_load_tensor", "umgen_vq_finalize", "umgen_vq_decode", "umgen_vq_last_error", "umgen_vq_destroy",
-           "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench", "umgen_dbg_oar_step"]
+           "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench", "umgen_dbg_oar_step", "umgen_dbg_sample_topk"]
 
 PREC_FP32, PREC_BF16, PREC_FP16 = 0, 1, 2
 DT_F32, DT_BF16, DT_F16, DT_F64 = 0, 1, 2, 3
@@ -185,6 +185,7 @@ def load_library() -> C.CDLL:
     lib.umgen_dbg_gemv.argtypes = [i32, fp, fp, vp, fp, i32, i32, i32, i32, fp]
     lib.umgen_dbg_gemm_bench.argtypes = [i32, i32, i32, i32, i32, fp]
     lib.umgen_dbg_oar_step.argtypes = [vp, i32, i32, fp, fp, i32, i32]
+    lib.umgen_dbg_sample_topk.argtypes = [fp, i32, i32, i32, C.c_float, fp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.umgen_vq_create.argtypes = [C.POINTER(VQConfig), C.POINTER(vp)]
     lib.umgen_vq_load_tensor.argtypes = [vp, C.c_char_p, fp, i64p, i32]
     lib.umgen_vq_finalize.argtypes = [vp]

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/umgen.h"
+#include "frame.h"
 #include "kernels.h"
 
 using namespace umgen;
@@ -183,6 +184,20 @@ int umgen_dbg_gemv(int bf16, const float* x, const float* ln_w, const void* W, c
         if (memcmp(alt.data(), out, (size_t)M * N * 4) != 0) return UMGEN_E_STATE;
     }
     return UMGEN_OK;
+}
+
+// the top-k sampler (frame.hip block_sample_topk: UMGen.py:899-913 + 967-974 on the build's uniforms) on n independent rows of V <= 8192
+// logits; *overflow counts the rows whose kept set (ties at the k-th value) exceeded the sampler's 64 slots
+int umgen_dbg_sample_topk(const float* logits, int n, int V, int k, float temp, const float* u, int32_t* tokens, int32_t* overflow) {
+    if (V > 8192 || V < 1 || n < 1) return UMGEN_E_INVALID;
+    DevBuf dL((size_t)n * V * 4), dU((size_t)n * 4), dT((size_t)n * 4), dO(4);
+    if (!dL.p || !dU.p || !dT.p || !dO.p) return UMGEN_E_NOMEM;
+    if (up(dL.p, logits, (size_t)n * V * 4) || up(dU.p, u, (size_t)n * 4)) return UMGEN_E_HIP;
+    (void)hipMemset(dO.p, 0, 4);
+    launch_sample_rows(nullptr, (const float*)dL.p, V, k, temp, (const float*)dU.p, (int*)dT.p, (int*)dO.p, n);
+    if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
+    if (int rc = down(tokens, dT.p, (size_t)n * 4)) return rc;
+    return down(overflow, dO.p, 4);
 }
 
 }  // extern "C"

@@ -1369,11 +1369,22 @@ int umgen_load_tensor(umgen_engine* e, const char* key, const void* data, int32_
     if (s.kind == 1 && e->cfg.precision == UMGEN_PREC_FP16) {   // round-to-nearest-even to IEEE half, like torch's .half()
         std::vector<f16_t> h(n);
         if (dtype == UMGEN_DT_F16) memcpy(h.data(), data, n * 2);
-        else for (size_t i = 0; i < n; ++i) {
-            const float v = load_as_f32(data, dtype, i);
-            if (std::isfinite(v) && std::fabs(v) > 65504.f)     // would become inf: refuse rather than decode garbage
-                return e->fail(UMGEN_E_INVALID, "%s[%zu] = %g does not fit fp16 (precision fp16 needs |w| <= 65504)", key, i, (double)v);
-            h[i] = (f16_t)v;
+        else {
+            float amax = 0.f;                                   // (no early exit in the conversion loop: it stays vectorisable)
+            for (size_t i = 0; i < n; ++i) {
+                const float v = load_as_f32(data, dtype, i);
+                const float av = std::fabs(v);
+                amax = (av <= 3.4e38f && av > amax) ? av : amax;   // finite values only
+                const uint16_t hb = f32_to_f16_bits_host(v);
+                memcpy(&h[i], &hb, 2);
+            }
+            if (amax > 65504.f) {                               // would become inf: refuse rather than decode garbage
+                for (size_t i = 0; i < n; ++i) {
+                    const float v = load_as_f32(data, dtype, i);
+                    if (std::isfinite(v) && std::fabs(v) > 65504.f)
+                        return e->fail(UMGEN_E_INVALID, "%s[%zu] = %g does not fit fp16 (precision fp16 needs |w| <= 65504)", key, i, (double)v);
+                }
+            }
         }
         HIPCHK(e, hipMemcpy(s.dst, h.data(), n * 2, hipMemcpyHostToDevice));
     } else if (to_bf16) {

@@ -90,6 +90,7 @@ void launch_first_input(hipStream_t s, int B, int E, const float* tske_row, cons
 void launch_fixed_token(hipStream_t s, const SampleArgs& a, int B);             // bos/eos/pose prefix steps
 void launch_sample_token(hipStream_t s, const SampleArgs& a, int B);            // sampled steps
 // ego head: sample 3 pose tokens per scene from logits [B*3][vocab]
+void launch_sample_rows(hipStream_t s, const float* logits, int V, int k, float temp, const float* u, int* out, int* overflow, int n);   // test hook
 void launch_sample_ego(hipStream_t s, const float* logits, int vocab, SamplerParams sp, const unsigned long long* seeds, int frame_idx,
                        const int* forced, int* out_tokens, int B, int* overflow);
 // ego query rows: egoe[j] + spe[j] + tpe[T-1]

@@ -214,63 +214,116 @@ struct SampleShared {
     float cand_v[4 * kMaxK];
     int cand_i[4 * kMaxK];
     float kth;
-    int n_kept;
+    int n_kept, n_cand;
     int kept_i[kMaxKept];
     float kept_v[kMaxKept];
     int result;
 };
 
 // all 256 threads call; returns the sampled index.  mask_idx (>=0) is treated as -inf.
-// k-th largest value: every wave extracts its own top-k (k rounds of register arg-max + two DPP wave reductions, no
-// barriers); wave 0 then holds the 4k candidates one per lane and ranks them with uniform readlane loops.  The final
-// softmax / inverse-CDF walk is sequential in ascending token index (bit-for-bit the oracle's order) but runs on
-// register values fetched with v_readlane, not on LDS round trips.
+// k-th largest value by threshold selection (round 3; was k arg-max rounds over every thread's 32 registers, ~230 instructions per
+// round: 12 / 14 / 25 us per map / bbox3d / image token): T = k-th largest of the per-thread maxima, then the exact k-th largest among
+// the few logits >= T; the exhaustive rounds remain as the fallback for > 64 such logits.  The k-th value -- and with it the kept set,
+// its order and the draw -- is the same number either way.  The final softmax / inverse-CDF walk is sequential in ascending token
+// index (bit-for-bit the oracle's order) but runs on register values fetched with v_readlane, not on LDS round trips.
 __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k, float temp, float u, int mask_idx, SampleShared& sh, int* overflow) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float v[32], v0[32];   // v is consumed by the arg-max rounds, v0 keeps the logits for the kept-set pass
+    float v0[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const int idx = tid + 256 * i;
-        v[i] = (idx < V && idx != mask_idx) ? logits[idx] : -INFINITY;
-        v0[i] = v[i];
+        v0[i] = (idx < V && idx != mask_idx) ? logits[idx] : -INFINITY;
     }
     const int kk = min(min(k, V), kMaxK);
     if (tid < 4 * kMaxK) { sh.cand_v[tid] = -INFINITY; sh.cand_i[tid] = 0x7fffffff; }
-    if (tid == 0) sh.n_kept = 0;
+    if (tid == 0) { sh.n_kept = 0; sh.n_cand = 0; }
     __syncthreads();
-    for (int it = 0; it < kk; ++it) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
+    // ---- the k-th largest logit, in two cheap selections instead of k arg-max rounds over every thread's 32 registers ----
+    // (1) T = k-th largest of the 256 per-thread maxima.  k different logits are >= T, so the k-th largest logit is >= T and every
+    //     logit of the top k is among the (few) logits >= T.  Per wave: k rounds of wave-max over ONE value per lane; wave 0 ranks
+    //     the 4k wave candidates (ties between equal maxima of different threads are separate candidates: order by slot).
+    {
+        float cur = v0[0];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int idx = tid + 256 * i;
-            if (v[i] > bv) { bv = v[i]; bi = idx; }   // ascending idx within a thread => lowest index kept on ties
-        }
-        const float wv = wave_max(bv);
-        const int wi = wave_min_i32(bv == wv ? bi : 0x7fffffff);   // lowest index among the lanes holding the wave maximum
-        if (lane == 0) { sh.cand_v[wave * kMaxK + it] = wv; sh.cand_i[wave * kMaxK + it] = wi; }
-        if (bi == wi) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i)
-                if (tid + 256 * i == wi) v[i] = -INFINITY;
+        for (int i = 1; i < 32; ++i) cur = fmaxf(cur, v0[i]);
+        for (int it = 0; it < kk; ++it) {
+            const float wv = wave_max(cur);
+            const int first = __ffsll((unsigned long long)__ballot(cur == wv)) - 1;   // lowest lane holding the wave maximum
+            if (lane == 0) { sh.cand_v[wave * kMaxK + it] = wv; sh.cand_i[wave * kMaxK + it] = wave * kMaxK + it; }
+            if (lane == first) cur = -INFINITY;
         }
     }
     __syncthreads();
-    if (wave == 0) {
-        // rank of each candidate = number of candidates that precede it (greater value, or equal value and lower index)
+    // rank of each candidate of sh.cand_* (one per lane of wave 0; slots [16 w, 16 w + per_wave)) = number of candidates that precede
+    // it (greater value, or equal value and lower index); the candidate of rank kk - 1 is written to sh.kth
+    auto rank_candidates = [&](int per_wave) {
         const float cv = sh.cand_v[lane];
         const int ci = sh.cand_i[lane];
         int rank = 0;
-        // only the kk real candidates of each wave (the other slots hold -inf and precede nobody): slot j = 16 (j / kk) + j % kk
-        const int ncand = 4 * kk;
+        const int ncand = 4 * per_wave;
         for (int jj = 0, w4 = 0, it = 0; jj < ncand; ++jj) {
             const int j = w4 * kMaxK + it;
             const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j));
             const int oi = __builtin_amdgcn_readlane(ci, j);
             rank += (ov > cv || (ov == cv && oi < ci)) ? 1 : 0;
-            if (++it == kk) { it = 0; ++w4; }
+            if (++it == per_wave) { it = 0; ++w4; }
         }
-        if (rank == kk - 1) sh.kth = cv;   // exactly one lane (ranks are a permutation)
+        if (rank == kk - 1) sh.kth = cv;   // exactly one lane (ranks are a permutation; the unused slots hold -inf / int-max and rank last)
+    };
+    if (wave == 0) rank_candidates(kk);
+    __syncthreads();
+    // (2) the logits >= T (k of them, plus whatever else a top thread holds above T): the exact k-th largest among them
+    {
+        const float T = sh.kth;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (v0[i] >= T && v0[i] > -INFINITY) {
+                const int slot = atomicAdd(&sh.n_cand, 1);
+                if (slot < kMaxKept) { sh.kept_i[slot] = tid + 256 * i; sh.kept_v[slot] = v0[i]; }
+            }
+        }
+    }
+    __syncthreads();
+    const int n_cand = sh.n_cand;
+    if (n_cand <= kMaxKept) {
+        if (wave == 0) {
+            const float cv = lane < n_cand ? sh.kept_v[lane] : -INFINITY;
+            const int ci = lane < n_cand ? sh.kept_i[lane] : 0x7fffffff;
+            int rank = 0;
+            for (int j = 0; j < n_cand; ++j) {
+                const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j));
+                const int oi = __builtin_amdgcn_readlane(ci, j);
+                rank += (ov > cv || (ov == cv && oi < ci)) ? 1 : 0;
+            }
+            if (lane < n_cand && rank == kk - 1) sh.kth = cv;
+        }
+    } else {
+        // more than 64 logits >= T (T = -inf with fewer than k finite logits, or massive ties): the exhaustive selection -- every wave
+        // extracts its own top k by k rounds of register arg-max + two wave reductions, wave 0 ranks the 4k candidates
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = v0[i];
+        if (tid < 4 * kMaxK) { sh.cand_v[tid] = -INFINITY; sh.cand_i[tid] = 0x7fffffff; }
+        __syncthreads();
+        for (int it = 0; it < kk; ++it) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int idx = tid + 256 * i;
+                if (v[i] > bv) { bv = v[i]; bi = idx; }   // ascending idx within a thread => lowest index kept on ties
+            }
+            const float wv = wave_max(bv);
+            const int wi = wave_min_i32(bv == wv ? bi : 0x7fffffff);   // lowest index among the lanes holding the wave maximum
+            if (lane == 0) { sh.cand_v[wave * kMaxK + it] = wv; sh.cand_i[wave * kMaxK + it] = wi; }
+            if (bi == wi) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (tid + 256 * i == wi) v[i] = -INFINITY;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) rank_candidates(kk);
     }
     __syncthreads();
     const float kth = sh.kth;
@@ -591,6 +644,17 @@ __global__ __launch_bounds__(256) void sample_ego_kernel(const float* __restrict
 void launch_sample_ego(hipStream_t s, const float* logits, int vocab, SamplerParams sp, const unsigned long long* seeds, int frame_idx,
                        const int* forced, int* out_tokens, int B, int* overflow) {
     hipLaunchKernelGGL(sample_ego_kernel, dim3(B * 3), dim3(256), 0, s, logits, vocab, sp, seeds, frame_idx, forced, out_tokens, overflow);
+}
+
+// test hook (debug_api.hip): the top-k sampler on n independent logit rows with given uniforms
+__global__ __launch_bounds__(256) void sample_rows_kernel(const float* __restrict__ logits, int V, int k, float temp, const float* __restrict__ u,
+                                                          int* __restrict__ out, int* overflow) {
+    __shared__ SamplerLds sh;
+    const int tok = block_sample_topk(logits + (long)blockIdx.x * V, V, k, temp, u[blockIdx.x], -1, sh.k, overflow);
+    if (threadIdx.x == 0) out[blockIdx.x] = tok;
+}
+void launch_sample_rows(hipStream_t s, const float* logits, int V, int k, float temp, const float* u, int* out, int* overflow, int n) {
+    hipLaunchKernelGGL(sample_rows_kernel, dim3(n), dim3(256), 0, s, logits, V, k, temp, u, out, overflow);
 }
 
 }  // namespace umgen

@@ -490,6 +490,8 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
     // default cache policy: after the layer's first scene they come out of this XCD's L2
     Rows768<RO> wo;
     Rows768<RF> wf;
+    Rows768<RQ> wq;
+    bool wq_ahead = false;   // SYS: the q|k|v rows of this item were requested during the previous item's mlp phase
 
     // items of this group in the order it works through them: (round rd, layer l) -- scene rd * R + pipe.
     //   !SYS: rounds outside, this pipeline's layers (q, q + D, ...) inside;
@@ -542,7 +544,6 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             u64* gxb = gpart + 2 * H * 50;
             u64* gpy = gxb + E;                      // mlp partial sums [32 producers][768 rows]
             u64* gxl = gpy + CU * E;                 // in-group x edge (D == 1)
-            Rows768<RQ> wq;
             u32x4_t wpl[6];                          // units 12..17 of the mlp c_proj slice (requested after the attention)
             const int rowq = (w * NW + wave) * RQ, rowo = (w * NW + wave) * RO, rowf = (w * NW + wave) * RF;
             const int rq0 = (w * NW + wave) * 3;
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         for (int j = 0; j < 6; ++j) w2p[(6 * hb + j) * NT] = wp[j];
                     }
                 }
-                req768_rows<RQ, true>(wq, lw.Wqkv, qkv_row, lane);
+                if (!wq_ahead) req768_rows<RQ, true>(wq, lw.Wqkv, qkv_row, lane);
                 if (load_w || !kSysKeepWo) req768<RO, !kSysKeepWo>(wo, lw.Wo, rowo, lane);
                 if (load_w || !kSysKeepWf) req768<RF, !kSysKeepWf>(wf, lw.Wfc, rowf, lane);
             } else {
@@ -909,6 +910,22 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             }
             wg_barrier();
             stamp(11);  // LN + c_fc rows + GELU
+#ifndef UMGEN_SYS_WQ_AHEAD
+#define UMGEN_SYS_WQ_AHEAD 0
+#endif
+            if (SYS && UMGEN_SYS_WQ_AHEAD) {
+                // EXPERIMENT, off: a busy systolic group has no idle wait in front of its next item -- its q|k|v rows (which no register
+                // can hold through the attention) are requested at the item's start and P1 waits for them (L2 latency + 110 KB per CU).
+                // Requesting them HERE, one item ahead, keeps 56 more VGPRs live over the loop's back edge: 18 spilled VGPRs with 3 K/V
+                // buffers (8 scenes: 909 vs 730 us per launch), 8 with 2 (803), none with 1 (740): never a gain
+                // (profiles/r03_engine_experiments.txt, session I).
+                wq_ahead = item + 1 < n_items;
+                if (wq_ahead) {
+                    const bool tail2 = item + 1 >= n_full * a.B;
+                    const int l2 = tail2 ? tail_l : q + D * ((item + 1) / a.B);
+                    req768_rows<RQ, true>(wq, a.layers[l2].Wqkv, qkv_row, lane);
+                }
+            }
             {
                 // this CU's partial sums of the 768 mlp c_proj outputs over its 96 hidden units.  Four lanes share four rows: thread t
                 // multiplies rows 4 (t / 4) .. + 3 by columns 24 (t % 4) .. + 23 (units 0..11, parked in LDS) and -- eight lanes per four
