@@ -34,7 +34,8 @@ enum {
 };
 
 /* FP32: exact-fp32 parity mode.  BF16: bf16 weights / operands / KV cache (the bench mode, BASELINE.json configs[1]).
- * FP16: the same kernels with IEEE-half operands -- the reference's own arithmetic (torch.cuda.amp.autocast fp16, UMGen.py:1604-1605) */
+ * FP16: the same kernels with IEEE-half operands -- the reference's own arithmetic (torch.cuda.amp.autocast fp16, UMGen.py:1604-1605);
+ *       umgen_load_tensor refuses (UMGEN_E_INVALID) a matrix weight whose magnitude exceeds 65504 instead of storing inf */
 enum { UMGEN_PREC_FP32 = 0, UMGEN_PREC_BF16 = 1, UMGEN_PREC_FP16 = 2 };
 enum { UMGEN_DT_F32 = 0, UMGEN_DT_BF16 = 1, UMGEN_DT_F16 = 2, UMGEN_DT_F64 = 3 };
 enum { UMGEN_SAMPLE_TOPK = 0, UMGEN_SAMPLE_TOPP = 1 };

@@ -421,6 +421,10 @@ __device__ inline void ln768(const float* xs, const float* lnw, int lane, f32x2_
 #define UMGEN_SYS_KEEP_WF 1
 #endif
 constexpr bool kSysKeepWo = UMGEN_SYS_KEEP_WO, kSysKeepWf = UMGEN_SYS_KEEP_WF;
+#ifndef UMGEN_SYS_LATE_PARK
+#define UMGEN_SYS_LATE_PARK 0
+#endif
+constexpr bool kLatePark = UMGEN_SYS_LATE_PARK;
 // q rows first: every wave owns 3 q, 3 k and 3 v rows (instead of 9 consecutive rows of the packed c_attn matrix), computes and
 // publishes its q rows, THEN its k | v rows: the latency of the q hand-off (one L2 round trip, 1.1 us) runs beside the k | v row
 // products instead of behind all nine, and the new token's own k | v -- only one more key of the softmax -- is merged after the
@@ -573,8 +577,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             }
             if (SYS) {
                 // layer switch of a resident group (once per layer and step): the parked mlp rows go through 6 staging registers at a
-                // time BEFORE anything else is requested (the q|k|v rows, c_proj / c_fc rows and K/V buffers then fill the registers)
-                if (load_w) {
+                // time in front of everything else (the q|k|v rows, c_proj / c_fc rows and K/V buffers then fill the registers).
+                // EXPERIMENT, off (kLatePark): the parked rows in three batches of 4 units behind P1, the key loop and P3's gather, so that a
+                // layer's first scene starts P1 as soon as its q|k|v rows are there: 8 scenes 748 vs 743 us, 5 / 6 scenes 673 / 692 vs
+                // 599 / 630 -- with idle time in front of the item the up-front staging was free, and at 8 scenes the switch's cost is
+                // the q|k|v rows' own trip from HBM (profiles/r03_engine_experiments.txt, session K).
+                if (load_w && !kLatePark) {
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb) {
                         u32x4_t wp[6];
@@ -621,7 +629,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // (Not on layer 0: a launch's first item has no idle wait, and the touch loop consumes its loads -- which return behind the whole
             //  weight stream, a wave's loads being in order: P1 started 6.6 us late.)
             u32 touched = 0;
-            if (!SYS && D > 1 && l != 0) {
+#ifndef UMGEN_SYS_TOUCH
+#define UMGEN_SYS_TOUCH 0
+#endif
+            if ((!SYS || UMGEN_SYS_TOUCH) && D > 1 && l != 0) {
                 const int n_lines = ((kb - ka) * kHeadDim * 2 + 127) >> 7;
                 const char* k0p = reinterpret_cast<const char*>(kbase + (long)ka * kHeadDim);
                 const char* v0p = reinterpret_cast<const char*>(vbase + (long)ka * kHeadDim);
@@ -694,6 +705,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
 #pragma unroll
             for (int bfr = 2; bfr < NB; ++bfr)     // (the q|k|v rows' registers are free now: these fly while q | k | v are exchanged)
                 if (k_lo + bfr * KPW * KP < k_hi) kv_req(bfr, k_lo + bfr * KPW * KP);
+            u32x4_t wps[4];                        // SYS, first scene of a layer: staging of the parked mlp rows (three batches of 4 units)
+            const bool late_park = SYS && kLatePark && load_w;
+            if (late_park) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wps[j] = ldwu(wp2 + (long)j * NT * 8, (u32)tid * 8u);
+            }
             stamp(1);   // LN + q|k|v rows
             // (never true for bf16 K/V bit patterns XORed; keeps the L2 touch loads alive.  Consumed HERE, not before P1: a wave's loads return
             //  in order, so on a launch's first item the touches arrive behind the whole weight stream -- P1 waited 6.6 us for them)
@@ -798,6 +815,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         chunk(kz, vz, Lk);
                     }
                 }
+                if (late_park) {   // batch 1 has arrived during the key loop: park it, request batch 2 (it flies during the merge and P3's gather)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w2p[j * NT] = wps[j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wps[j] = ldwu(wp2 + (long)(4 + j) * NT * 8, (u32)tid * 8u);
+                }
                 // the wave's 16 lane groups fold to 8 (group kg + 8 into group kg: lanes l + 32 into l, fixed order), then the 64 partials
                 // of this CU -> LDS -> one half partial (m, l, o[48]) published by wave 0
                 {
@@ -863,6 +886,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // ================= P3: merge the halves -> c_proj -> x' =================
             gather<4>(c, tid, gpart, 2 * H * 50, tg + 2, lds + L_GP);
             stamp(4);   // waited for the half partials
+            if (late_park) {   // batch 2 -> LDS, batch 3 requested (with the mlp rows' last 6 units below: parked behind P4's gather)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w2p[(4 + j) * NT] = wps[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wps[j] = ldwu(wp2 + (long)(8 + j) * NT * 8, (u32)tid * 8u);
+            }
 #pragma unroll
             for (int j = 0; j < 6; ++j) wpl[j] = ldwu(wp2 + (long)(12 + j) * NT * 8, (u32)tid * 8u);
             {
@@ -895,6 +924,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // ================= P4: x' -> LN -> c_fc -> GELU -> this CU's partial sums of the mlp c_proj =================
             gather<2>(c, tid, gxb, E, tg + 3, xb);
             stamp(6);   // waited for x'
+            if (late_park) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w2p[(8 + j) * NT] = wps[j];
+            }
             float* hsl = lds + L_HS;              // [96] gelu(c_fc) of this CU's hidden units
             float* hrow = hsl + 96;               // [256] second halves of the shared rows 512..767
             float* part = hrow + 256;             // [32][24] gathered partial sums (P5)
