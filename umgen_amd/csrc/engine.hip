@@ -78,6 +78,7 @@ struct umgen_engine {
     // the ego / map / box / TAR stacks on `bg_stream` (a CU-masked stream) while the latency-bound decode loop runs on the
     // other CUs; their temporal k | v rows are kept per layer in `tcache`.  The next frame then only computes its last slot.
     bool overlap = false, overlap_suspended = false;
+    bool conc_stacks = false;            // plain path: the map / box stacks on side streams beside the TAR stack (UMGEN_CONCURRENT_STACKS, default on)
     int last_B = 0;
     float last_full_pre_ms = 0.f, last_oar_ms = 0.f;   // ego + TAR phase of the last whole-window frame / decode loop of the last frame
     int overlap_mode = 1;                // UMGEN_OVERLAP: 0 off, 1 on for one scene per GPU (default), 2 always
@@ -775,9 +776,11 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
 
     // Step 2: the three TAR stacks (UMGen.py:1484-1494) and the conditioning rows (1496-1511)
     WindowTokens ws{e->d_pose_shift, e->d_map, e->d_box, e->d_img, B, Tc, Tn, t0};
-    if (use_px && e->side_stream[0]) {
-        // last-slot passes: 2207 rows per scene leave most CUs idle, and the three stacks are independent -- map and box run on
-        // side streams (own 1-slot workspaces) beside the TAR stack
+    // (a profiled frame keeps the stacks one behind the other: its per-launch events are meant to time each kernel alone)
+    if ((use_px || (e->conc_stacks && !e->profiling)) && e->side_stream[0]) {
+        // the three stacks are independent -- map and box run on side streams (own workspaces: 1 slot for the last-slot passes of the
+        // overlapped path, where 2207 rows per scene leave most CUs idle; the whole window otherwise) beside the TAR stack
+        struct Restore { umgen_engine* e; hipStream_t s; ~Restore() { e->stream = s; e->set_work(e->w_main); } } restore{e, st};
         HIPCHK(e, hipEventRecord(e->ev_side_in, st));
         const int side_stack[2] = {STACK_MAP, STACK_BOX};
         for (int i = 0; i < 2; ++i) {
@@ -1263,17 +1266,24 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (int rc = dev_alloc(e, &e->Hb, R * 4 * E * e->tsz)) return rc;
     if (int rc = dalloc(e, &e->mapfeat, Bm * Tm * kNMap * E)) return rc;
     e->w_main = umgen_engine::Work{e->X, e->A, e->QKV, e->VT, e->Hb, e->mapfeat};
-    if (e->overlap) {   // 1-slot workspaces + streams for the concurrent last-slot passes
-        const size_t R1 = Bm * kSeq;
+    // The three TAR stacks of a frame are independent (UMGen.py:1484-1494 feeds each the same window): in the plain path the map and box
+    // stacks run on two side streams with whole-window workspaces of their own, so that the tail of every launch (a persistent GEMM's
+    // last partial round of tiles, the ragged last attention blocks, the gaps between dependent launches) is filled by the other
+    // stacks' workgroups instead of idling.  (The overlapped pass of round 1 uses the same streams with 1-slot workspaces.)
+    const char* cs_env = getenv("UMGEN_CONCURRENT_STACKS");
+    e->conc_stacks = !e->overlap && (cs_env ? cs_env[0] != '0' : true);
+    if (e->overlap || e->conc_stacks) {   // 1-slot (overlap) / whole-window (concurrent stacks) workspaces + streams
+        const size_t slots = e->overlap ? 1 : Tm;
+        const size_t R1 = Bm * slots * kSeq;
         for (int i = 0; i < 2; ++i) {
             umgen_engine::Work& w = e->w_side[i];
             if (int rc = dalloc(e, &w.X, R1 * E)) return rc;
             if (int rc = dev_alloc(e, &w.A, R1 * E * e->tsz)) return rc;
             if (int rc = dev_alloc(e, &w.QKV, R1 * 3 * E * e->tsz)) return rc;
-            if (int rc = dev_alloc(e, &w.VT, Bm * E * e->S_pad * e->tsz)) return rc;
-            HIPCHK(e, hipMemset(w.VT, 0, Bm * E * e->S_pad * e->tsz));
+            if (int rc = dev_alloc(e, &w.VT, Bm * slots * E * e->S_pad * e->tsz)) return rc;
+            HIPCHK(e, hipMemset(w.VT, 0, Bm * slots * E * e->S_pad * e->tsz));
             if (int rc = dev_alloc(e, &w.Hb, R1 * 4 * E * e->tsz)) return rc;
-            if (int rc = dalloc(e, &w.mapfeat, Bm * kNMap * E)) return rc;
+            if (int rc = dalloc(e, &w.mapfeat, Bm * slots * kNMap * E)) return rc;
             HIPCHK(e, hipStreamCreateWithFlags(&e->side_stream[i], hipStreamNonBlocking));
             HIPCHK(e, hipEventCreate(&e->ev_side_done[i]));
         }
