@@ -3,6 +3,7 @@ evaluate CLI value resolution, library ABI (no compute calls -- there is no GPU 
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -131,3 +132,32 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_lib.Config) == 24 * 4
     assert ctypes.sizeof(_lib.Sampling) == 48
     assert ctypes.sizeof(_lib.Trace) == 10 * 8
+
+
+def test_vq_decoder_key_inventory_and_checkpoint_unwrapping(tmp_path):
+    """umgen_amd/vq.py host logic (no GPU): the decoder's state-dict inventory of the two production configurations (vq_model.py:153-202)
+    -- and, when the reference checkout is here, exactly the decode-path entries of its NormVQModel with the same shapes -- and
+    the three checkpoint forms Mapdecoder / Imagedecoder accept (path like VQModel.init_from_ckpt, loaded dict, bare state dict)."""
+    from umgen_amd.vq import IMAGE_VQ, MAP_VQ, _state_dict_of, decoder_keys
+    ki, km = decoder_keys(IMAGE_VQ), decoder_keys(MAP_VQ)
+    assert ki["quantize.embedding.weight"] == (8192, 16) and ki["post_quant_conv.weight"] == (256, 16, 3, 3)
+    assert km["post_quant_conv.weight"] == (16, 16, 1, 1) and km["decoder.conv_out.weight"] == (5, 128, 3, 3)
+    assert ki["decoder.conv_in.weight"] == (512, 256, 3, 3) and "decoder.up.4.attn.0.q.weight" in ki   # attention at resolution 32 = the deepest level
+    assert sum(int(np.prod(s)) for s in ki.values()) > 40e6
+    sd = {"decoder.conv_in.weight": torch.zeros(2), "encoder.x": torch.zeros(1)}
+    assert _state_dict_of(None) is None and _state_dict_of(sd) is sd and _state_dict_of({"state_dict": sd, "epoch": 3}) is sd
+    torch.save({"state_dict": sd}, tmp_path / "vq.pt")
+    assert set(_state_dict_of(str(tmp_path / "vq.pt"))) == set(sd)
+    ref = "/root/reference"
+    if os.path.isdir(os.path.join(ref, "projects", "tokenizer")):
+        sys.path.insert(0, ref)
+        from projects.tokenizer.vq_model import NormVQModel
+        for cfg in (MAP_VQ, IMAGE_VQ):
+            dd = dict(double_z=False, z_channels=cfg["z_channels"], resolution=cfg["resolution"], in_channels=cfg["out_ch"], out_ch=cfg["out_ch"],
+                      ch=cfg["ch"], ch_mult=list(cfg["ch_mult"]), num_res_blocks=cfg["num_res_blocks"],
+                      attn_resolutions=list(cfg["attn_resolutions"]), dropout=0.0)
+            m = NormVQModel(n_embed=cfg["n_embed"], embed_dim=cfg["embed_dim"], ddconfig=dd, stride=cfg["post_quant_ks"],
+                            padding=cfg["post_quant_pad"], ckpt_path=None)
+            want = {k: tuple(v.shape) for k, v in m.state_dict().items()
+                    if k.startswith(("decoder.", "post_quant_conv.")) or k == "quantize.embedding.weight"}
+            assert dict(decoder_keys(cfg)) == want
