@@ -121,6 +121,7 @@ struct umgen_engine {
     unsigned long long *eng_gx = nullptr, *eng_gloc = nullptr;
     unsigned int *eng_ticket = nullptr, *eng_err = nullptr;
     std::vector<void*> eng_wp2;             // per BlockOAR: mlp c_proj repacked for the engine's hidden-unit split (repack_mlp_proj)
+    std::vector<void*> eng_wf2;             // per BlockOAR: c_fc as matrix-core fragments (UMGEN_ENG_MFMA & 4)
     unsigned long long* eng_stamps = nullptr;   // UMGEN_DEBUG_TIMING: per-phase ticks of the engine (printed at destroy)
     size_t eng_gloc_bytes = 0;
     int fg_xcds = 8;
@@ -1029,7 +1030,12 @@ int repack_mlp_proj(umgen_engine* e) {
             for (int j = 0; j < kEngWpUnits; ++j)
                 for (int t = 0; t < kEngThreads; ++t) {
                     bf16_t* d8 = &dst[(((size_t)c * kEngWpUnits + j) * kEngThreads + t) * 8];
-                    if (j < 12) {
+                    if (UMGEN_ENG_MFMA & 8) {
+                        // matrix-core form (oar_engine.hip, kMfmaP): unit f = 3 tile + kstep of lane (t % 64) of wave (t / 64) is the A fragment
+                        // W[96 wave + 16 tile + lane % 16][96 c + 32 kstep + 8 (lane / 16) .. + 7]
+                        const int wave = t / 64, lane = t % 64, tile = j / 3, ks = j % 3;
+                        memcpy(d8, &src[(size_t)(96 * wave + 16 * tile + lane % 16) * F4 + 96 * c + 32 * ks + 8 * (lane / 16)], 8 * sizeof(bf16_t));
+                    } else if (j < 12) {
                         memcpy(d8, &src[(size_t)(4 * (t / 4) + j / 3) * F4 + 96 * c + 24 * (t % 4) + 8 * (j % 3)], 8 * sizeof(bf16_t));
                     } else {
                         for (int k = 0; k < 8; ++k) {
@@ -1040,6 +1046,26 @@ int repack_mlp_proj(umgen_engine* e) {
                 }
         HIPCHK(e, hipMemcpy(e->eng_wp2[li], dst.data(), dst.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
         hl[li].Wp2 = reinterpret_cast<const bf16_t*>(e->eng_wp2[li]);
+        hl[li].Wf2 = nullptr;
+        if (UMGEN_ENG_MFMA & 4) {
+            // c_fc [4E][E] as the engine's A fragments: CU c owns rows 96 c .. + 95 (6 tiles of 16), wave v the k range 96 v .. + 95
+            // (3 k-steps of 32); fragment f = 3 tile + kstep of lane l = W[96 c + 16 tile + l % 16][96 v + 32 kstep + 8 (l / 16) .. + 7],
+            // stored [c][v][f][l][8]: a wave's request of one fragment is 1 KB contiguous (row-strided 64-byte pieces streamed at
+            // two thirds of the rate where the weight stream is not hidden: 4 scenes 564 vs 511 us per launch)
+            if (e->eng_wf2.size() != e->oar.size()) e->eng_wf2.assign(e->oar.size(), nullptr);
+            std::vector<bf16_t> fsrc((size_t)F4 * E), fdst((size_t)F4 * E);
+            if (!e->eng_wf2[li])
+                if (int rc = dev_alloc(e, &e->eng_wf2[li], fdst.size() * sizeof(bf16_t))) return rc;
+            HIPCHK(e, hipMemcpy(fsrc.data(), e->oar[li].mlp.Wfc, fsrc.size() * sizeof(bf16_t), hipMemcpyDeviceToHost));
+            for (int c = 0; c < kEngGroup; ++c)
+                for (int v = 0; v < 8; ++v)
+                    for (int f = 0; f < 18; ++f)
+                        for (int ln = 0; ln < 64; ++ln)
+                            memcpy(&fdst[((((size_t)c * 8 + v) * 18 + f) * 64 + ln) * 8],
+                                   &fsrc[(size_t)(96 * c + 16 * (f / 3) + ln % 16) * E + 96 * v + 32 * (f % 3) + 8 * (ln / 16)], 8 * sizeof(bf16_t));
+            HIPCHK(e, hipMemcpy(e->eng_wf2[li], fdst.data(), fdst.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+            hl[li].Wf2 = reinterpret_cast<const bf16_t*>(e->eng_wf2[li]);
+        }
     }
     HIPCHK(e, hipMemcpy(e->d_layers, hl.data(), hl.size() * sizeof(OarLayerDev), hipMemcpyHostToDevice));
     return 0;

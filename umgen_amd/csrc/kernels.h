@@ -108,6 +108,12 @@ template <typename T> void launch_gemv_resid(hipStream_t s, const GemvResidArgs&
 // XCD-resident decode engine (oar_engine.hip): all BlockOAR layers of one decode step in one launch, bf16 weights, n_embd 768
 // ------------------------------------------------------------------------------------------------
 constexpr int kEngE = 768, kEngH = 16;         // the width the engine is built for (UMGen_Large); other widths use the launches above
+// UMGEN_ENG_MFMA: which of the decode engine's row dot products run on the matrix cores (oar_engine.hip; bits: 1 q|k|v rows, 2 c_proj rows,
+// 4 c_fc rows, 8 mlp partial sums).  Bit 4 adds a fragment-ordered copy of c_fc, bit 8 changes the repacked mlp c_proj layout (engine.hip).
+// Measured (profiles/r03_engine_experiments.txt, sessions N-R): 12 is the best set -- 441 vs 462 us per launch at one scene, 710 vs 743 at eight
+#ifndef UMGEN_ENG_MFMA
+#define UMGEN_ENG_MFMA 12
+#endif
 constexpr int kEngThreads = 512;               // one workgroup per CU
 constexpr int kEngGroup = 32;                  // workgroups per group == CUs per XCD
 constexpr int kEngWpUnits = 18;                // 16-byte units of the repacked mlp c_proj slice per thread (12 of its full row + 6 of a shared row)
@@ -116,6 +122,7 @@ struct OarLayerDev {                           // one BlockOAR's parameters (mod
     const bf16_t *Wqkv, *Wo, *Wfc, *Wproj;
     const bf16_t *Wp2;                         // mlp c_proj repacked for the hidden-unit split: [32 CUs][18 units][512 threads][8] (engine.hip repack_mlp_proj)
     const float *bqkv, *bo, *ln_a, *ln_b;
+    const bf16_t *Wf2;                         // UMGEN_ENG_MFMA & 4: c_fc as matrix-core fragments [32 CUs][8 waves][6 tiles x 3 k-steps][64 lanes][8] (1 KB per request)
 };
 struct OarState;
 struct OarEngineArgs {

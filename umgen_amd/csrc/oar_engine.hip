@@ -44,6 +44,13 @@ constexpr int RO = E / CU / NW;       // 3 c_proj rows per wave
 constexpr int RF = F / CU / NW;       // 12 c_fc rows per wave
 constexpr int RP = E / CU / NW;       // 3 mlp c_proj rows per wave
 static_assert(RQ * NW * CU == 3 * E && RO * NW * CU == E && RF * NW * CU == F, "row partition");
+// UMGEN_ENG_MFMA bits: 1 q|k|v rows (P1), 2 c_proj rows (P3), 4 c_fc rows (P4), 8 mlp partial sums (P4b; changes the repacked layout)
+constexpr bool kMfma = UMGEN_ENG_MFMA != 0, kMfmaQ = (UMGEN_ENG_MFMA & 1) != 0, kMfmaO = (UMGEN_ENG_MFMA & 2) != 0, kMfmaF = (UMGEN_ENG_MFMA & 4) != 0,
+               kMfmaP = (UMGEN_ENG_MFMA & 8) != 0;
+#ifndef UMGEN_ENG_MFMA_LATE_TILE
+#define UMGEN_ENG_MFMA_LATE_TILE 0
+#endif
+constexpr bool kLateTile = UMGEN_ENG_MFMA_LATE_TILE != 0;
 constexpr u32 kSpinLimit = 2000000;   // bounded polls: ~1 s worst case, then the give-up code is published
 constexpr float kScaleQK = 0.14433756729740643f;   // float32(1/sqrt(48)), module.py:196-198
 
@@ -59,7 +66,14 @@ constexpr int L_SO = L_SM + 192;           // per lane-group o [64][48]         
 constexpr int L_MISC = L_SO + 64 * 48;     // rank / scratch                                                      [16]
 constexpr int L_LN = L_MISC + 16;          // ln_1 | ln_2 weights of the item                                     [1536]
 constexpr int L_W2 = L_LN + 2 * E;         // parked mlp c_proj units 0..11 of every thread: [12][512] x 16 B      [24576]
-constexpr int L_TOTAL = L_W2 + 12 * NT * 4;
+// Row dot products on the matrix cores (UMGEN_ENG_MFMA, frame.h): activation split x = hi + lo in the operand type (16-bit each) [768 + 768],
+// the same for the CU's 96 gelu(c_fc) values [96 + 96], a zero strip for the 14 unused operand columns, per-wave partial row sums [8][96]
+constexpr int L_XH = L_W2 + 12 * NT * 4;    // hi halves of the 768 activations (16-bit)     [384 floats]
+constexpr int L_XL = L_XH + E / 2;          // lo halves                                      [384]
+constexpr int L_HH = L_XL + E / 2;          // hi | lo of the 96 hidden values                 [48 + 48]
+constexpr int L_ZR = L_HH + 96;             // zeros                                            [64]
+constexpr int L_PT = L_ZR + 64;             // partial row sums of the 8 waves' k ranges        [8][96]
+constexpr int L_TOTAL = kMfma ? L_PT + NW * 96 : L_XH;
 static_assert(L_TOTAL * 4 <= 160 * 1024, "LDS budget");
 
 __device__ inline u32 xcc_id() {
@@ -214,7 +228,9 @@ __device__ inline void load8p(const float* p, f32x2_t (&o)[4]) {
 #define UMGEN_ENG_KP 1
 #endif
 #ifndef UMGEN_ENG_NB
-#define UMGEN_ENG_NB 4        // measured (profiles/r03_engine_experiments.txt): 2: 476 us per launch, 3: 476, 4: 471, 5 (15 spilled VGPRs): 504
+// measured (profiles/r03_engine_experiments.txt): VALU row products 2: 476 us per launch, 3: 476, 4: 471, 5 (15 spilled VGPRs): 504; with the c_fc
+// rows as matrix-core fragments (aligned register tuples) 4 buffers spill 8 VGPRs (462 us), 3 do not (443)
+#define UMGEN_ENG_NB ((UMGEN_ENG_MFMA & 4) ? 3 : 4)
 #endif
 #ifndef UMGEN_ENG_NB_SYS
 #define UMGEN_ENG_NB_SYS 3    // the systolic kernel keeps more of a layer live: 4 buffers spill 2-4 VGPRs there
@@ -405,6 +421,110 @@ __device__ inline void ln768(const float* xs, const float* lnw, int lane, f32x2_
     for (int e = 0; e < 4; ++e) { x1[e] = (x1[e] - mean2) * rstd2 * l1[e]; x2[e] = (x2[e] - mean2) * rstd2 * l2[e]; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row dot products on the matrix cores (kMfma).  A wave's rows x 768 products were ~2/3 of an item's VALU instructions (a third of
+// them the 16-bit -> fp32 widening of the weights).  v_mfma_f32_16x16x32 takes the 16-bit weights as they are: A = 16 weight rows x
+// 32 k, B = 32 k x 16 columns of which TWO are used -- column 0 holds the activations' 16-bit hi parts, column 1 their lo parts
+// (x = hi + lo to 2^-17 relative in bf16, 2^-22 in fp16: fp32-class against the weights' own 2^-9 / 2^-12) -- so one instruction
+// per 512 weights gives W . hi and W . lo, added afterwards.  The k range is split over the CU's 8 waves (96 k each: 3 instructions
+// per 16-row tile) so that a wave's fragments are as many registers as its whole rows were; the 8 partial sums of a row meet in LDS.
+//   fragment (tile t, k-step j) of lane l: 8 weights W[row0 + 16 t + l % 16][96 wave + 32 j + 8 (l / 16) ..]
+//   result of tile t: lane l holds column l % 16 of rows 4 (l / 16) .. + 3
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NTILE> struct WFrags { u32x4_t f[NTILE][3]; };
+template <int NTILE, bool KEEP, int T0 = 0, int T1 = NTILE>
+__device__ inline void req_frags(WFrags<NTILE>& w, const bf16_t* W, int row0, int nvalid, int wave, int lane) {
+    const bf16_t* base = W + (long)row0 * E + 96 * wave;
+#pragma unroll
+    for (int t = T0; t < T1; ++t) {
+        const u32 ro = (u32)min(16 * t + (lane & 15), nvalid - 1) * (u32)E + (u32)(lane >> 4) * 8u;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w.f[t][j] = KEEP ? ldwk(base, ro + 32u * j) : ldwu(base, ro + 32u * j);
+    }
+}
+// the same fragments out of a repacked copy [..][NTILE x 3 fragments][64 lanes][8]: 1 KB contiguous per request
+template <int NTILE, bool KEEP>
+__device__ inline void req_frags_packed(WFrags<NTILE>& w, const bf16_t* P, int lane) {
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const u32 off = (u32)((3 * t + j) * 64 + lane) * 8u;
+            w.f[t][j] = KEEP ? ldwk(P, off) : ldwu(P, off);
+        }
+}
+// value -> (hi, lo) in the operand type, as raw 16-bit patterns
+template <typename TT>
+__device__ inline void split16(float v, unsigned short& hi, unsigned short& lo) {
+    const auto h = Cvt<TT>::from_f(v);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, Cvt<TT>::from_f(v - Cvt<TT>::to_f(h)));
+}
+// the B operand of k-step j: column 0 = hi parts, column 1 = lo parts, columns 2..15 = 0; k0 = first k of the wave's range in xh / xl
+template <typename TT>
+__device__ inline void load_bfrags(const float* lds, int hi_off, int lo_off, int k0, int lane, typename Mma16<TT>::vec (&b)[3]) {
+    const int n = lane & 15;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(lds + (n == 0 ? hi_off : n == 1 ? lo_off : L_ZR)) + (n < 2 ? 2 * k0 : 0) + 16 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) b[j] = *reinterpret_cast<const typename Mma16<TT>::vec*>(base + 64 * j);
+}
+// NTILE tiles x 3 k-steps; hi + lo columns added; the wave's partial sums of rows 16 t + 4 (l / 16) .. + 3 -> part[row] (lanes of column 0)
+template <typename TT, int NTILE>
+__device__ inline void mfma_rows(const WFrags<NTILE>& w, const typename Mma16<TT>::vec (&b)[3], int lane, f32x4_t (&acc)[NTILE]) {
+    typedef typename Mma16<TT>::vec vec;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) acc[t] = Mma16<TT>::mfma(__builtin_bit_cast(vec, w.f[t][j]), b[j], acc[t]);
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += dpp_mov<0x101>(acc[t][r]);       // row_shl:1: column 1 (lo) onto column 0 (hi)
+}
+template <int NTILE>
+__device__ inline void store_partials(float* part, int lane, const f32x4_t (&acc)[NTILE]) {
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) *reinterpret_cast<f32x4_t*>(part + 16 * t + 4 * (lane >> 4)) = acc[t];
+    }
+}
+// LayerNorm of the 768-vector in LDS (statistics by every wave, as ln768), normalised values of THIS wave's 96 k split into hi / lo
+template <typename TT>
+__device__ inline void ln_split(const float* xs, const float* lnw, int lane, int wave, float* lds) {
+    f32x2_t x1[4], x2[4];
+    load8p(xs + lane * 8, x1);
+    load8p(xs + 512 + (lane & 31) * 8, x2);
+    f32x2_t s1 = (x1[0] + x1[1]) + (x1[2] + x1[3]);
+    f32x2_t s2 = (x2[0] + x2[1]) + (x2[2] + x2[3]);
+    float s = s1.x + s1.y;
+    s += (lane < 32) ? (s2.x + s2.y) : 0.f;
+    const float mean = wave_sum_all(s) * (1.0f / (float)E);
+    const f32x2_t mean2 = {mean, mean};
+    f32x2_t q1 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const f32x2_t d = x1[e] - mean2; q1 = __builtin_elementwise_fma(d, d, q1); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const f32x2_t d = x2[e] - mean2; q2 = __builtin_elementwise_fma(d, d, q2); }
+    float q = q1.x + q1.y;
+    q += (lane < 32) ? (q2.x + q2.y) : 0.f;
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(wave_sum_all(q), 1.0f / (float)E, 1e-5f));
+    unsigned short* xh = reinterpret_cast<unsigned short*>(lds + L_XH);
+    unsigned short* xl = reinterpret_cast<unsigned short*>(lds + L_XL);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = 96 * wave + 64 * i + lane;
+        if (i == 0 || lane < 32) {
+            unsigned short hi, lo;
+            split16<TT>((xs[k] - mean) * rstd * lnw[k], hi, lo);
+            xh[k] = hi; xl[k] = lo;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the fragment reads below are this wave's own k range: no workgroup barrier)
+}
+
+
 
 }  // namespace
 
@@ -456,6 +576,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
     const int g = a.xcc_group[xcc];
     if (g >= a.NG) return;   // (the census guarantees this never happens)
     if (tid0 == 0) reinterpret_cast<u32*>(lds + L_MISC)[0] = atomicAdd(a.ticket + g, 1u) & (u32)(CU - 1);
+    if (kMfma && tid0 < 64) lds[L_ZR + tid0] = 0.f;     // the B operand's 14 unused columns
     wg_barrier();
     const int w0 = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<u32*>(lds + L_MISC)[0]);
     Ctx c{a.err, false};
@@ -495,6 +616,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
     Rows768<RO> wo;
     Rows768<RF> wf;
     Rows768<RQ> wq;
+    WFrags<5> fq;            // kMfma: the CU's 72 q|k|v rows as 5 tiles of 16 (this wave's 96 k), c_proj 24 rows as 2 tiles, c_fc 96 rows as 6
+    WFrags<2> fo;
+    WFrags<6> ff;
+    static_assert(!(kMfma && kQFirst), "the q-first experiment is written for the VALU row products");
     bool wq_ahead = false;   // SYS: the q|k|v rows of this item were requested during the previous item's mlp phase
 
     // items of this group in the order it works through them: (round rd, layer l) -- scene rd * R + pipe.
@@ -568,8 +693,11 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 for (int k = 0; k < 3; ++k) lnr[k] = ldg((tid + k * NT < E ? lw.ln_a : lw.ln_b - E) + tid + k * NT);
             }
             float bq = 0.f, bo = 0.f;
-            if (lane < RQ) bq = ldg(lw.bqkv + qkv_row(lane));
-            if (lane < RO) bo = ldg(lw.bo + rowo + lane);
+            // (matrix-core form: thread r finishes row r of the CU's 72 q|k|v / 24 c_proj rows)
+            if (kMfmaQ) { if (tid < 72) bq = ldg(lw.bqkv + 72 * w + tid); }
+            else if (lane < RQ) bq = ldg(lw.bqkv + qkv_row(lane));
+            if (kMfmaO) { if (tid < 24) bo = ldg(lw.bo + 24 * w + tid); }
+            else if (lane < RO) bo = ldg(lw.bo + rowo + lane);
             float x_first[2] = {0.f, 0.f};
             if (l == 0) {
                 x_first[0] = ldg(a.xdec + (long)s * E + tid);
@@ -592,12 +720,20 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         for (int j = 0; j < 6; ++j) w2p[(6 * hb + j) * NT] = wp[j];
                     }
                 }
-                if (!wq_ahead) req768_rows<RQ, true>(wq, lw.Wqkv, qkv_row, lane);
-                if (load_w || !kSysKeepWo) req768<RO, !kSysKeepWo>(wo, lw.Wo, rowo, lane);
-                if (load_w || !kSysKeepWf) req768<RF, !kSysKeepWf>(wf, lw.Wfc, rowf, lane);
+                if (kMfmaQ) req_frags<5, true>(fq, lw.Wqkv, 72 * w, 72, wave, lane);
+                else if (!wq_ahead) req768_rows<RQ, true>(wq, lw.Wqkv, qkv_row, lane);
+                if (load_w || !kSysKeepWo) {
+                    if (kMfmaO) req_frags<2, !kSysKeepWo>(fo, lw.Wo, 24 * w, 24, wave, lane);
+                    else req768<RO, !kSysKeepWo>(wo, lw.Wo, rowo, lane);
+                }
+                if (load_w || !kSysKeepWf) {
+                    if (kMfmaF) req_frags_packed<6, !kSysKeepWf>(ff, lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8, lane);
+                    else req768<RF, !kSysKeepWf>(wf, lw.Wfc, rowf, lane);
+                }
             } else {
                 u32x4_t wp[12];
-                req768_rows<RQ, false>(wq, lw.Wqkv, qkv_row, lane);
+                if (kMfmaQ) req_frags<5, false>(fq, lw.Wqkv, 72 * w, 72, wave, lane);
+                else req768_rows<RQ, false>(wq, lw.Wqkv, qkv_row, lane);
 #pragma unroll
                 for (int j = 0; j < 12; ++j) wp[j] = ldwu(wp2 + (long)j * NT * 8, (u32)tid * 8u);
 
@@ -607,8 +743,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
 #pragma unroll
                 for (int j = 0; j < 12; ++j) w2p[j * NT] = wp[j];
                 // (the other two matrices only now: every wave's q|k|v and parked rows reach the memory system ahead of anybody's c_proj / c_fc rows)
-                req768(wo, lw.Wo, rowo, lane);
-                req768(wf, lw.Wfc, rowf, lane);
+                if (kMfmaO) req_frags<2, false>(fo, lw.Wo, 24 * w, 24, wave, lane);
+                else req768(wo, lw.Wo, rowo, lane);
+                // (kLateTile, measured and off: the sixth c_fc tile behind the attention so that 4 K/V buffers fit without spilling --
+                //  its HBM round trip then sits in front of P4's poll: 472.6 vs 443.9 us with 3 buffers and all 18 fragments up front)
+                if (kMfmaF) { if (kLateTile) req_frags<6, false, 0, 5>(ff, lw.Wfc, 96 * w, 96, wave, lane); else req_frags_packed<6, false>(ff, lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8, lane); }
+                else req768(wf, lw.Wfc, rowf, lane);
                 if (STAMPS && timer && first_item) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a.stamps[13] += wall_clock64() - t_k0; }
             }
             // attention geometry of this CU: head hh, half of the L + 1 keys, split in 8 wave spans of 16-key passes (4 lanes per key)
@@ -671,6 +811,27 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             };
             if (k_lo < k_hi) kv_req(0, k_lo);
             if (NB > 1 && k_lo + KPW * KP < k_hi) kv_req(NB > 1 ? 1 : 0, k_lo + KPW * KP);
+            if (kMfmaQ) {
+                typename Mma16<TT>::vec bx[3];
+                f32x4_t acc[5];
+                ln_split<TT>(xs, lnw, lane, wave, lds);
+                load_bfrags<TT>(lds, L_XH, L_XL, 96 * wave, lane, bx);
+                mfma_rows<TT, 5>(fq, bx, lane, acc);
+                store_partials<5>(lds + L_PT + wave * 96, lane, acc);
+                wg_barrier();
+                if (tid < 72) {
+                    float v = bq;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) v += (lds + L_PT)[ww * 96 + tid];      // fixed order: k ranges 0, 1, ..., 7
+                    const int n = 72 * w + tid;
+                    put_local(gqkv, (u32)n, tg + 1, v);
+                    if (n >= E) {   // K / V rows of the new token: 16 bits into the cache (head-major [2][H][Lmax][48])
+                        const int cc = n - E, kvsel = cc / E, hc = cc % E;
+                        (a.kvcache + (long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride)[
+                            (u32)(((kvsel * H + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim)] = bits16<TT>(v);
+                    }
+                }
+            } else
             {
                 f32x2_t x1[4], x2[4];
                 ln768(xs, lnw, lane, x1, x2);
@@ -894,6 +1055,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) wpl[j] = ldwu(wp2 + (long)(12 + j) * NT * 8, (u32)tid * 8u);
+            if (kMfmaF && kLateTile && !SYS) req_frags<6, false, 5, 6>(ff, lw.Wfc, 96 * w, 96, wave, lane);
             {
                 const float* gp = lds + L_GP;
                 for (int col = tid; col < E; col += NT) {
@@ -904,20 +1066,44 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     const float M = fmaxf(m0, m1);
                     const float e0 = (m0 > -INFINITY) ? __expf(m0 - M) : 0.f, e1 = (m1 > -INFINITY) ? __expf(m1 - M) : 0.f;
                     const float Ls = fmaf(e1, p1[49], e0 * p0[49]);
-                    as[col] = fmaf(e1, p1[d], e0 * p0[d]) * __builtin_amdgcn_rcpf(Ls);
+                    const float av = fmaf(e1, p1[d], e0 * p0[d]) * __builtin_amdgcn_rcpf(Ls);
+                    if (kMfmaO) {
+                        unsigned short hi, lo;
+                        split16<TT>(av, hi, lo);
+                        reinterpret_cast<unsigned short*>(lds + L_XH)[col] = hi;
+                        reinterpret_cast<unsigned short*>(lds + L_XL)[col] = lo;
+                    } else {
+                        as[col] = av;
+                    }
                 }
                 wg_barrier();
-                f32x2_t x1[4], x2[4];
-                float out[RO];
-                load8p(as + lane * 8, x1);
-                load8p(as + 512 + (lane & 31) * 8, x2);
-                dot768<TT, RO>(wo, x1, x2, lane, out);
-                float v = 0.f;
+                if (kMfmaO) {
+                    typename Mma16<TT>::vec bx[3];
+                    f32x4_t acc[2];
+                    load_bfrags<TT>(lds, L_XH, L_XL, 96 * wave, lane, bx);
+                    mfma_rows<TT, 2>(fo, bx, lane, acc);
+                    store_partials<2>(lds + L_PT + wave * 96, lane, acc);
+                    wg_barrier();
+                    if (tid < 24) {
+                        float v = 0.f;
 #pragma unroll
-                for (int r = 0; r < RO; ++r) v = (lane == r) ? out[r] : v;
-                if (lane < RO) {
-                    const int n = rowo + lane;
-                    put_local(gxb, (u32)n, tg + 3, xs[n] + (v + bo));
+                        for (int ww = 0; ww < NW; ++ww) v += (lds + L_PT)[ww * 96 + tid];
+                        const int n = 24 * w + tid;
+                        put_local(gxb, (u32)n, tg + 3, xs[n] + (v + bo));
+                    }
+                } else {
+                    f32x2_t x1[4], x2[4];
+                    float out[RO];
+                    load8p(as + lane * 8, x1);
+                    load8p(as + 512 + (lane & 31) * 8, x2);
+                    dot768<TT, RO>(wo, x1, x2, lane, out);
+                    float v = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RO; ++r) v = (lane == r) ? out[r] : v;
+                    if (lane < RO) {
+                        const int n = rowo + lane;
+                        put_local(gxb, (u32)n, tg + 3, xs[n] + (v + bo));
+                    }
                 }
             }
             stamp(5);   // merge + c_proj rows
@@ -931,7 +1117,45 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             float* hsl = lds + L_HS;              // [96] gelu(c_fc) of this CU's hidden units
             float* hrow = hsl + 96;               // [256] second halves of the shared rows 512..767
             float* part = hrow + 256;             // [32][24] gathered partial sums (P5)
-            {
+            if (kMfmaF) {
+                typename Mma16<TT>::vec bx[3];
+                ln_split<TT>(xb, lnw + E, lane, wave, lds);
+                load_bfrags<TT>(lds, L_XH, L_XL, 96 * wave, lane, bx);
+                {   // two passes of three tiles: 12 accumulator registers live instead of 24
+                    typedef typename Mma16<TT>::vec vec;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        f32x4_t a3[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) a3[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) a3[t] = Mma16<TT>::mfma(__builtin_bit_cast(vec, ff.f[3 * hf + t][j]), bx[j], a3[t]);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a3[t][r] += dpp_mov<0x101>(a3[t][r]);
+                            if ((lane & 15) == 0) *reinterpret_cast<f32x4_t*>(lds + L_PT + wave * 96 + 16 * (3 * hf + t) + 4 * (lane >> 4)) = a3[t];
+                        }
+                    }
+                }
+                wg_barrier();
+                if (tid < 96) {   // hidden unit 96 w + tid: sum of the 8 k ranges -> exact GELU -> hi / lo for the mlp projection's B operand
+                    float v = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) v += (lds + L_PT)[ww * 96 + tid];
+                    const float hv = gelu_erf(v);
+                    if (kMfmaP) {
+                        unsigned short hi, lo;
+                        split16<TT>(hv, hi, lo);
+                        reinterpret_cast<unsigned short*>(lds + L_HH)[tid] = hi;
+                        reinterpret_cast<unsigned short*>(lds + L_HH)[96 + tid] = lo;
+                    } else {
+                        hsl[tid] = hv;
+                    }
+                }
+            } else {
                 f32x2_t x1[4], x2[4];
                 float out[RF];
                 ln768(xb, lnw + E, lane, x1, x2);
@@ -939,7 +1163,17 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 float v = 0.f;
 #pragma unroll
                 for (int r = 0; r < RF; ++r) v = (lane == r) ? out[r] : v;
-                if (lane < RF) hsl[wave * RF + lane] = gelu_erf(v);
+                if (lane < RF) {
+                    const float hv = gelu_erf(v);
+                    if (kMfmaP) {
+                        unsigned short hi, lo;
+                        split16<TT>(hv, hi, lo);
+                        reinterpret_cast<unsigned short*>(lds + L_HH)[wave * RF + lane] = hi;
+                        reinterpret_cast<unsigned short*>(lds + L_HH)[96 + wave * RF + lane] = lo;
+                    } else {
+                        hsl[wave * RF + lane] = hv;
+                    }
+                }
             }
             wg_barrier();
             stamp(11);  // LN + c_fc rows + GELU
@@ -959,7 +1193,33 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     req768_rows<RQ, true>(wq, a.layers[l2].Wqkv, qkv_row, lane);
                 }
             }
-            {
+            if (kMfmaP) {
+                // this CU's partial sums of the 768 mlp c_proj outputs over its 96 hidden units: wave w takes rows 96 w .. 96 w + 95 (6 tiles
+                // of 16) x all 96 k (3 k-steps); the 18 fragments are the thread's 18 repacked units (12 parked in LDS, 6 in registers).
+                // The results sit in 4 lanes x 4 rows per tile: they go through the wave's strip of the partial-sum buffer so that every
+                // lane publishes one or two rows (24 store instructions with 4 active lanes each cost more than the 18 MFMAs)
+                typename Mma16<TT>::vec bh[3];
+                typedef typename Mma16<TT>::vec vec;
+                load_bfrags<TT>(lds, L_HH, L_HH + 48, 0, lane, bh);
+                float* strip = lds + L_PT + wave * 96;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int f = 3 * t + j;
+                        const u32x4_t wfrag = f < 12 ? w2p[f * NT] : wpl[f < 12 ? 0 : f - 12];
+                        acc = Mma16<TT>::mfma(__builtin_bit_cast(vec, wfrag), bh[j], acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += dpp_mov<0x101>(acc[r]);
+                    if ((lane & 15) == 0) *reinterpret_cast<f32x4_t*>(strip + 16 * t + 4 * (lane >> 4)) = acc;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's own strip: no workgroup barrier)
+                u64* mine = gpy + (long)w * E;
+                put_local(mine, (u32)(96 * wave + lane), tg + 4, strip[lane]);
+                if (lane < 32) put_local(mine, (u32)(96 * wave + 64 + lane), tg + 4, strip[64 + lane]);
+            } else {
                 // this CU's partial sums of the 768 mlp c_proj outputs over its 96 hidden units.  Four lanes share four rows: thread t
                 // multiplies rows 4 (t / 4) .. + 3 by columns 24 (t % 4) .. + 23 (units 0..11, parked in LDS) and -- eight lanes per four
                 // rows -- rows 512 + 4 (t / 8) .. + 3 by columns 12 (t % 8) .. + 11 (units 12..17); transposed quad sums leave row t's
