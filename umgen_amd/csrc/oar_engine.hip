@@ -21,11 +21,13 @@
 // never leaves the CU; what is exchanged are the CUs' partial sums of the 768 outputs (each CU then adds the 32 partials of its
 // own 24 rows): a 768-granule gather instead of a 3072-granule one, and the projection needs no cross-lane reduction.
 //
-// Arithmetic (fixed, independent of B / D / group placement, so scenes are batch-invariant): fp32 activations, bf16 weights and
-// bf16 K/V cache, fp32 accumulation.  Row dot products: lane l owns k = 8l..8l+7 (+512 i), 8 sequential FMAs per chunk, DPP
-// wave sum.  Attention of a head: its keys are split in two halves (two CUs), each half in 8 wave spans, each span in groups
-// of 8 lanes per key with an online softmax per lane group; the 64 group partials of a half, then the two halves, are merged in
-// a fixed order.
+// Arithmetic (fixed, independent of B / D / group placement, so scenes are batch-invariant): fp32 activations, 16-bit weights (bf16 or
+// IEEE half) and 16-bit K/V cache, fp32 accumulation.  VALU row dot products (q|k|v, c_proj): lane l owns k = 8l..8l+7 (+512 i), packed
+// fp32 FMAs, transposed wave sums (rows_sum).  Matrix-core row products (c_fc, mlp partial sums; UMGEN_ENG_MFMA): the activations enter
+// as hi + lo 16-bit columns of one v_mfma_f32_16x16x32 (2^-17 relative), k split over the 8 waves, partial sums added in wave order.
+// Attention of a head: its keys are split in two halves (two CUs), each half in 8 wave spans, each span in groups of 4 lanes per key
+// (16 keys per pass) with an online softmax per lane group; the 16 lane groups of a wave, the 64 partials of a half, then the two
+// halves, are merged in a fixed order.
 #include "frame.h"
 #include "kernels.h"
 
