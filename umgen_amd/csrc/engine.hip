@@ -65,6 +65,8 @@ struct umgen_engine {
     void *A = nullptr, *QKV = nullptr, *VT = nullptr, *Hb = nullptr;
     float *xdec = nullptr, *qdec = nullptr, *part = nullptr, *hdec = nullptr, *logits = nullptr, *logits_tar = nullptr, *qkv3 = nullptr;
     void* kvcache = nullptr;
+    void* vtcache = nullptr;            // UMGEN_ENG_MFMA & 16: the decode engine's dim-major copy of V [layer][scene][H][48][Lmax]
+    long vt_layer_stride = 0, vt_scene_stride = 0;
     long kv_layer_stride = 0, kv_scene_stride = 0;
     int Lmax = kAttnSplit * kAttnChunk, S_pad = 2240;   // cache rows per head: every split's fixed key range is addressable
     int *d_pose = nullptr, *d_pose_shift = nullptr, *d_map = nullptr, *d_box = nullptr, *d_img = nullptr;
@@ -478,6 +480,7 @@ int oar_layers(umgen_engine* e, int B, int ns) {
         OarEngineArgs a{};
         a.layers = e->d_layers; a.n_layers = (int)e->oar.size();
         a.kvcache = reinterpret_cast<bf16_t*>(e->kvcache); a.kv_layer_stride = e->kv_layer_stride; a.kv_scene_stride = e->kv_scene_stride; a.Lmax = e->Lmax;
+        a.vtcache = reinterpret_cast<bf16_t*>(e->vtcache); a.vt_layer_stride = e->vt_layer_stride; a.vt_scene_stride = e->vt_scene_stride;
         a.xdec = e->xdec; a.st = e->d_state; a.gx = e->eng_gx; a.gloc = e->eng_gloc; a.ticket = e->eng_ticket; a.err = e->eng_err;
         a.B = B; a.NG = es->NG;
         a.R = es->NG;
@@ -1330,6 +1333,14 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     e->kv_scene_stride = (long)e->Lmax * 2 * E;
     e->kv_layer_stride = (long)Bm * e->kv_scene_stride;
     if (int rc = dev_alloc(e, &e->kvcache, (size_t)cfg->n_oar_layer * e->kv_layer_stride * e->tsz)) return rc;
+    if ((UMGEN_ENG_MFMA & 16) && e->tsz == 2) {
+        // the matrix-core attention multiplies whole 32-key tiles, masked keys included: no NaN bit patterns may sit behind the mask
+        HIPCHK(e, hipMemset(e->kvcache, 0, (size_t)cfg->n_oar_layer * e->kv_layer_stride * e->tsz));
+        e->vt_scene_stride = (long)e->H * kHeadDim * e->Lmax;
+        e->vt_layer_stride = (long)Bm * e->vt_scene_stride;
+        if (int rc = dev_alloc(e, &e->vtcache, (size_t)cfg->n_oar_layer * e->vt_layer_stride * e->tsz)) return rc;
+        HIPCHK(e, hipMemset(e->vtcache, 0, (size_t)cfg->n_oar_layer * e->vt_layer_stride * e->tsz));
+    }
     if (e->overlap) {   // slot caches of the overlapped TAR pass: k | v rows of every temporal sub-block, all history slots
         size_t free_b = 0, total_b = 0;
         HIPCHK(e, hipMemGetInfo(&free_b, &total_b));

@@ -109,7 +109,7 @@ template <typename T> void launch_gemv_resid(hipStream_t s, const GemvResidArgs&
 // ------------------------------------------------------------------------------------------------
 constexpr int kEngE = 768, kEngH = 16;         // the width the engine is built for (UMGen_Large); other widths use the launches above
 // UMGEN_ENG_MFMA: which of the decode engine's row dot products run on the matrix cores (oar_engine.hip; bits: 1 q|k|v rows, 2 c_proj rows,
-// 4 c_fc rows, 8 mlp partial sums).  Bit 4 adds a fragment-ordered copy of c_fc, bit 8 changes the repacked mlp c_proj layout (engine.hip).
+// 4 c_fc rows, 8 mlp partial sums, 16 attention -- correct, but its 32-key register buffers leave room for one only: slower, off).  Bit 4 adds a fragment-ordered copy of c_fc, bit 8 changes the repacked mlp c_proj layout (engine.hip).
 // Measured (profiles/r03_engine_experiments.txt, sessions N-R): 12 is the best set -- 441 vs 462 us per launch at one scene, 710 vs 743 at eight
 #ifndef UMGEN_ENG_MFMA
 #define UMGEN_ENG_MFMA 12
@@ -128,6 +128,7 @@ struct OarState;
 struct OarEngineArgs {
     const OarLayerDev* layers; int n_layers;
     bf16_t* kvcache; long kv_layer_stride, kv_scene_stride; int Lmax;   // [layer][scene][2][H][Lmax][48]
+    bf16_t* vtcache; long vt_layer_stride, vt_scene_stride;             // UMGEN_ENG_MFMA & 16: V once more, dim-major [layer][scene][H][48][Lmax]
     float* xdec;                               // [B][E]: in = input of layer 0, out = output of the last layer
     const OarState* st;                        // step (cached keys) and epoch of the hand-off tags
     unsigned long long* gx;                    // [max_batch][E] cross-group x granules

@@ -48,7 +48,7 @@ constexpr int RP = E / CU / NW;       // 3 mlp c_proj rows per wave
 static_assert(RQ * NW * CU == 3 * E && RO * NW * CU == E && RF * NW * CU == F, "row partition");
 // UMGEN_ENG_MFMA bits: 1 q|k|v rows (P1), 2 c_proj rows (P3), 4 c_fc rows (P4), 8 mlp partial sums (P4b; changes the repacked layout)
 constexpr bool kMfma = UMGEN_ENG_MFMA != 0, kMfmaQ = (UMGEN_ENG_MFMA & 1) != 0, kMfmaO = (UMGEN_ENG_MFMA & 2) != 0, kMfmaF = (UMGEN_ENG_MFMA & 4) != 0,
-               kMfmaP = (UMGEN_ENG_MFMA & 8) != 0;
+               kMfmaP = (UMGEN_ENG_MFMA & 8) != 0, kMfmaA = (UMGEN_ENG_MFMA & 16) != 0;   // 16: attention (needs the dim-major V cache)
 #ifndef UMGEN_ENG_MFMA_LATE_TILE
 #define UMGEN_ENG_MFMA_LATE_TILE 0
 #endif
@@ -75,7 +75,8 @@ constexpr int L_XL = L_XH + E / 2;          // lo halves                        
 constexpr int L_HH = L_XL + E / 2;          // hi | lo of the 96 hidden values                 [48 + 48]
 constexpr int L_ZR = L_HH + 96;             // zeros                                            [64]
 constexpr int L_PT = L_ZR + 64;             // partial row sums of the 8 waves' k ranges        [8][96]
-constexpr int L_TOTAL = kMfma ? L_PT + NW * 96 : L_XH;
+constexpr int L_PS = L_PT + NW * 96;        // attention on the matrix cores: per wave the 32 probabilities of a pass as hi [32] | lo [32] 16-bit   [8][32 floats]
+constexpr int L_TOTAL = kMfma ? L_PS + NW * 32 : L_XH;
 static_assert(L_TOTAL * 4 <= 160 * 1024, "LDS budget");
 
 __device__ inline u32 xcc_id() {
@@ -228,6 +229,9 @@ __device__ inline void load8p(const float* p, f32x2_t (&o)[4]) {
 // Attention lane mapping: LPK lanes per key, KPW keys per wave pass; a lane holds 12 of a key's 48 values: 16 bytes + 8 bytes
 #ifndef UMGEN_ENG_KP
 #define UMGEN_ENG_KP 1
+#endif
+#ifndef UMGEN_ENG_NBM
+#define UMGEN_ENG_NBM 2        // matrix-core attention: register buffers of 32 keys (28 VGPRs each)
 #endif
 #ifndef UMGEN_ENG_NB
 // measured (profiles/r03_engine_experiments.txt): VALU row products 2: 476 us per launch, 3: 476, 4: 471, 5 (15 spilled VGPRs): 504; with the c_fc
@@ -756,14 +760,17 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             // attention geometry of this CU: head hh, half of the L + 1 keys, split in 8 wave spans of 16-key passes (4 lanes per key)
             const int hh = w >> 1, half = w & 1;
             const int nk = kQFirst ? Lk : Lk + 1;     // keys of the spans: the cached ones (the new token's own key is merged behind them) / all
-            const int n0 = min(nk, (((nk + 1) >> 1) + KPW - 1) & ~(KPW - 1));
+            constexpr int KPA = kMfmaA ? 32 : KPW;    // keys per pass (matrix-core attention: 32)
+            const int n0 = min(nk, (((nk + 1) >> 1) + KPA - 1) & ~(KPA - 1));
             const int ka = half ? n0 : 0, kb = half ? nk : n0;
-            const int span = ((((kb - ka) + NW - 1) / NW) + KPW - 1) & ~(KPW - 1);
+            const int span = ((((kb - ka) + NW - 1) / NW) + KPA - 1) & ~(KPA - 1);
             const int k_lo = ka + wave * span;
             int k_hi = min(kb, k_lo + span);
             const int piece = lane & (LPK - 1), kg = lane / LPK;
             const bf16_t* kbase = a.kvcache + (long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride + (long)hh * a.Lmax * kHeadDim;
             const bf16_t* vbase = kbase + (long)H * a.Lmax * kHeadDim;
+            // matrix-core attention: V of this head dim-major [48][Lmax] (8 consecutive keys of one dimension are one 16-byte request)
+            const bf16_t* vtbase = kMfmaA ? a.vtcache + (long)l * a.vt_layer_stride + (long)s * a.vt_scene_stride + (long)hh * kHeadDim * a.Lmax : nullptr;
             // With D > 1 this group now waits for the other groups: pull this CU's share of the cached K / V rows (two contiguous
             // byte ranges, head-major cache) into the XCD's L2 meanwhile -- one dword per 128-byte line, default cache policy, issued
             // BEHIND the non-temporal weight requests so that the weight stream does not push them out again.  The attention's own
@@ -778,6 +785,15 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 const int n_lines = ((kb - ka) * kHeadDim * 2 + 127) >> 7;
                 const char* k0p = reinterpret_cast<const char*>(kbase + (long)ka * kHeadDim);
                 const char* v0p = reinterpret_cast<const char*>(vbase + (long)ka * kHeadDim);
+                if (kMfmaA) {
+                    // K as before; V dim-major: 48 rows of (kb - ka) keys
+                    for (int ln = tid; ln < n_lines; ln += NT) touched ^= *(const UMGEN_GLOBAL u32*)(k0p + ((long)ln << 7));
+                    const int per_dim = ((kb - ka) * 2 + 127) >> 7;
+                    for (int i = tid; i < per_dim * kHeadDim; i += NT) {
+                        const int d = i / per_dim, ln = i - d * per_dim;
+                        touched ^= *(const UMGEN_GLOBAL u32*)(reinterpret_cast<const char*>(vtbase + (long)d * a.Lmax + ka) + ((long)ln << 7));
+                    }
+                } else
                 for (int ln = tid; ln < n_lines; ln += NT) {
                     touched ^= *(const UMGEN_GLOBAL u32*)(k0p + ((long)ln << 7));
                     touched ^= *(const UMGEN_GLOBAL u32*)(v0p + ((long)ln << 7));
@@ -811,8 +827,28 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     vc[buf][i].b = ldwu2(vbase, off + 32u + (u32)piece * 4u);
                 }
             };
-            if (k_lo < k_hi) kv_req(0, k_lo);
-            if (NB > 1 && k_lo + KPW * KP < k_hi) kv_req(NB > 1 ? 1 : 0, k_lo + KPW * KP);
+            // matrix-core attention: a 32-key pass = K as the B operand of q . K^T (2 key tiles x 2 k-steps of 32 dims; the second k-step's
+            // upper half is the zero padding 48..63 of q, any finite filler will do) + V^T as the B operand of P . V (3 dim tiles x 32 keys)
+            struct KVM { u32x4_t k[2][2]; u32x4_t v[3]; };
+            constexpr int NBM = UMGEN_ENG_NBM;
+            KVM km[NBM];
+            auto kvm_req = [&](int buf, int k0) {
+                const int cg = lane >> 4;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const u32 key = (u32)min(k0 + 16 * kt + (lane & 15), a.Lmax - 1) * (u32)kHeadDim;
+                    km[buf].k[kt][0] = ldwu(kbase, key + 8u * cg);
+                    km[buf].k[kt][1] = ldwu(kbase, key + (cg < 2 ? 32u + 8u * cg : 8u * (cg - 2)));
+                }
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) km[buf].v[dt] = ldwu(vtbase, (u32)(16 * dt + (lane & 15)) * (u32)a.Lmax + (u32)k0 + 8u * cg);
+            };
+            if (kMfmaA) {
+                if (k_lo < k_hi) kvm_req(0, k_lo);      // (the other buffers behind P1: 28 VGPRs each, and the q|k|v rows are still live here)
+            } else {
+                if (k_lo < k_hi) kv_req(0, k_lo);
+                if (NB > 1 && k_lo + KPW * KP < k_hi) kv_req(NB > 1 ? 1 : 0, k_lo + KPW * KP);
+            }
             if (kMfmaQ) {
                 typename Mma16<TT>::vec bx[3];
                 f32x4_t acc[5];
@@ -831,6 +867,8 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         const int cc = n - E, kvsel = cc / E, hc = cc % E;
                         (a.kvcache + (long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride)[
                             (u32)(((kvsel * H + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim)] = bits16<TT>(v);
+                        if (kMfmaA && kvsel == 1)   // the same value dim-major for the matrix-core attention
+                            (a.vtcache + (long)l * a.vt_layer_stride + (long)s * a.vt_scene_stride)[(u32)(hc * a.Lmax + Lk)] = bits16<TT>(v);
                     }
                 }
             } else
@@ -862,12 +900,20 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         const int cc = n - E, kvsel = cc / E, hc = cc % E;
                         (a.kvcache + (long)l * a.kv_layer_stride + (long)s * a.kv_scene_stride)[
                             (u32)(((kvsel * H + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim)] = bits16<TT>(v);
+                        if (kMfmaA && kvsel == 1)   // the same value dim-major for the matrix-core attention
+                            (a.vtcache + (long)l * a.vt_layer_stride + (long)s * a.vt_scene_stride)[(u32)(hc * a.Lmax + Lk)] = bits16<TT>(v);
                     }
                 }
             }
+            if (kMfmaA) {
 #pragma unroll
-            for (int bfr = 2; bfr < NB; ++bfr)     // (the q|k|v rows' registers are free now: these fly while q | k | v are exchanged)
-                if (k_lo + bfr * KPW * KP < k_hi) kv_req(bfr, k_lo + bfr * KPW * KP);
+                for (int bfr = 1; bfr < NBM; ++bfr)
+                    if (k_lo + bfr * 32 < k_hi) kvm_req(bfr, k_lo + bfr * 32);
+            } else {
+#pragma unroll
+                for (int bfr = 2; bfr < NB; ++bfr)     // (the q|k|v rows' registers are free now: these fly while q | k | v are exchanged)
+                    if (k_lo + bfr * KPW * KP < k_hi) kv_req(bfr, k_lo + bfr * KPW * KP);
+            }
             u32x4_t wps[4];                        // SYS, first scene of a layer: staging of the parked mlp rows (three batches of 4 units)
             const bool late_park = SYS && kLatePark && load_w;
             if (late_park) {
@@ -890,6 +936,125 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 };
                 poll_head(0, kQFirst ? kHeadDim : 3 * kHeadDim);
                 stamp(2);   // waited for q_h (| k_h | v_h)
+                if (kMfmaA) {
+                    typedef typename Mma16<TT>::vec vec;
+                    const int cg = lane >> 4, mrow = lane & 15;
+                    // A operand of q . K^T: row 0 = q's hi parts, row 1 = its lo parts, rows 2..15 zero; k-step 1 holds dims 32..47 and zeros
+                    vec qa[2];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bool valid = ks == 0 || cg < 2;
+                        const float* qp = qs + (valid ? 32 * ks + 8 * cg : 0);
+                        u32 pk[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            unsigned short h0, l0, h1, l1;
+                            split16<TT>(qp[2 * e], h0, l0);
+                            split16<TT>(qp[2 * e + 1], h1, l1);
+                            const u32 hi = (u32)h0 | ((u32)h1 << 16), lo = (u32)l0 | ((u32)l1 << 16);
+                            pk[e] = !valid ? 0u : (mrow == 0 ? hi : (mrow == 1 ? lo : 0u));
+                        }
+                        qa[ks] = __builtin_bit_cast(vec, u32x4_t{pk[0], pk[1], pk[2], pk[3]});
+                    }
+                    // the new token's own key / value (not in the caches yet): score and value row from the head's q | k | v exchange, 16 bits
+                    const float own_d = lane < kHeadDim ? qs[lane] * round16<TT>(qs[kHeadDim + lane]) : 0.f;
+                    const float s_own = wave_sum_all(own_d) * kScaleQK;
+                    float vn[3];
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) vn[dt] = round16<TT>(qs[2 * kHeadDim + 16 * dt + mrow]);
+                    float m_run = -INFINITY, l_run = 0.f;      // (wave-uniform)
+                    f32x4_t oacc[3];
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    unsigned short* pstrip = reinterpret_cast<unsigned short*>(lds + L_PS + wave * 32);   // hi [32] | lo [32]
+                    auto rowmax16 = [](float v) {   // over lanes 0..15 (every lane of the row ends with it)
+                        v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+                        return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+                    };
+                    auto rowsum16 = [](float v) {
+                        v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+                        return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+                    };
+                    auto pass = [&](const KVM& kv, int k0) {
+                        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            s0 = Mma16<TT>::mfma(qa[ks], __builtin_bit_cast(vec, kv.k[0][ks]), s0);
+                            s1 = Mma16<TT>::mfma(qa[ks], __builtin_bit_cast(vec, kv.k[1][ks]), s1);
+                        }
+                        // lanes 0..15: rows 0 (q hi) + 1 (q lo) of key k0 + lane (tile 0) / k0 + 16 + lane (tile 1)
+                        const int io = Lk - k0;                 // position of the new token's own key in this pass (if 0 <= io < 32)
+                        float c0 = (s0[0] + s0[1]) * kScaleQK, c1 = (s1[0] + s1[1]) * kScaleQK;
+                        if (io >= 0 && io < 16 && lane == io) c0 = s_own;
+                        if (io >= 16 && io < 32 && lane == io - 16) c1 = s_own;
+                        c0 = (lane < 16 && k0 + lane < k_hi) ? c0 : -INFINITY;
+                        c1 = (lane < 16 && k0 + 16 + lane < k_hi) ? c1 : -INFINITY;
+                        const float m_new = fmaxf(m_run, rowmax16(fmaxf(c0, c1)));
+                        if (m_new > -INFINITY) {
+                            const float scale = __expf(m_run - m_new);   // exp(-inf) = 0 on the first pass
+                            float p0 = __expf(c0 - m_new), p1 = __expf(c1 - m_new);
+                            l_run = fmaf(l_run, scale, rowsum16(p0 + p1));
+                            float p_own = 0.f;
+                            if (io >= 0 && io < 32 && Lk < k_hi) {        // (wave-uniform)
+                                p_own = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(io < 16 ? p0 : p1), io & 15));
+                                if (io < 16) p0 = (lane == io) ? 0.f : p0; else p1 = (lane == io - 16) ? 0.f : p1;   // its V row is not in the cache
+                            }
+                            if (lane < 16) {
+                                unsigned short h, lo2;
+                                split16<TT>(p0, h, lo2); pstrip[lane] = h; pstrip[32 + lane] = lo2;
+                                split16<TT>(p1, h, lo2); pstrip[16 + lane] = h; pstrip[48 + lane] = lo2;
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            // A operand of P . V: row 0 = hi parts, row 1 = lo parts of the 32 probabilities (8 keys per lane group)
+                            const unsigned char* pb = mrow == 0 ? reinterpret_cast<const unsigned char*>(pstrip)
+                                                    : mrow == 1 ? reinterpret_cast<const unsigned char*>(pstrip + 32)
+                                                                : reinterpret_cast<const unsigned char*>(lds + L_ZR);
+                            const vec pa = *reinterpret_cast<const vec*>(pb + 16 * cg);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the strip is rewritten by the next pass)
+#pragma unroll
+                            for (int dt = 0; dt < 3; ++dt) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) oacc[dt][r] *= scale;
+                                oacc[dt] = Mma16<TT>::mfma(pa, __builtin_bit_cast(vec, kv.v[dt]), oacc[dt]);
+                                oacc[dt][0] = fmaf(p_own, vn[dt], oacc[dt][0]);
+                            }
+                            m_run = m_new;
+                        }
+                    };
+                    for (int k0 = k_lo; k0 < k_hi; k0 += 32 * NBM) {
+#pragma unroll
+                        for (int bfr = 0; bfr < NBM; ++bfr) {
+                            if (k0 + 32 * bfr < k_hi) {
+                                pass(km[bfr], k0 + 32 * bfr);
+                                if (k0 + 32 * (NBM + bfr) < k_hi) kvm_req(bfr, k0 + 32 * (NBM + bfr));
+                            }
+                        }
+                    }
+                    // one partial per wave: (m, l, o[48] = rows 0 + 1 of the three dim tiles, lanes 0..15) -> LDS -> wave 0 merges the 8 and publishes
+                    float* sm = lds + L_SM;
+                    float* so = lds + L_SO;
+                    if (lane == 0) { sm[wave] = m_run; sm[8 + wave] = l_run; }
+                    if (lane < 16) {
+#pragma unroll
+                        for (int dt = 0; dt < 3; ++dt) so[wave * kHeadDim + 16 * dt + lane] = oacc[dt][0] + oacc[dt][1];
+                    }
+                    wg_barrier();
+                    if (tid < kHeadDim) {
+                        float M = sm[0];
+#pragma unroll
+                        for (int ww = 1; ww < NW; ++ww) M = fmaxf(M, sm[ww]);
+                        float Ls = 0.f, o = 0.f;
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) {
+                            const float e = (M > -INFINITY) ? __expf(sm[ww] - M) : 0.f;
+                            Ls = fmaf(e, sm[8 + ww], Ls);
+                            o = fmaf(e, so[ww * kHeadDim + tid], o);
+                        }
+                        u64* gp = gpart + (hh * 2 + half) * 50;
+                        put_local(gp, (u32)tid, tg + 2, o);
+                        if (tid == 0) { put_local(gp, 48u, tg + 2, M); put_local(gp, 49u, tg + 2, Ls); }
+                    }
+                } else {
                 // this lane's 12 of the head's 48 dimensions: 8 piece .. 8 piece + 7 and 32 + 4 piece .. + 3, as 6 packed pairs
                 auto dim_of = [&](int j) { return j < 4 ? piece * 8 + 2 * j : 32 + piece * 4 + 2 * (j - 4); };
                 auto own16 = [&](const float* src, f32x2_t (&o)[6]) {   // the new token's own k / v, as the cache will hold it (16 bits)
@@ -1044,6 +1209,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                         if (tid == 0) { put_local(gp, 48u, tg + 2, M); put_local(gp, 49u, tg + 2, Ls); }
                     }
                 }
+                            }
             }
             stamp(3);   // attention of this CU's half
             // ================= P3: merge the halves -> c_proj -> x' =================
