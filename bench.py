@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from umgen_amd.config import MOD_ORDER, SEQ_LEN, large_config, tiny_config, wide2x_config  # noqa: E402
-from umgen_amd.synth import synthetic_scene  # noqa: E402
+from umgen_amd.synth import synthetic_control, synthetic_scene  # noqa: E402
 from umgen_amd.weights import expected_keys, synth_tensor  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="bf16: BASELINE.json configs[1]; fp16: the same kernels with IEEE-half operands (the reference's autocast dtype)")
     ap.add_argument("--history", type=int, default=20, help="history frames T (configs[4]: 40 = doubled context)")
+    ap.add_argument("--task", default="video", choices=["video", "control"],
+                    help="control: ego pose + one agent slot of every new frame given (configs[2] with --batch 4); the bench line is video")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     args = ap.parse_args()
@@ -145,8 +147,15 @@ def main():
     tokens = {m: np.concatenate([scenes[i][m] for i in mine]) for m in MOD_ORDER}
     seeds = [scene_seed(1000, i) for i in mine]
 
-    def rollout_fn(toks, seeds, new_frames):
-        return eng.rollout(toks, new_frames, cond_frames=T, input_cond_frames=T, seeds=seeds)
+    def control_of(ids, new_frames):
+        if args.task != "control":
+            return {}
+        ctl = [synthetic_control(i, n_frames=new_frames) for i in ids]
+        return {"init_tokens": {k: np.concatenate([c[k] for c in ctl]) for k in ("pose", "bbox3d")}, "control_test": True}
+
+    def rollout_fn(toks, seeds, new_frames, scene_ids=None):
+        return eng.rollout(toks, new_frames, cond_frames=T, input_cond_frames=T, seeds=seeds,
+                           **control_of(scene_ids if scene_ids is not None else mine, new_frames))
 
     def sync():
         torch.cuda.synchronize()
@@ -159,7 +168,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     # the timed region: every rank's rollouts + the one exchange of the path (all-gather of the sampled tokens, north_star)
-    out = sharded_rollout(rollout_fn, scenes, base_seed=1000, batch=B, device="cuda" if world > 1 else "cpu", new_frames=args.steps)
+    out = sharded_rollout(rollout_fn, scenes, base_seed=1000, batch=B, device="cuda" if world > 1 else "cpu", pass_ids=True, new_frames=args.steps)
     assert out["map"].shape[0] == n_scenes
     sync()
     dt = time.perf_counter() - t0
@@ -173,7 +182,7 @@ def main():
         # kernel-level rooflines of the prefill side: one extra frame with per-launch HIP events (the engine runs the whole
         # window in the foreground then, on all its CUs, so the launches are timed alone)
         eng.set_profiling(True)
-        eng.rollout(tokens, 1, cond_frames=T, input_cond_frames=T, seeds=seeds)
+        eng.rollout(tokens, 1, cond_frames=T, input_cond_frames=T, seeds=seeds, **control_of(mine, 1))
         tp = eng.timings()
         eng.set_profiling(False)
         for k in ("gemm_ms", "gemm_flops", "gemm_launches", "attn_ms", "attn_flops", "attn_launches", "layers_ms", "layers_launches"):
@@ -204,7 +213,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic tokenized_origin_scenes-shaped tokens; random-init weights (no checkpoint offline)",
-            "config": {"workload": f"UMGen_{args.config} --infer_task video, {args.steps}-frame rollout, "
+            "config": {"workload": f"UMGen_{args.config} --infer_task {args.task}, {args.steps}-frame rollout, "
                                    f"{B} scene(s)/GPU, T={T} history frames, top-k 5/5/16 sampling, rule_constrain",
                        "scenes_per_gpu": B, "history_frames": T, "sec_per_frame": dt / args.steps},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

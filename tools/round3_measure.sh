@@ -27,6 +27,7 @@ python bench.py --steps 10 --warmup 1 --no-cpu-baseline --precision fp16 > gpuru
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision fp32 > gpurun_out/r03_bench_fp32.json 2> gpurun_out/r03_bench_fp32.err
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch 8 > gpurun_out/r03_bench_b8.json 2> gpurun_out/r03_bench_b8.err
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch 4 > gpurun_out/r03_bench_b4.json 2> gpurun_out/r03_bench_b4.err
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch 4 --task control > gpurun_out/r03_bench_control_b4.json 2> gpurun_out/r03_bench_control_b4.err
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch 6 > gpurun_out/r03_bench_b6.json 2> gpurun_out/r03_bench_b6.err
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 16 > gpurun_out/r03_bench_b16.json 2> gpurun_out/r03_bench_b16.err
 UMGEN_DECODE_ENGINE=0 UMGEN_OVERLAP=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r03_bench_launches_plain.json 2> gpurun_out/r03_bench_launches_plain.err
