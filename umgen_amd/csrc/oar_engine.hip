@@ -65,7 +65,7 @@ constexpr int L_QKV = L_HS + 1152;          // q_h | k_h | v_h of this CU's head
 constexpr int L_GP = L_QKV + 160;          // gathered half partials [32][50]                                   [1600]
 constexpr int L_SM = L_GP + 2 * H * 50;    // per lane-group m [64], l [64], weights [64]                        [192]
 constexpr int L_SO = L_SM + 192;           // per lane-group o [64][48]                                          [3072]
-constexpr int L_MISC = L_SO + 64 * 48;     // rank / scratch                                                      [16]
+constexpr int L_MISC = L_SO + (kMfmaA ? NW : 64) * 48;   // rank / scratch (matrix-core attention: one partial per wave)        [16]
 constexpr int L_LN = L_MISC + 16;          // ln_1 | ln_2 weights of the item                                     [1536]
 constexpr int L_W2 = L_LN + 2 * E;         // parked mlp c_proj units 0..11 of every thread: [12][512] x 16 B      [24576]
 // Row dot products on the matrix cores (UMGEN_ENG_MFMA, frame.h): activation split x = hi + lo in the operand type (16-bit each) [768 + 768],
@@ -76,7 +76,9 @@ constexpr int L_HH = L_XL + E / 2;          // hi | lo of the 96 hidden values  
 constexpr int L_ZR = L_HH + 96;             // zeros                                            [64]
 constexpr int L_PT = L_ZR + 64;             // partial row sums of the 8 waves' k ranges        [8][96]
 constexpr int L_PS = L_PT + NW * 96;        // attention on the matrix cores: per wave the 32 probabilities of a pass as hi [32] | lo [32] 16-bit   [8][32 floats]
-constexpr int L_TOTAL = kMfma ? L_PS + NW * 32 : L_XH;
+constexpr int L_FT = L_PS + NW * 32;       // matrix-core attention: the sixth c_fc tile's 3 fragments of every thread, parked like the mlp rows  [3][512] x 16 B
+constexpr bool kParkFT = kMfmaA && kMfmaF;
+constexpr int L_TOTAL = kMfma ? L_FT + (kParkFT ? 3 * NT * 4 : 0) : L_XH;
 static_assert(L_TOTAL * 4 <= 160 * 1024, "LDS budget");
 
 __device__ inline u32 xcc_id() {
@@ -449,10 +451,10 @@ __device__ inline void req_frags(WFrags<NTILE>& w, const bf16_t* W, int row0, in
     }
 }
 // the same fragments out of a repacked copy [..][NTILE x 3 fragments][64 lanes][8]: 1 KB contiguous per request
-template <int NTILE, bool KEEP>
+template <int NTILE, bool KEEP, int T0 = 0, int T1 = NTILE>
 __device__ inline void req_frags_packed(WFrags<NTILE>& w, const bf16_t* P, int lane) {
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t)
+    for (int t = T0; t < T1; ++t)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const u32 off = (u32)((3 * t + j) * 64 + lane) * 8u;
@@ -733,7 +735,19 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     else req768<RO, !kSysKeepWo>(wo, lw.Wo, rowo, lane);
                 }
                 if (load_w || !kSysKeepWf) {
-                    if (kMfmaF) req_frags_packed<6, !kSysKeepWf>(ff, lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8, lane);
+                    if (kMfmaF) {
+                        const bf16_t* pf = lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8;
+                        if (kParkFT) {   // five tiles in registers, the sixth through three staging registers into LDS (read back by this thread in P4)
+                            u32x4_t st[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) st[j] = ldwu(pf, (u32)((15 + j) * 64 + lane) * 8u);
+                            req_frags_packed<6, !kSysKeepWf, 0, 5>(ff, pf, lane);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) reinterpret_cast<u32x4_t*>(lds + L_FT)[j * NT + tid] = st[j];
+                        } else {
+                            req_frags_packed<6, !kSysKeepWf>(ff, pf, lane);
+                        }
+                    }
                     else req768<RF, !kSysKeepWf>(wf, lw.Wfc, rowf, lane);
                 }
             } else {
@@ -753,7 +767,18 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 else req768(wo, lw.Wo, rowo, lane);
                 // (kLateTile, measured and off: the sixth c_fc tile behind the attention so that 4 K/V buffers fit without spilling --
                 //  its HBM round trip then sits in front of P4's poll: 472.6 vs 443.9 us with 3 buffers and all 18 fragments up front)
-                if (kMfmaF) { if (kLateTile) req_frags<6, false, 0, 5>(ff, lw.Wfc, 96 * w, 96, wave, lane); else req_frags_packed<6, false>(ff, lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8, lane); }
+                if (kMfmaF) {
+                    const bf16_t* pf = lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8;
+                    if (kLateTile) req_frags<6, false, 0, 5>(ff, lw.Wfc, 96 * w, 96, wave, lane);
+                    else if (kParkFT) {
+                        u32x4_t st[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) st[j] = ldwu(pf, (u32)((15 + j) * 64 + lane) * 8u);
+                        req_frags_packed<6, false, 0, 5>(ff, pf, lane);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) reinterpret_cast<u32x4_t*>(lds + L_FT)[j * NT + tid] = st[j];
+                    } else req_frags_packed<6, false>(ff, pf, lane);
+                }
                 else req768(wf, lw.Wfc, rowf, lane);
                 if (STAMPS && timer && first_item) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a.stamps[13] += wall_clock64() - t_k0; }
             }
@@ -829,7 +854,9 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
             };
             // matrix-core attention: a 32-key pass = K as the B operand of q . K^T (2 key tiles x 2 k-steps of 32 dims; the second k-step's
             // upper half is the zero padding 48..63 of q, any finite filler will do) + V^T as the B operand of P . V (3 dim tiles x 32 keys)
-            struct KVM { u32x4_t k[2][2]; u32x4_t v[3]; };
+            // (the k-step-1 fragment is SHARED by the two key tiles: its lower half-wave holds tile 0's dims 32..47, its upper half-wave
+            //  tile 1's -- a v_permlane32_swap brings the latter down; whatever sits in the other half meets q's zero padding)
+            struct KVM { u32x4_t k0[2]; u32x4_t k1; u32x4_t v[3]; };
             constexpr int NBM = UMGEN_ENG_NBM;
             KVM km[NBM];
             auto kvm_req = [&](int buf, int k0) {
@@ -837,8 +864,11 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
                     const u32 key = (u32)min(k0 + 16 * kt + (lane & 15), a.Lmax - 1) * (u32)kHeadDim;
-                    km[buf].k[kt][0] = ldwu(kbase, key + 8u * cg);
-                    km[buf].k[kt][1] = ldwu(kbase, key + (cg < 2 ? 32u + 8u * cg : 8u * (cg - 2)));
+                    km[buf].k0[kt] = ldwu(kbase, key + 8u * cg);
+                }
+                {
+                    const u32 key = (u32)min(k0 + 16 * (cg >> 1) + (lane & 15), a.Lmax - 1) * (u32)kHeadDim;
+                    km[buf].k1 = ldwu(kbase, key + 32u + 8u * (cg & 1));
                 }
 #pragma unroll
                 for (int dt = 0; dt < 3; ++dt) km[buf].v[dt] = ldwu(vtbase, (u32)(16 * dt + (lane & 15)) * (u32)a.Lmax + (u32)k0 + 8u * cg);
@@ -977,10 +1007,14 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                     };
                     auto pass = [&](const KVM& kv, int k0) {
                         f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+                        s0 = Mma16<TT>::mfma(qa[0], __builtin_bit_cast(vec, kv.k0[0]), s0);
+                        s1 = Mma16<TT>::mfma(qa[0], __builtin_bit_cast(vec, kv.k0[1]), s1);
+                        {
+                            u32x4_t up;     // the upper half-wave's registers in every lane
 #pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            s0 = Mma16<TT>::mfma(qa[ks], __builtin_bit_cast(vec, kv.k[0][ks]), s0);
-                            s1 = Mma16<TT>::mfma(qa[ks], __builtin_bit_cast(vec, kv.k[1][ks]), s1);
+                            for (int e = 0; e < 4; ++e) up[e] = __builtin_amdgcn_permlane32_swap(kv.k1[e], kv.k1[e], false, false)[1];
+                            s0 = Mma16<TT>::mfma(qa[1], __builtin_bit_cast(vec, kv.k1), s0);
+                            s1 = Mma16<TT>::mfma(qa[1], __builtin_bit_cast(vec, up), s1);
                         }
                         // lanes 0..15: rows 0 (q hi) + 1 (q lo) of key k0 + lane (tile 0) / k0 + 16 + lane (tile 1)
                         const int io = Lk - k0;                 // position of the new token's own key in this pass (if 0 <= io < 32)
@@ -1299,7 +1333,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
 #pragma unroll
                         for (int j = 0; j < 3; ++j)
 #pragma unroll
-                            for (int t = 0; t < 3; ++t) a3[t] = Mma16<TT>::mfma(__builtin_bit_cast(vec, ff.f[3 * hf + t][j]), bx[j], a3[t]);
+                            for (int t = 0; t < 3; ++t) {
+                                const u32x4_t fr = (kParkFT && 3 * hf + t == 5) ? reinterpret_cast<const u32x4_t*>(lds + L_FT)[j * NT + tid] : ff.f[3 * hf + t][j];
+                                a3[t] = Mma16<TT>::mfma(__builtin_bit_cast(vec, fr), bx[j], a3[t]);
+                            }
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
 #pragma unroll
