@@ -455,8 +455,11 @@ void launch_gemm_mfma(hipStream_t s, const GemmArgs& a) {
     // large launches: the 256 x 256 deep-pipelined kernel (gemm256.hip); it needs >= 1.5 tiles per CU to fill the chip
     // (measured, profiles/r03_gemm_bench_256tile_stagger.txt: at one scene -- 44 140 tokens -- it wins on qkv / fc / the K = 3072
     //  projection (+4 / +10 / +16 %) and loses on the two launches with ~1000 tiles, where 256 workgroups x 1 tile quantise badly;
-    //  from two scenes on it wins everywhere, +12-20 %)
-    static const int min_tiles256 = getenv("UMGEN_GEMM256_MIN_TILES") ? atoi(getenv("UMGEN_GEMM256_MIN_TILES")) : 1100;
+    //  from two scenes on it wins everywhere, +12-20 %).  That was one launch at a time: with the three TAR stacks on three streams
+    //  (engine.hip, UMGEN_CONCURRENT_STACKS) the other stacks' workgroups fill a launch's last partial round, and the threshold that
+    //  is best for a whole frame drops to <= 300 tiles (one scene: TAR 233.6 / 230.0 / 229.5 / 227.8 ms per frame at 1100 / 700 / 500 /
+    //  300, no further change below; profiles/r03_engine_experiments.txt)
+    static const int min_tiles256 = getenv("UMGEN_GEMM256_MIN_TILES") ? atoi(getenv("UMGEN_GEMM256_MIN_TILES")) : 300;
     const long tiles256 = (long)(a.Mi / 256) * ((a.Nj + 255) / 256);
     if (a.tile256 >= 0 && gemm256_supported(a) && (a.tile256 > 0 || tiles256 >= min_tiles256 || (a.K >= 2048 && tiles256 >= min_tiles256 / 3))) {
         launch_gemm256<TT>(s, a);
