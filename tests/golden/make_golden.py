@@ -81,12 +81,16 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
 
 def main():
     torch.manual_seed(0)
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("UMGEN_GOLDEN_THREADS", "8")))
     cfg = tiny_config()
     only = sys.argv[1:]
     cases = [("tiny_video_greedy", dict(weight_seed=1, scene_id=0, cond_frames=3, input_cond_frames=3, new_frames=2, control=False)),
              ("tiny_control_greedy", dict(weight_seed=2, scene_id=1, cond_frames=3, input_cond_frames=2, new_frames=3, control=True)),
-             ("tiny_boxctl_greedy", dict(weight_seed=3, scene_id=2, cond_frames=3, input_cond_frames=2, new_frames=3, control="bbox3d"))]
+             ("tiny_boxctl_greedy", dict(weight_seed=3, scene_id=2, cond_frames=3, input_cond_frames=2, new_frames=3, control="bbox3d")),
+             # growing window over several frames (configs[2]'s shape in small: 2 -> 6 history frames, then it slides): the engine's
+             # slot-cache reuse runs on frames 1..4 of these rollouts
+             ("tiny_grow_control_greedy", dict(weight_seed=4, scene_id=3, cond_frames=6, input_cond_frames=2, new_frames=6, control=True)),
+             ("tiny_grow_boxctl_greedy", dict(weight_seed=5, scene_id=4, cond_frames=5, input_cond_frames=2, new_frames=5, control="bbox3d"))]
     for name, kw in cases:
         if not only or name in only:
             run_case(name, cfg, **kw)

@@ -77,6 +77,27 @@ def test_linear_256_tile_kernel(prec, R, N, K, gelu, resid):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("R,N,K,gelu,resid", [(2207, 768, 768, 0, 1), (4500, 2304, 768, 0, 0), (3000, 3072, 768, 1, 0), (1031, 768, 3072, 0, 1),
+                                               (8192, 3072, 16, 1, 0), (130, 1028, 768, 0, 0), (257, 768, 770, 0, 0), (300, 132, 37, 0, 0)])
+def test_fp32_mfma_gemm_is_the_fma_chain(R, N, K, gelu, resid):
+    """fp32 parity mode's GEMM on the matrix cores (gemm_f32_mfma_kernel: v_mfma_f32_32x32x2_f32, 128 x 128 x 32 tiles) against the VALU
+    FMA-chain kernel it replaces (flag 32): the instruction is a k-ascending fmaf chain with one rounding per product, so the two are
+    BIT-IDENTICAL -- ragged token counts, K = 16 (the GMLP tables), K not a multiple of the slab or of 4, an odd K, every epilogue."""
+    rng = np.random.default_rng(R + N + K)
+    act = rng.standard_normal((R, K), dtype=np.float32)
+    W = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal((N,), dtype=np.float32) * 0.1
+    x0 = rng.standard_normal((R, N), dtype=np.float32) if resid else None
+    outs = []
+    for flag in (0, 32):       # 0: the launcher's choice (matrix cores), 32: the VALU kernel
+        out = x0.copy() if resid else np.zeros((R, N), dtype=np.float32)
+        check(lib().umgen_dbg_linear(flag, vp(act), vp(W), fp(bias), R, N, K, gelu, resid, vp(out)))
+        outs.append(out)
+    ref = ref_linear(act, W, bias, gelu, x0)
+    np.testing.assert_allclose(outs[0], ref, atol=2e-5 * max(1.0, np.abs(ref).max()), rtol=0)
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 def ref_attention(q, k, v, H, causal):
     B, Tq, E = q.shape
     D = E // H

@@ -50,6 +50,41 @@ def test_fp32_greedy_rollout_is_token_exact_vs_reference_golden(name):
     e.close()
 
 
+@pytest.mark.parametrize("name", ["tiny_control_greedy", "tiny_boxctl_greedy", "tiny_grow_control_greedy", "tiny_grow_boxctl_greedy"])
+@pytest.mark.parametrize("precision", ["fp32"])
+def test_growing_window_slot_reuse_in_the_foreground_is_token_exact(name, precision, monkeypatch):
+    """SURVEY.md section 8 row f-3, the production form: while the control-mode window still grows (2 -> 6 history frames here, 13 -> 20
+    in configs[2]; infer_fun.py:64-71, UMGen.py:1600-1603) a frame leaves the temporal k | v rows of all its slots in the per-layer slot
+    caches and the next frame pushes only its new last slot through the ego / map / box / TAR stacks -- on the ONE stream the decode
+    engine uses (UMGEN_OVERLAP=0: no masked background stream).  The rollouts recorded from the reference itself (pose + bbox3d control
+    and bbox3d-only control, where the ego stack is cached too) must come out bit for bit, and the reuse must really have happened."""
+    monkeypatch.setenv("UMGEN_OVERLAP", "0")
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
+    cfg = tiny_config().greedy()
+    e = Engine(cfg, precision=precision, max_batch=1, max_cond_frames=cf)
+    e.load_state_dict(synthetic_state_dict(cfg, seed=ws))
+    e.finalize()
+    scene = synthetic_scene(sid, n_frames=icf)
+    init = golden_init_tokens(sid, nf, ctl)
+    out = e.rollout(scene, nf, cond_frames=cf, input_cond_frames=icf, init_tokens=init, control_test=bool(ctl), seeds=[0])
+    reused = e.timings()["overlapped_frames"]
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(out[m], g[f"out_{m}"].astype(np.int64), err_msg=m)
+    assert reused == min(nf - 1, cf - icf), f"{reused} frames reused the slot caches, expected {min(nf - 1, cf - icf)}"
+    # the same rollout with the reuse switched off (every frame recomputes its whole window, like the reference) is the same tokens
+    monkeypatch.setenv("UMGEN_GROW_CACHE", "0")
+    e2 = Engine(cfg, precision=precision, max_batch=1, max_cond_frames=cf)
+    e2.load_state_dict(synthetic_state_dict(cfg, seed=ws))
+    e2.finalize()
+    out2 = e2.rollout(scene, nf, cond_frames=cf, input_cond_frames=icf, init_tokens=init, control_test=bool(ctl), seeds=[0])
+    assert e2.timings()["overlapped_frames"] == 0
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(out2[m], out[m], err_msg=m)
+    e.close()
+    e2.close()
+
+
 def test_fp32_first_frame_activations_match_reference_golden():
     g = np.load(os.path.join(GOLD, "tiny_video_greedy.npz"))
     ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]

@@ -17,7 +17,7 @@ LOGIT_POS = {"map": [0, 1, 511, 1023], "bbox3d": [0, 9, 10, 11, 330, 659], "imag
 COND_ROWS = [0, 1, 4, 5, 6, 500, 1030, 1031, 1032, 1042, 1692, 1693, 1694, 2000, 2206]
 
 
-@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy"])
+@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy", "tiny_grow_boxctl_greedy"])
 def test_oracle_matches_reference_golden(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
@@ -36,7 +36,8 @@ def test_oracle_matches_reference_golden(name):
     for m, pos in LOGIT_POS.items():
         np.testing.assert_allclose(o.trace["logits"][0][m][pos], g[f"logits_{m}"], atol=1e-5, rtol=0)
     # the fixtures must exercise the host-side control flow, not just the transformer
-    assert o.counters.get("rule_blanked", 0) > 0 and o.counters.get("rule_free", 0) > 0
+    if "grow" not in name:      # (the growing-window case is there for the window arithmetic: 2 -> 5 history frames, then it slides)
+        assert o.counters.get("rule_blanked", 0) > 0 and o.counters.get("rule_free", 0) > 0
     if ctl:
         assert o.counters.get("control_resample", 0) > 0
 

@@ -28,10 +28,10 @@ def scenes(n):
     return [{m: np.full((1, 2, CONTENT_LEN[m]), i, dtype=np.int64) for m in MOD_ORDER} for i in range(n)]
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, batch=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = sharded_rollout(fake_rollout, scenes(n), base_seed=100, batch=2, new_frames=3)
+    res = sharded_rollout(fake_rollout, scenes(n), base_seed=100, batch=batch, new_frames=3)
     if rank == 0:
         q.put({m: res[m] for m in MOD_ORDER})
     dist.destroy_process_group()
@@ -57,6 +57,31 @@ def test_two_rank_gloo_sharded_equals_unsharded():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    for m in MOD_ORDER:
+        assert got[m].shape == (n, 5, CONTENT_LEN[m])
+        np.testing.assert_array_equal(got[m], ref[m])
+
+
+@pytest.mark.parametrize("n", [64, 61])
+def test_eight_rank_gloo_partition_of_configs3_equals_unsharded(n):
+    """BASELINE.json configs[3]: 64 independent scenes over 8 ranks, 8 per rank as ONE engine batch (scene i -> rank i mod 8), one
+    all-gather at the end -- and an uneven 61-scene case (ranks 5..7 own 7 scenes: the padded gather and a short last batch).
+    Sharded over 8 gloo ranks == the unsharded one-scene-at-a-time result, token for token (per-scene seeds keyed by scene id)."""
+    ref = sharded_rollout(fake_rollout, scenes(n), base_seed=100, batch=1, new_frames=3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, n, q, 8)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [len(scene_partition(n, 8, r)) for r in range(8)] == [n // 8 + (1 if r < n % 8 else 0) for r in range(8)]
     for m in MOD_ORDER:
         assert got[m].shape == (n, 5, CONTENT_LEN[m])
         np.testing.assert_array_equal(got[m], ref[m])

@@ -98,10 +98,47 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     stamp = LIB_PATH + ".srchash"
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB_PATH
-    cmd = [hipcc_path()] + HIPCC_FLAGS + [f'-DUMGEN_SRC_HASH="{want}"', "-o", LIB_PATH] + srcs
+    # one object per source, cached by the hash of (source, headers, flags) under csrc/.obj/ and compiled in parallel: a one-file
+    # change rebuilds one object + the link instead of the whole library
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr = b"".join(open(os.path.join(CSRC, x), "rb").read() for x in ("common.h", "kernels.h", "frame.h")) + \
+        open(os.path.join(os.path.dirname(HERE), "include", "umgen.h"), "rb").read()
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+    def obj_for(src):
+        extra = [f'-DUMGEN_SRC_HASH="{want}"'] if os.path.basename(src) == "engine.hip" else []     # umgen_version() lives there
+        h = hashlib.sha256(open(src, "rb").read() + hdr + " ".join(cflags + extra).encode()).hexdigest()[:16]
+        return os.path.join(objdir, f"{os.path.basename(src)}.{h}.o"), extra
+
+    def compile_one(src):
+        obj, extra = obj_for(src)
+        if not os.path.exists(obj):
+            t = f"{obj}.{os.getpid()}.tmp"
+            cmd = [hipcc_path()] + cflags + extra + ["-c", src, "-o", t]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=CSRC)
+            os.replace(t, obj)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    keep = set(objs)
+    for f in os.listdir(objdir):                      # objects of older source states
+        if os.path.join(objdir, f) not in keep and f.endswith(".o"):
+            os.remove(os.path.join(objdir, f))
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print(" ".join(cmd), flush=True)
+    try:
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        os.replace(tmp, LIB_PATH)          # atomic: a concurrent rank never maps a half-written library
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     with open(stamp, "w") as f:
         f.write(want + "\n")
     return LIB_PATH
@@ -121,8 +158,16 @@ def build_host_library(force: bool = False) -> str:
     cxx = shutil.which("g++") or shutil.which("c++")
     if not cxx:
         raise RuntimeError("no host C++ compiler (g++) found: cannot build libumgen_host.so")
-    subprocess.run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas", "-x", "c++", src,
-                    "-o", HOST_LIB_PATH], check=True)
+    # several ranks may hit first use together (torchrun): compile to a private file and rename it into place, so that nobody can
+    # CDLL a half-written library
+    tmp = f"{HOST_LIB_PATH}.{os.getpid()}.tmp"
+    try:
+        subprocess.run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas", "-x", "c++", src,
+                        "-o", tmp], check=True)
+        os.replace(tmp, HOST_LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return HOST_LIB_PATH
 
 

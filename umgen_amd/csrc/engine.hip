@@ -96,6 +96,14 @@ struct umgen_engine {
     hipEvent_t ev_tar_done = nullptr, ev_bg_done = nullptr, ev_bg0 = nullptr;
     bool bg_pending = false;
     std::vector<void*> tcache[4];        // per stack, per BlockTAR: [max_batch][max_cond_frames][S_stack][2E] of T
+    // Growing window in the FOREGROUND (control mode starts with 13 history frames and grows to the cap,
+    // infer_fun.py:64-71, UMGen.py:1600-1603): while the window grows, slot t of frame n + 1's window is slot t of frame n's window --
+    // same tokens (the control overwrite of the last bbox3d frame persists, UMGen.py:1465-1467), same tpe row, and every later block
+    // sees it through frame-local spatial sub-blocks and a CAUSAL temporal sub-block (module.py:332-359) -- so a frame that is followed
+    // by a longer window leaves the temporal k | v rows of all its slots in the slot caches (allocated on first use), and the next
+    // frame pushes only its new last slot through the stacks.  No second stream: this is the production path with the decode engine.
+    bool grow_cache = true;              // UMGEN_GROW_CACHE=0: recompute the whole window every frame, like the reference
+    int tcache_state = 0;                // 0 not tried, 1 allocated, -1 does not fit (plain path)
     struct Prefix {
         bool valid = false, has_ego = false;
         int B = 0, P = 0, Tfull = 0;
@@ -136,6 +144,7 @@ struct umgen_engine {
         return es->ok ? es : nullptr;
     }
     double gemm_flops_pending = 0, attn_flops_pending = 0;
+    hipError_t launch_status = hipSuccess;   // first refused kernel launch of the frame (hipGetLastError behind the GEMM launches): fails the frame
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -296,6 +305,8 @@ void gemm_timed(umgen_engine* e, const GemmArgs& a) {
     } else {
         Path<T>::gemm(e->stream, a);
     }
+    // a refused launch (e.g. a dynamic-LDS attribute missing on this device) would leave stale workspace data behind: never silently
+    if (!e->in_capture) { const hipError_t le = hipGetLastError(); if (le != hipSuccess && e->launch_status == hipSuccess) e->launch_status = le; }
 }
 
 // out[tokens R][N] (T) = A[R][K] . W[N][K]^T + bias  (optionally GELU)
@@ -391,7 +402,8 @@ void tar_sub(umgen_engine* e, const SubW& w, int B, int Tn, int S, bool temporal
 }
 
 // cache_mode: 0 = one pass over the whole window; 1 = prefix pass (slots [0, w.T), k | v appended to the slot caches);
-// 2 = last-slot pass (slots [w.t0, w.t0 + w.T) against the caches)
+// 2 = last-slot pass (slots [w.t0, w.t0 + w.T) against the caches); 3 = whole window like 0, and its k | v rows are left in the slot
+// caches for a longer window that follows; 4 = last-slot pass like 2 that appends its own k | v rows (the window keeps growing)
 template <typename T>
 void run_stack(umgen_engine* e, int stack, const WindowTokens& w, int cache_mode = 0) {
     const int S = stack_len(stack);
@@ -401,9 +413,10 @@ void run_stack(umgen_engine* e, int stack, const WindowTokens& w, int cache_mode
     static const bool no_tail = getenv("UMGEN_NO_TAIL") != nullptr;   // measurement: evaluate every block on every frame like the reference
     for (size_t i = 0; i < e->stk[stack].size(); ++i) {
         const TarW& blk = e->stk[stack][i];
-        TemporalRange tr{w.t0, cache_mode ? e->tcache[stack][i] : nullptr, e->cfg.max_cond_frames, cache_mode == 1 ? 1 : 0};
-        // the final block's tail on the last frame only (f-3): whole-window passes with more than one slot
-        const bool last = i + 1 == e->stk[stack].size() && cache_mode == 0 && w.T > 1 && !no_tail;
+        TemporalRange tr{w.t0, cache_mode ? e->tcache[stack][i] : nullptr, e->cfg.max_cond_frames, (cache_mode == 1 || cache_mode >= 3) ? 1 : 0};
+        // the final block's tail on the last frame only (f-3): whole-window passes with more than one slot (the temporal sub-block still
+        // evaluates the k | v rows of every slot, so a pass that fills the slot caches keeps the shortcut)
+        const bool last = i + 1 == e->stk[stack].size() && (cache_mode == 0 || cache_mode == 3) && w.T > 1 && !no_tail;
         tar_sub<T>(e, blk.sub[0], w.B, w.T, S, false);
         tar_sub<T>(e, blk.sub[1], w.B, w.T, S, true, tr, last ? 1 : 0);
         tar_sub<T>(e, blk.sub[2], w.B, w.T, S, false, TemporalRange{0, nullptr, 0, 0}, last ? 2 : 0);
@@ -526,6 +539,25 @@ int oar_layers(umgen_engine* e, int B, int ns) {
     return 0;
 }
 
+// Slot caches of the temporal sub-blocks: per stack and block [max_batch][max_cond_frames][S_stack][2E] of T (10.5 GB per scene for
+// UMGen_Large in 16 bits -- what the 288 GB are for).  Allocated once, at create for the overlapped pass or on the first frame whose
+// window will grow; when they would take more than half of the free memory the engine keeps recomputing the window (tcache_state -1).
+bool ensure_tcache(umgen_engine* e) {
+    if (e->tcache_state) return e->tcache_state > 0;
+    const size_t Bm = e->cfg.max_batch, Tm = e->cfg.max_cond_frames;
+    size_t free_b = 0, total_b = 0, need = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); e->tcache_state = -1; return false; }
+    for (int st = 0; st < 4; ++st) need += e->stk[st].size() * Bm * Tm * (size_t)stack_len(st) * 2 * e->E * e->tsz;
+    if (need > free_b / 2) { e->tcache_state = -1; return false; }
+    for (int st = 0; st < 4; ++st) {
+        e->tcache[st].assign(e->stk[st].size(), nullptr);
+        for (auto& c : e->tcache[st])
+            if (dev_alloc(e, &c, Bm * Tm * (size_t)stack_len(st) * 2 * e->E * e->tsz)) { (void)hipGetLastError(); e->tcache_state = -1; return false; }
+    }
+    e->tcache_state = 1;
+    return true;
+}
+
 struct FrameIO {
     int B, T;
     const int *pose, *map, *box, *img;          // host window tokens [B][T][S_mod] (box already control-overwritten)
@@ -543,7 +575,7 @@ struct FrameIO {
 // Does the prefix pass that ran beside the previous frame's decode cover exactly this window's slots 0..P-1 ?
 bool prefix_matches(const umgen_engine* e, const FrameIO& io) {
     const umgen_engine::Prefix& px = e->px;
-    if (!e->overlap || !px.valid || io.trace || io.B != px.B || io.T != px.Tfull || px.P != io.T - 1 || px.P < 1) return false;
+    if (!px.valid || io.trace || io.B != px.B || io.T != px.Tfull || px.P != io.T - 1 || px.P < 1) return false;
     if (!io.ctrl_pose && !px.has_ego) return false;
     const int S[4] = {kNPose, kNMap, kNBox, kNImg};
     const int* cur[4] = {io.pose, io.map, io.box, io.img};
@@ -678,6 +710,7 @@ template <typename T>
 int run_frame(umgen_engine* e, const FrameIO& io) {
     const int E = e->E, B = io.B, Tn = io.T;
     hipStream_t const fg = e->stream;   // the decode stream of overlapped rollouts (6 of the 8 XCDs when the overlap exists)
+    e->launch_status = hipSuccess;
     struct RestoreStream { umgen_engine* e; hipStream_t s; ~RestoreStream() { e->stream = s; e->set_work(e->w_main); } } restore{e, fg};
     hipStream_t st = fg;
     SamplerParams sp{io.smp->method, io.smp->top_k, io.smp->top_k_map, io.smp->topk_image, io.smp->p, io.smp->p_map, io.smp->temperature,
@@ -729,7 +762,11 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     HIPCHK(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(int), st));
     HIPCHK(e, hipMemsetAsync(e->d_nboxes, 0, (size_t)B * sizeof(int), st));
 
-    const int t0 = use_px ? Tn - 1 : 0, Tc = use_px ? 1 : Tn, cmode = use_px ? 2 : 0;
+    // foreground growing-window reuse (f-3): the next frame's window is this one plus one slot (it grows, it does not slide), so this
+    // frame's passes leave their temporal k | v rows in the slot caches
+    const bool fg_write = !e->overlap && e->grow_cache && io.next_follows && io.cond_cap > 0 && Tn + 1 <= io.cond_cap &&
+                          Tn + 1 <= e->cfg.max_cond_frames && !tr && ensure_tcache(e);
+    const int t0 = use_px ? Tn - 1 : 0, Tc = use_px ? 1 : Tn, cmode = use_px ? (fg_write ? 4 : 2) : (fg_write ? 3 : 0);
     e->px.valid = false;
     WindowTokens w{e->d_pose, e->d_map, e->d_box, e->d_img, B, Tc, Tn, t0};
     // Step 1: ego pose tokens (UMGen.py:1440-1455)
@@ -767,7 +804,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     }
     // Hand-off tags of the decode engine never repeat while a copy of an old granule can survive anywhere (a group's L2 keeps its
     // plain-stored granules across launches): the epoch runs on monotonically over the engine's lifetime.  Before the 32-bit
-    // counter would wrap (~470 frames) everything is drained and the granule buffers are cleared.
+    // counter would wrap (~100 frames at 16384 tags per step) everything is drained and the granule buffers are cleared.
     if (e->eng_enabled && e->eng_epoch > 0xE0000000u) {
         HIPCHK(e, hipDeviceSynchronize());
         HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
@@ -811,6 +848,16 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     }
     if (tr && tr->cond) HIPCHK(e, hipMemcpyAsync(tr->cond, e->cond, (size_t)kSeq * E * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipEventRecord(e->ev[2], st));
+    if (fg_write) {   // the slot caches now hold slots 0 .. Tn-1 of this window: what the next frame must find unchanged (prefix_matches)
+        umgen_engine::Prefix& px = e->px;
+        px.B = B; px.P = Tn; px.Tfull = Tn + 1; px.has_ego = !io.ctrl_pose;
+        px.pose.assign(io.pose, io.pose + (size_t)B * Tn * kNPose);
+        px.map.assign(io.map, io.map + (size_t)B * Tn * kNMap);
+        px.box.assign(io.box, io.box + (size_t)B * Tn * kNBox);
+        px.img.assign(io.img, io.img + (size_t)B * Tn * kNImg);
+        px.pose_next.assign(ego.begin(), ego.end());   // slot Tn-1 was evaluated with the new frame's pose (the shift of UMGen.py:1445-1452)
+        px.valid = true;
+    }
 
     // Step 3: OAR decode loop (infer_oar_net, UMGen.py:1151-1273).  Step j consumes scene position j (KV length j) and
     // emits scene token j; j = 0..4 replays the given pose prefix, bos/eos are fixed, everything else is sampled.
@@ -898,6 +945,11 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     unsigned eng_err = 0;
     if (eng) HIPCHK(e, hipMemcpyAsync(&eng_err, e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
+    {
+        const hipError_t le = e->launch_status != hipSuccess ? e->launch_status : hipGetLastError();
+        e->launch_status = hipSuccess;
+        if (le != hipSuccess) return e->fail(UMGEN_E_HIP, "a kernel launch of this frame was refused: %s", hipGetErrorString(le));
+    }
     if (eng_err) {   // a hand-off of the decode engine timed out (e.g. two engines sharing one GPU): never return tokens from such a frame
         (void)hipMemset(e->eng_err, 0, sizeof(unsigned));
         return e->fail(UMGEN_E_HIP, "decode engine gave up waiting for hand-off tag 0x%08x (is another persistent kernel using this GPU?)", eng_err);
@@ -1108,6 +1160,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return e->fail(UMGEN_E_HIP, "no HIP device visible: libumgen_hip has no CPU fallback");
     HIPCHK(e, hipSetDevice(cfg->device));
+    HIPCHK(e, gemm256_prepare());   // per device: dynamic-LDS attribute + CU count of the 256 x 256 GEMM (a second GPU in one process gets its own)
     // overlapped TAR pass (UMGEN_OVERLAP=0 disables it): the decode stream and the background stream get disjoint CU masks --
     // measured on MI355X, a decode loop sharing CUs with a concurrent GEMM stream runs at a quarter of its speed, with disjoint
     // masks (64 background CUs) it loses 8 %
@@ -1303,8 +1356,25 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     e->conc_stacks = !e->overlap && (cs_env ? cs_env[0] != '0' : true);
     if (e->overlap || e->conc_stacks) {   // 1-slot (overlap) / whole-window (concurrent stacks) workspaces + streams
         const size_t slots = e->overlap ? 1 : Tm;
-        const size_t R1 = Bm * slots * kSeq;
+        // the side workspaces hold the map stack (1031 rows per frame) and the box stack (1693), not 2207; when they do not fit beside
+        // the main workspace and the caches (a large max_batch), the stacks simply run one behind the other on one stream
+        const int side_len[2] = {stack_len(STACK_MAP), stack_len(STACK_BOX)};
+        size_t need = 0, free_b = 0, total_b = 0;
+        for (int i = 0; i < 2; ++i)
+            need += Bm * slots * ((size_t)side_len[i] * E * (4 + 8 * e->tsz) + (size_t)E * e->S_pad * e->tsz + (size_t)kNMap * E * 4);
+        HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
+        const size_t kv_need = (size_t)cfg->n_oar_layer * Bm * (size_t)e->Lmax * 2 * E * e->tsz;
+        if (!e->overlap && need + kv_need > free_b - free_b / 8) {
+            e->conc_stacks = false;
+            fprintf(stderr, "[umgen] note: %.1f GB of side workspaces for the concurrent map / box stacks do not fit (%.1f GB free): the three TAR stacks run "
+                            "one behind the other\n", (double)need / 1e9, (double)free_b / 1e9);
+        }
+    }
+    if (e->overlap || e->conc_stacks) {
+        const size_t slots = e->overlap ? 1 : Tm;
+        const int side_len[2] = {stack_len(STACK_MAP), stack_len(STACK_BOX)};
         for (int i = 0; i < 2; ++i) {
+            const size_t R1 = Bm * slots * (size_t)(e->overlap ? kSeq : side_len[i]);
             umgen_engine::Work& w = e->w_side[i];
             if (int rc = dalloc(e, &w.X, R1 * E)) return rc;
             if (int rc = dev_alloc(e, &w.A, R1 * E * e->tsz)) return rc;
@@ -1341,21 +1411,10 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         if (int rc = dev_alloc(e, &e->vtcache, (size_t)cfg->n_oar_layer * e->vt_layer_stride * e->tsz)) return rc;
         HIPCHK(e, hipMemset(e->vtcache, 0, (size_t)cfg->n_oar_layer * e->vt_layer_stride * e->tsz));
     }
-    if (e->overlap) {   // slot caches of the overlapped TAR pass: k | v rows of every temporal sub-block, all history slots
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
-        size_t need = 0;
-        for (int st = 0; st < 4; ++st) need += e->stk[st].size() * Bm * Tm * (size_t)stack_len(st) * 2 * E * e->tsz;
-        if (need > free_b / 2) {
-            e->overlap = false;     // keep the plain path rather than crowding the KV caches out
-        } else {
-            for (int st = 0; st < 4; ++st) {
-                e->tcache[st].resize(e->stk[st].size(), nullptr);
-                for (auto& c : e->tcache[st])
-                    if (int rc = dev_alloc(e, &c, Bm * Tm * (size_t)stack_len(st) * 2 * E * e->tsz)) return rc;
-            }
-        }
-    }
+    // slot caches of the overlapped TAR pass: k | v rows of every temporal sub-block, all history slots (the foreground's growing-window
+    // reuse allocates the same caches on first use, run_frame)
+    if (e->overlap && !ensure_tcache(e)) e->overlap = false;     // keep the plain path rather than crowding the KV caches out
+    if (const char* gc = getenv("UMGEN_GROW_CACHE")) e->grow_cache = gc[0] != '0';
     if (int rc = dalloc(e, &e->d_pose, Bm * Tm * 3)) return rc;
     if (int rc = dalloc(e, &e->d_pose_shift, Bm * Tm * 3)) return rc;
     if (int rc = dalloc(e, &e->d_map, Bm * Tm * kNMap)) return rc;
@@ -1417,19 +1476,19 @@ int umgen_load_tensor(umgen_engine* e, const char* key, const void* data, int32_
         std::vector<f16_t> h(n);
         if (dtype == UMGEN_DT_F16) memcpy(h.data(), data, n * 2);
         else {
-            float amax = 0.f;                                   // (no early exit in the conversion loop: it stays vectorisable)
+            unsigned overflow = 0;                              // (no early exit in the conversion loop: it stays vectorisable)
             for (size_t i = 0; i < n; ++i) {
                 const float v = load_as_f32(data, dtype, i);
-                const float av = std::fabs(v);
-                amax = (av <= 3.4e38f && av > amax) ? av : amax;   // finite values only
                 const uint16_t hb = f32_to_f16_bits_host(v);
+                // the CONVERTED value decides, like torch's .half(): (65504, 65520) still rounds to 65504, only >= 65520 becomes inf
+                overflow |= (unsigned)(((hb & 0x7fffu) == 0x7c00u) & (std::fabs(v) <= 3.4e38f));
                 memcpy(&h[i], &hb, 2);
             }
-            if (amax > 65504.f) {                               // would become inf: refuse rather than decode garbage
+            if (overflow) {                                     // a finite weight would become inf: refuse rather than decode garbage
                 for (size_t i = 0; i < n; ++i) {
                     const float v = load_as_f32(data, dtype, i);
-                    if (std::isfinite(v) && std::fabs(v) > 65504.f)
-                        return e->fail(UMGEN_E_INVALID, "%s[%zu] = %g does not fit fp16 (precision fp16 needs |w| <= 65504)", key, i, (double)v);
+                    if (std::isfinite(v) && (f32_to_f16_bits_host(v) & 0x7fffu) == 0x7c00u)
+                        return e->fail(UMGEN_E_INVALID, "%s[%zu] = %g does not fit fp16 (precision fp16 needs |w| < 65520)", key, i, (double)v);
                 }
             }
         }
@@ -1498,6 +1557,7 @@ int umgen_finalize_weights(umgen_engine* e) {
                  : e->cfg.precision == UMGEN_PREC_FP16 ? build_tables<f16_t>(e) : build_tables<float>(e);
     if (rc) return rc;
     if (e->eng_enabled) { if (int rc2 = repack_mlp_proj(e)) return rc2; }
+    e->px.valid = false;   // slot caches filled with other weights are not a prefix of anything
     e->finalized = true;
     return UMGEN_OK;
 }

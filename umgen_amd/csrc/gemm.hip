@@ -552,6 +552,130 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fp32 on the matrix cores (parity mode): v_mfma_f32_32x32x2_f32 is bit-for-bit the k-ascending fmaf chain of gemm_valu_kernel
+// (one rounding per product, no wider accumulator: MI355X guide, "FP32-input MFMA"), at the fp32 vector peak from one wave per
+// SIMD -- the VALU kernel reaches a seventh of that (21 TFLOP/s in the TAR stacks).  128 x 128 x 32 tiles, 4 waves (2 x 2), each
+// wave 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs); operands staged k-major in LDS ([k][row], so that the A / B fragments --
+// lane l: row l % 32, k = l / 32 -- are conflict-free 4-byte reads), next slab prefetched into registers, two LDS buffers.
+// Same k order and same epilogue as gemm_valu_kernel => identical bits (tests/test_gpu_kernels.py::test_fp32_mfma_gemm_is_the_fma_chain).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FM = 128, FK = 32, FLD = FM + 4;
+template <int MODE, typename TO>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float sP[2][FK][FLD];
+    __shared__ __attribute__((aligned(16))) float sQ[2][FK][FLD];
+    const int z = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i_base = blockIdx.x * FM, j_base = blockIdx.y * FM;
+    const float* P = reinterpret_cast<const float*>(a.P) + (long)z * a.strideP;
+    const float* Q = reinterpret_cast<const float*>(a.Q) + (long)z * a.strideQ;
+    const int lr = tid >> 3, lk = (tid & 7) * 4;     // staging: rows lr + 32 it, k offset lk .. lk + 3
+    const bool k4 = (a.K % 4 == 0) && (a.ldp % 4 == 0) && (a.ldq % 4 == 0);
+    float4 rp[4], rq[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int gi = min(i_base + lr + 32 * it, a.Mi - 1), gj = min(j_base + lr + 32 * it, a.Nj - 1);
+            const float* pp = P + (long)gi * a.ldp + k0 + lk;
+            const float* qq = Q + (long)gj * a.ldq + k0 + lk;
+            if (k4 && k0 + lk + 3 < a.K) {
+                rp[it] = *reinterpret_cast<const float4*>(pp);
+                rq[it] = *reinterpret_cast<const float4*>(qq);
+            } else {
+                float tp[4], tq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = k0 + lk + e < a.K;
+                    tp[e] = in ? pp[e] : 0.f;
+                    tq[e] = in ? qq[e] : 0.f;
+                }
+                rp[it] = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                rq[it] = make_float4(tq[0], tq[1], tq[2], tq[3]);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = lr + 32 * it;
+            sP[buf][lk + 0][r] = rp[it].x; sP[buf][lk + 1][r] = rp[it].y; sP[buf][lk + 2][r] = rp[it].z; sP[buf][lk + 3][r] = rp[it].w;
+            sQ[buf][lk + 0][r] = rq[it].x; sQ[buf][lk + 1][r] = rq[it].y; sQ[buf][lk + 2][r] = rq[it].z; sQ[buf][lk + 3][r] = rq[it].w;
+        }
+    };
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int l32 = lane & 31, lk2 = lane >> 5;
+    int buf = 0;
+    for (int k0 = 0; k0 < a.K; k0 += FK) {
+        const bool more = k0 + FK < a.K;
+        if (more) fetch(k0 + FK);
+        const int kmax = min(FK, a.K - k0);          // k beyond K is never multiplied (an odd tail's partner is a zero product)
+        for (int kk = 0; kk < kmax; kk += 2) {
+            const float a0 = sP[buf][kk + lk2][wi * 64 + l32], a1 = sP[buf][kk + lk2][wi * 64 + 32 + l32];
+            const float b0 = sQ[buf][kk + lk2][wj * 64 + l32], b1 = sQ[buf][kk + lk2][wj * 64 + 32 + l32];
+#if defined(__HIP_DEVICE_COMPILE__)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#endif
+        }
+        if (more) {
+            stash(buf ^ 1);       // the other buffer: its last readers passed the barrier at the end of the previous slab
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // C layout of the 32 x 32 tile: column (j) = lane % 32, row (i) = 8 (reg / 4) + 4 (lane / 32) + reg % 4
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i0 = i_base + wi * 64 + m * 32 + 8 * q + 4 * lk2;
+                const int j = j_base + wj * 64 + n * 32 + l32;
+                float v[4] = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+                epilogue4<MODE, TO>(a, z, i0, j, v);
+            }
+}
+
+static bool use_f32_mfma() {
+    static const bool on = !(getenv("UMGEN_FP32_MFMA") && getenv("UMGEN_FP32_MFMA")[0] == '0');   // 0: the VALU FMA-chain kernel (A/B, tests)
+    return on;
+}
+
+template <>
+void launch_gemm_valu<float, float>(hipStream_t s, const GemmArgs& a) {
+    if (use_f32_mfma() && a.tile256 >= 0 && a.Mi % 4 == 0) {
+        dim3 grid((a.Mi + FM - 1) / FM, (a.Nj + FM - 1) / FM, a.batch), block(256);
+        switch (a.mode) {
+            case GEMM_STORE: hipLaunchKernelGGL((gemm_f32_mfma_kernel<GEMM_STORE, float>), grid, block, 0, s, a); break;
+            case GEMM_RESID: hipLaunchKernelGGL((gemm_f32_mfma_kernel<GEMM_RESID, float>), grid, block, 0, s, a); break;
+            case GEMM_STORE_F32: hipLaunchKernelGGL((gemm_f32_mfma_kernel<GEMM_STORE_F32, float>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((gemm_f32_mfma_kernel<GEMM_VT, float>), grid, block, 0, s, a); break;
+        }
+        return;
+    }
+    dim3 grid((a.Mi + 63) / 64, (a.Nj + 63) / 64, a.batch), block(256);
+    switch (a.mode) {
+        case GEMM_STORE: hipLaunchKernelGGL((gemm_valu_kernel<GEMM_STORE, float, float, float>), grid, block, 0, s, a); break;
+        case GEMM_RESID: hipLaunchKernelGGL((gemm_valu_kernel<GEMM_RESID, float, float, float>), grid, block, 0, s, a); break;
+        case GEMM_STORE_F32: hipLaunchKernelGGL((gemm_valu_kernel<GEMM_STORE_F32, float, float, float>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((gemm_valu_kernel<GEMM_VT, float, float, float>), grid, block, 0, s, a); break;
+    }
+}
+
 template <typename TP, typename TQ>
 void launch_gemm_valu(hipStream_t s, const GemmArgs& a) {
     dim3 grid((a.Mi + 63) / 64, (a.Nj + 63) / 64, a.batch), block(256);
@@ -563,7 +687,6 @@ void launch_gemm_valu(hipStream_t s, const GemmArgs& a) {
         default: hipLaunchKernelGGL((gemm_valu_kernel<GEMM_VT, TP, TQ, TP>), grid, block, 0, s, a); break;
     }
 }
-template void launch_gemm_valu<float, float>(hipStream_t, const GemmArgs&);
 template void launch_gemm_valu<bf16_t, float>(hipStream_t, const GemmArgs&);   // bf16 weights x fp32 activations (tables)
 template void launch_gemm_valu<bf16_t, bf16_t>(hipStream_t, const GemmArgs&);
 template void launch_gemm_valu<f16_t, float>(hipStream_t, const GemmArgs&);

@@ -303,7 +303,17 @@ bool gemm256_supported(const GemmArgs& a) {
     return true;
 }
 
+// Per DEVICE, before the first launch there (umgen_create / umgen_vq_create call it behind hipSetDevice): the 160 KB dynamic-LDS
+// attribute applies to the current device only, and the persistent grid is one workgroup per CU of THAT device.
+static int g_ncu256[64] = {};
 hipError_t gemm256_prepare() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t rc0 = hipGetDevice(&dev);
+    if (rc0 != hipSuccess) return rc0;
+    rc0 = hipGetDeviceProperties(&prop, dev);
+    if (rc0 != hipSuccess) return rc0;
+    if (dev >= 0 && dev < 64) g_ncu256[dev] = (prop.multiProcessorCount / 8) * 8;
     const void* fns[] = {
         reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE, bf16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_RESID, bf16_t>),
         reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE_F32, bf16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE, f16_t>),
@@ -317,16 +327,11 @@ hipError_t gemm256_prepare() {
 
 template <typename TT>
 void launch_gemm256(hipStream_t s, const GemmArgs& a) {
-    static int n_cu = 0;
-    static bool prepared = false;
-    if (!prepared) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        n_cu = (n_cu / 8) * 8;
-        (void)gemm256_prepare();
-        prepared = true;
-    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!g_ncu256[dev]) (void)gemm256_prepare();   // a caller that skipped the per-device prepare (debug hooks): do it here, for this device
+    const int n_cu = g_ncu256[dev] ? g_ncu256[dev] : 256;
     const int nI = a.Mi / TM, nJ = (a.Nj + TM - 1) / TM;
     // feature split over the XCDs only when the weight matrix would not stay in one 4 MB L2 and the feature tiles divide evenly
     const int splitI = (nI % 2 == 0 && (size_t)a.Mi * a.K * 2 > (size_t)(3u << 20)) ? 2 : 1;

@@ -297,6 +297,7 @@ int umgen_vq_create(const umgen_vq_config* cfg, umgen_vq** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return e->fail(UMGEN_E_HIP, "no HIP device visible: libumgen_hip has no CPU fallback");
     VQCHK(e, hipSetDevice(cfg->device));
+    VQCHK(e, gemm256_prepare());   // per device (the decoder's convolutions are this library's GEMMs)
     VQCHK(e, hipStreamCreate(&e->stream));
     const int L = cfg->n_levels;
     // Decoder.__init__ (vq_modules.py:294-383)
