@@ -33,19 +33,43 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak
 
 
+PMC_FILES = ["r04_pmc_fetch_size_engine.csv", "r03_pmc_fetch_size_engine.csv"]   # newest first
+
+
 def pmc_traffic_per_launch(engine_on: bool):
-    """HBM bytes per launch of the dominant kernel (oar_engine_kernel) from the committed rocprofv3 PMC pass of this round
-    (tools/round3_measure.sh: `rocprofv3 --pmc FETCH_SIZE`, decode steps 1101..1104 only via UMGEN_DEBUG_OAR_STEPS, i.e. at the MEAN
-    KV length of a frame -- the same L the algorithmic bytes per launch are quoted at; mean FETCH_SIZE [KB] x 2 = the gfx950
-    correction of MI355X_MICROARCH.md for wide streaming reads).  PMC serialises every dispatch, so it cannot be collected inside
-    the timed region; null when the file is absent or the engine did not run."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_fetch_size_engine.csv")
-    if not engine_on or not os.path.exists(path):
-        return None
-    for line in open(path).read().splitlines()[1:]:
-        name, _, rest = line.rpartition('",')
-        if "oar_engine_kernel" in name:
-            return float(rest.split(",")[2]) * 2.0 * 1024.0
+    """(HBM bytes per launch of the dominant kernel, source) from the newest committed rocprofv3 PMC pass (tools/gpu_session.sh pmc:
+    `rocprofv3 --pmc FETCH_SIZE`, decode steps 1101..1104 only via UMGEN_DEBUG_OAR_STEPS, i.e. at the MEAN KV length of a frame --
+    the same L the algorithmic bytes per launch are quoted at; mean FETCH_SIZE [KB] x 2 = the gfx950 correction of
+    MI355X_MICROARCH.md for wide streaming reads).  PMC serialises every dispatch, so it is a separate pass and NOT a measurement of
+    this run: `roofline.traffic_source` says which file the number comes from.  (None, None) when absent or the engine did not run."""
+    if not engine_on:
+        return None, None
+    for fn in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        for line in open(path).read().splitlines()[1:]:
+            name, _, rest = line.rpartition('",')
+            if "oar_engine_kernel" in name:
+                return float(rest.split(",")[2]) * 2.0 * 1024.0, f"profiles/{fn} (separate rocprofv3 --pmc FETCH_SIZE pass at KV length 1101..1104, x2 gfx950 correction; not measured in this run)"
+    return None, None
+
+
+def closed_loop_record(precision: str):
+    """Greedy closed-loop token agreement of the timed precision with the fp32 engine (frames 0 / 2 / 8), from the newest committed
+    tools/closed_loop.py run -- a 30-frame fp32 rollout does not fit a bench run; `source` names the file."""
+    for fn in ("r04_closed_loop.json", "r03_closed_loop.json"):
+        path = os.path.join(ROOT, "profiles", fn)
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path)).get(precision)
+                if d:
+                    ag = d.get("per_frame_token_agreement") or []
+                    return {"vs": "fp32 engine, greedy, same weights / scene", "frame0": ag[0] if len(ag) > 0 else None,
+                            "frame2": ag[2] if len(ag) > 2 else None, "frame8": ag[8] if len(ag) > 8 else None,
+                            "first_divergence": d.get("first_divergence"), "source": f"profiles/{fn} (not measured in this run)"}
+            except Exception:
+                pass
     return None
 
 
@@ -83,18 +107,18 @@ def cpu_baseline(cfg_name: str, threads: int):
               "what": ("oracle/umgen_oracle.py (PyTorch-CPU fp32): 1 BlockTAR at S=1031/1693/2207 x T=20 "
                        f"({t_blk[1031]:.1f}/{t_blk[1693]:.1f}/{t_blk[2207]:.1f} s) + 16 BlockOAR steps at L=1100 "
                        f"({t_oar * 1e3:.2f} ms/step), scaled by UMGen_Large block/step counts -> {frame_s:.0f} s/frame")}
-    fp = os.path.join(ROOT, "profiles", "r02_cpu_baseline_full.json")
-    if cfg_name == "large" and os.path.exists(fp):
-        # The MEASURED baseline: tools/cpu_baseline_full.py ran the oracle over 2 whole UMGen_Large frames on a GPU box's host
-        # (32 threads, median of 3 runs; SURVEY.md section 8d protocol; ~30 min per run, so it is run once, not inside every bench).
-        # `value` is that measurement; the bounded sample timed in THIS run is kept beside it as a drift check.
-        full = json.load(open(fp))
-        return {"value": full["scene_tokens_per_s"], "unit": "scene-tokens/s", "cores": full.get("torch_num_threads", threads), "kind": "port",
-                "sample": (f"oracle/umgen_oracle.py, 2 whole UMGen_Large frames (video, T=20), median of {len(full.get('seconds_per_run', []))} runs: "
-                           f"{full.get('median_s', 0):.0f} s for 2 frames (profiles/r02_cpu_baseline_full.json)"),
-                "bounded_sample_this_run": sample}
-    return {"value": sample["value"], "unit": "scene-tokens/s", "cores": threads, "kind": "port", "extrapolated_from_sample": True,
-            "sample": sample["what"]}
+    res = {"value": sample["value"], "unit": "scene-tokens/s", "cores": threads, "kind": "port", "measured_in": "this run",
+           "extrapolated_from_sample": True, "sample": sample["what"]}
+    for fn in ("r04_cpu_baseline_full.json", "r02_cpu_baseline_full.json"):
+        fp = os.path.join(ROOT, "profiles", fn)
+        if cfg_name == "large" and os.path.exists(fp):
+            # whole-frame measurement of the same oracle on a GPU box's host (tools/cpu_baseline_full.py; SURVEY.md section 8d protocol):
+            # ~15 min per frame, so it is a separate run, quoted beside the bounded sample this run timed -- never in place of it
+            full = json.load(open(fp))
+            res["whole_frame_measurement"] = {"value": full["scene_tokens_per_s"], "unit": "scene-tokens/s", "cores": full.get("torch_num_threads"),
+                                              "protocol": full.get("protocol"), "source": f"profiles/{fn} (cached measurement, not this run)"}
+            break
+    return res
 
 
 def main():
@@ -109,6 +133,9 @@ def main():
     ap.add_argument("--history", type=int, default=20, help="history frames T (configs[4]: 40 = doubled context)")
     ap.add_argument("--task", default="video", choices=["video", "control"],
                     help="control: ego pose + one agent slot of every new frame given (configs[2] with --batch 4); the bench line is video")
+    ap.add_argument("--input-history", type=int, default=0,
+                    help="history frames the rollout STARTS with (0 = the reference's setting: --history for video, 13 for control, "
+                         "infer_fun.py:64-71 -- the control window then grows 13 -> 20 before it slides)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     args = ap.parse_args()
@@ -132,6 +159,7 @@ def main():
     if os.environ.get("UMGEN_BENCH_OAR_LAYERS"):      # experiment knob (not a bench configuration)
         cfg.n_oar_layer = int(os.environ["UMGEN_BENCH_OAR_LAYERS"])
     T = min(args.history, cfg.max_frame_len - 1)
+    T_in = min(T, args.input_history if args.input_history > 0 else (13 if args.task == "control" else T))
     B = args.batch
     eng = Engine(cfg, precision=args.precision, max_batch=B, max_cond_frames=T, device=local_rank, use_graphs=not args.no_graphs)
     t_load = time.perf_counter()
@@ -154,7 +182,7 @@ def main():
         return {"init_tokens": {k: np.concatenate([c[k] for c in ctl]) for k in ("pose", "bbox3d")}, "control_test": True}
 
     def rollout_fn(toks, seeds, new_frames, scene_ids=None):
-        return eng.rollout(toks, new_frames, cond_frames=T, input_cond_frames=T, seeds=seeds,
+        return eng.rollout(toks, new_frames, cond_frames=T, input_cond_frames=T_in, seeds=seeds,
                            **control_of(scene_ids if scene_ids is not None else mine, new_frames))
 
     def sync():
@@ -206,6 +234,7 @@ def main():
         layers_us = tp["layers_ms"] * 1e3 / max(1, tp["layers_launches"])
         ach = layer_bytes / (layers_us * 1e-6) / 1e9 if layers_us > 0 else 0.0
         oar_gbs = (tm["oar_bytes"] / (tm["oar_ms"] * 1e-3) / 1e9) if tm["oar_ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_per_launch(engine_on and B == 1 and args.config == "large")
         kname = ("umgen::oar_engine_kernel (XCD-resident decode engine: the 36 BlockOAR layers of a decode step in one launch)" if engine_on else
                  "OAR decode layers as launches (gemv_ln_kernel x72, attn_partial_kernel x36, gemv_resid_kernel x72 per step)")
         res = {
@@ -214,17 +243,19 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic tokenized_origin_scenes-shaped tokens; random-init weights (no checkpoint offline)",
             "config": {"workload": f"UMGen_{args.config} --infer_task {args.task}, {args.steps}-frame rollout, "
-                                   f"{B} scene(s)/GPU, T={T} history frames, top-k 5/5/16 sampling, rule_constrain",
-                       "scenes_per_gpu": B, "history_frames": T, "sec_per_frame": dt / args.steps},
+                                   f"{B} scene(s)/GPU, T={T} history frames" + (f" (starting from {T_in})" if T_in != T else "") +
+                                   ", top-k 5/5/16 sampling, rule_constrain",
+                       "scenes_per_gpu": B, "history_frames": T, "input_history_frames": T_in, "sec_per_frame": dt / args.steps},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_per_launch(engine_on and B == 1 and args.config == "large"), "kernel": kname,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
                          "avg_launch_us": layers_us, "launches_timed": tp["layers_launches"],
                          "algorithmic_bytes_per_launch": layer_bytes, "scenes_per_launch": B,
                          # the whole decode step (layer kernel + head GEMV + sampler, replayed from a hipGraph), timed region:
                          "step": {"avg_step_us": step_us, "algorithmic_bytes_per_step": bytes_per_step, "achieved": oar_gbs,
                                   "frac": oar_gbs / HBM_PEAK_GBS, "kernels_per_step": tm["oar_kernels"] / steps_total}},
             "roofline_gemm": {"bound": "mfma", "achieved": gemm_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                              "frac": gemm_tfs / MFMA_BF16_PEAK_TFS, "kernel": "gemm_bf16_pers_kernel / gemm_bf16_glds_kernel (TAR / ego stacks)",
+                              "frac": gemm_tfs / MFMA_BF16_PEAK_TFS, "kernel": ("gemm16_256_kernel (256 x 256 tiles; launches under 300 tiles: gemm_bf16_pers_kernel / gemm_bf16_glds_kernel), TAR / ego stacks"
+                                         if args.precision != "fp32" else "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32), TAR / ego stacks"),
                               "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(1, tm["gemm_launches"])},
             "roofline_attn": {"bound": "mfma", "achieved": attn_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
                               "frac": attn_tfs / MFMA_BF16_PEAK_TFS, "kernel": "attn_spatial_mfma_kernel",
@@ -233,9 +264,12 @@ def main():
             # second stream while the decode loop runs (only with UMGEN_OVERLAP=1, i.e. without the engine)
             "phases_ms_per_frame": {"ego": tm["ego_ms"] / frames, "tar": tm["tar_ms"] / frames, "oar": tm["oar_ms"] / frames,
                                     "background_per_pass": tm["bg_ms"] / max(1, tm["overlapped_frames"]),
-                                    "overlapped_frames": tm["overlapped_frames"]},
+                                    "overlapped_frames": tm["overlapped_frames"],
+                                    # frames that pushed only their new last slot through the stacks (growing window, slot caches: f-3)
+                                    "frames_reusing_slot_caches": tm["overlapped_frames"]},
             "prefill_ms_unoverlapped": {"ego": tp["ego_ms"], "tar": tp["tar_ms"]},
             "weight_load_s": t_load,
+            "closed_loop": closed_loop_record(args.precision) if args.config == "large" else None,
             "decode_engine": int(engine_on), "engine_fallback": int(tm["engine_fallback"]),
         }
         if tm["engine_fallback"]:

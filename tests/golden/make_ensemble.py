@@ -1,6 +1,6 @@
 """Accumulation-order ensemble of the rounding-aware oracle: the noise floor the 16-bit engine modes are bounded by.
 
-    python tests/golden/make_ensemble.py [tiny] [full_width] [--modes bf16_engine fp16_engine] [--members 8]
+    python tests/golden/make_ensemble.py [tiny] [full_width] [deep] [--modes bf16_engine fp16_engine] [--members 8]
         ->  tests/golden/ensemble_<width>_<mode>.npz
 
 The rounding-aware oracle (oracle/umgen_oracle.py, weight_dtype="bf16_engine" / "fp16_engine") rounds to 16 bits wherever the
@@ -87,6 +87,8 @@ def main(width, mode, members):
 
 
 if __name__ == "__main__":
+    import torch
+    torch.set_num_threads(int(os.environ.get("UMGEN_GOLDEN_THREADS", "8")))
     ap = argparse.ArgumentParser()
     ap.add_argument("widths", nargs="*", default=["tiny", "full_width"])
     ap.add_argument("--modes", nargs="*", default=["bf16_engine", "fp16_engine"])

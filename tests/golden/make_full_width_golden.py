@@ -1,7 +1,8 @@
-"""Golden vectors at the production WIDTH (E=768, H=16, all vocabularies at production size, one layer per stack) from the CPU
+"""Golden vectors at the production WIDTH (E=768, H=16, all vocabularies at production size; one block per stack and two BlockOAR
+layers, or -- "deep" -- two blocks per stack and ten BlockOAR layers) from the CPU
 oracle, so that the -m gpu tests do not spend minutes of GPU-box time re-running the oracle:
 
-    python tests/golden/make_full_width_golden.py [full_width] [wide2x]   ->  tests/golden/{full_width,wide2x}_{fp32,bf16_engine}.npz
+    python tests/golden/make_full_width_golden.py [full_width] [wide2x] [deep] [--mode=fp32]   ->  tests/golden/{full_width,wide2x,deep}_{fp32,bf16_engine}.npz
 
 fp32: the oracle in the reference's semantics (itself pinned on the reference goldens, tests/test_oracle.py);
 bf16_engine: the rounding-aware restatement of the engine's production mode (oracle/umgen_oracle.py header).
@@ -26,9 +27,19 @@ COND_ROWS = [0, 1, 4, 5, 6, 7, 100, 500, 1029, 1030, 1031, 1032, 1042, 1043, 140
 LOGIT_POS = {"map": [0, 1, 2, 511, 512, 1022, 1023], "bbox3d": [0, 9, 10, 11, 330, 658, 659], "image": [0, 1, 255, 510, 511]}
 
 
+# "deep": production width with SEVERAL layers per stack -- 2 blocks in every TAR stack and in the ego decoder, 10 BlockOAR layers: the
+# decode engine's layer -> XCD-group rotation wraps (layers 8, 9 run on groups 0, 1 again), the x vector crosses the fabric nine times,
+# and the TAR stacks chain a second block behind the first (the production decode kernel met the oracle
+# only at the depth of the other goldens)
+DEEP = dict(n_ego_tar_layer=2, n_ego_ca_layer=2, n_map_tar_layer=2, n_box_tar_layer=2, n_tar_layer=2, n_oar_layer=10)
+
+
 def config(width: str = "full_width", **over):
-    """full_width: UMGen_Large's E=768 / H=16; wide2x: BASELINE.json config #5's E=1536 / H=32 -- one layer per stack either way."""
-    E, H = (768, 16) if width == "full_width" else (1536, 32)
+    """full_width: UMGen_Large's E=768 / H=16; wide2x: BASELINE.json config #5's E=1536 / H=32 -- tiny_config's depth either way (one
+    block per stack, two BlockOAR layers); deep: E=768 / H=16 with DEEP's layer counts."""
+    E, H = (1536, 32) if width == "wide2x" else (768, 16)
+    if width == "deep":
+        over = {**DEEP, **over}
     return tiny_config(n_embd=E, n_head=H, rule_constrain=False, **over).greedy()
 
 
@@ -64,5 +75,7 @@ def main(width: str = "full_width", modes=("fp32", "bf16_engine")):
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     only = [a[7:] for a in sys.argv[1:] if a.startswith("--mode=")]
+    import torch
+    torch.set_num_threads(int(os.environ.get("UMGEN_GOLDEN_THREADS", "8")))
     for w in (args or ["full_width", "wide2x"]):
         main(w, tuple(only) if only else ("fp32", "bf16_engine"))

@@ -66,10 +66,13 @@ def test_engine_logits_match_the_five_launch_path_under_teacher_forcing(setup):
         np.testing.assert_array_equal(out_g[m], out_e[m], err_msg=m)
 
 
-@pytest.mark.parametrize("B,engine_on", [(2, True), (3, True), (4, True), (8, True), (8, False), (7, True), (7, False), (10, True)])
+@pytest.mark.parametrize("B,engine_on", [(2, True), (3, True), (4, True), (8, True), (8, False), (7, True), (7, False), (10, True),
+                                         (12, True), (16, True), (32, True), (40, True)])
 def test_engine_is_batch_invariant(setup, B, engine_on):
-    """Scenes never interact: a batch of B scenes (B = 2: 4 XCDs per scene, 3: idle pipeline, 8: one XCD per scene, 10: two rounds)
-    gives exactly the B one-scene results, whatever group runs which layer."""
+    """Scenes never interact: a batch of B scenes (B = 2: 4 XCDs per scene, 3 / 4: disjoint group sets, 5 .. 32: the systolic schedule
+    -- 8 scenes: zero slack, 12 / 16 / 32: the throughput-bound forms the bench quotes, shared tail layers split over two groups --,
+    40: more scenes than one systolic launch carries, rounds of whole-scene groups) gives exactly the B one-scene results, whatever
+    group runs which layer."""
     cfg, sd = setup
     scenes = [synthetic_scene(40 + i, n_frames=2) for i in range(B)]
     seeds = [100 + i for i in range(B)]

@@ -131,6 +131,24 @@ def test_attn_spatial(bf16, F, S, H):
     np.testing.assert_allclose(got, ref, atol=(2e-2 * EPS16[bf16] if bf16 else 2e-5), rtol=0)
 
 
+@pytest.mark.parametrize("F,S,H", [(2, 2207, 16), (3, 1031, 2), (1, 70, 2), (2, 1693, 4), (1, 33, 2), (1, 129, 2)])
+def test_attn_spatial_fp32_matrix_core_kernel(F, S, H):
+    """fp32 parity mode's spatial attention on v_mfma_f32_32x32x2_f32 (attn_spatial_f32_mfma_kernel: 32 queries per wave, 32-key tiles,
+    the probabilities feed the second product straight from the score registers) and the one-thread-per-query VALU kernel it replaces
+    (flag 32): both within 2e-5 of the fp64 reference at production shapes, ragged key / query tails (S % 32 = 1, 2, 6, 29, 31)."""
+    E = H * 48
+    rng = np.random.default_rng(S + H)
+    q = rng.standard_normal((F, S, E), dtype=np.float32) * 1.5
+    k = rng.standard_normal((F, S, E), dtype=np.float32) * 1.5
+    v = rng.standard_normal((F, S, E), dtype=np.float32)
+    qk = np.ascontiguousarray(np.concatenate([q, k], axis=-1))
+    ref = ref_attention(q, k, v, H, False)
+    for flag in (0, 32):
+        y = np.zeros((F, S, E), dtype=np.float32)
+        check(lib().umgen_dbg_attn_spatial(flag, vp(qk), vp(v), F, S, H, vp(y)))
+        np.testing.assert_allclose(y, ref, atol=2e-5, rtol=0, err_msg=f"flag {flag}")
+
+
 @pytest.mark.parametrize("B,T,S,H", [(1, 20, 333, 16), (2, 3, 100, 2), (1, 40, 77, 4), (1, 64, 31, 2)])
 @pytest.mark.parametrize("bf16", PREC)
 def test_attn_temporal(bf16, B, T, S, H):

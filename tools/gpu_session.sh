@@ -1,0 +1,77 @@
+#!/bin/bash
+# GPU-box sessions of this round, ONE parameterised script (round 3 left 20 one-off tools/r3_gpu_*.sh behind):
+#     gpurun --timeout N -- 'bash tools/gpu_session.sh <session> [<session> ...]'
+# Every session writes under gpurun_out/ (merged back by gpurun); what is quoted in DESIGN.md is copied into profiles/ by hand.
+#   tests      the whole -m gpu suite                                                   -> r04_pytest_gpu.log
+#   smoke      __graft_entry__.smoke()
+#   bench      the default bench line (30 frames, CPU-baseline sample)                  -> r04_bench_full.json
+#   variants   fp16 / fp32 / batches / control / five-launch layer / 2x width lines       -> r04_bench_<name>.json
+#   control    configs[2] (control, 4 scenes, window 13 -> 20) with and without the slot-cache reuse (f-3) -> r04_bench_control_b4{,_nogrow}.json
+#   fp32ab     fp32 parity mode on the matrix cores vs the VALU kernel                   -> r04_bench_fp32{,_valu}.json
+#   stats      rocprofv3 --kernel-trace --stats of bench.py --steps 3                    -> r04_rocprofv3_kernel_stats_bench_steps3.csv
+#   pmc        rocprofv3 --pmc FETCH_SIZE of the decode engine at the mean KV length     -> r04_pmc_fetch_size_engine.csv
+#   pmcgemm    SQ / TA / TCC counters of the fc GEMM and the spatial attention          -> r04_pmc_gemm_*.txt, r04_pmc_attn_*.txt
+#   gemm       isolated GEMM shapes (tools/gemm_bench.py)                                -> r04_gemm_bench.txt
+#   stamps     per-phase microseconds of an engine item                                  -> r04_engine_stamps.txt
+#   closed     30-frame greedy closed loop, 16-bit modes vs fp32 mode                    -> r04_closed_loop.json
+#   cpubase    the oracle over one whole UMGen_Large frame on this host (32 threads)     -> r04_cpu_baseline_full.json
+#   ab:<name>  bench.py --steps 3 with UMGEN_LIB_PATH=umgen_amd/libumgen_hip_<name>.so (tools/build_variant.sh) next to the shipped library
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+R=r04
+line() {  # one-line summary of a bench JSON
+python - "$1" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    p = d["phases_ms_per_frame"]
+    print(sys.argv[1].split("/")[-1], round(d["value"], 1), "scene-tokens/s", round(d["ms_per_step"], 1), "ms/frame | layer kernel(s)", round(d["roofline"]["avg_launch_us"], 1),
+          "us frac", round(d["roofline"]["frac"], 4), "| step", round(d["roofline"]["step"]["avg_step_us"], 1), "us | gemm", round(d["roofline_gemm"]["achieved"]), "attn", round(d["roofline_attn"]["achieved"]),
+          "TFLOP/s | ego/tar/oar ms", round(p["ego"], 1), round(p["tar"], 1), round(p["oar"], 1), "reuse", p.get("frames_reusing_slot_caches"))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+}
+b() { name=$1; shift; "$@" > gpurun_out/${R}_bench_$name.json 2> gpurun_out/${R}_bench_$name.err; line gpurun_out/${R}_bench_$name.json; }
+for s in "$@"; do
+echo "=== session $s"
+case $s in
+tests) timeout 2400 python -m pytest tests -x -q -m gpu ${PYTEST_K:+-k "$PYTEST_K"} --durations=8 > gpurun_out/${R}_pytest_gpu.log 2>&1; tail -25 gpurun_out/${R}_pytest_gpu.log ;;
+smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
+bench) b full python bench.py ;;
+quick) b quick python bench.py --steps 5 --warmup 1 --no-cpu-baseline ;;
+variants)
+  b fp16 python bench.py --steps 10 --warmup 1 --no-cpu-baseline --precision fp16
+  b b4 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch 4
+  b b8 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch 8
+  b b16 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 16
+  b b32 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 32
+  b launches_plain env UMGEN_DECODE_ENGINE=0 UMGEN_OVERLAP=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  b wide2x python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x
+  b wide2x_h40 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x --history 40 ;;
+control)
+  b control_b4 python bench.py --steps 30 --warmup 0 --no-cpu-baseline --batch 4 --task control
+  b control_b4_nogrow env UMGEN_GROW_CACHE=0 python bench.py --steps 30 --warmup 0 --no-cpu-baseline --batch 4 --task control ;;
+fp32ab)
+  b fp32 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision fp32
+  b fp32_valu env UMGEN_FP32_MFMA=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision fp32 ;;
+stats)
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python /root/repo/bench.py --steps 3 --warmup 0 --no-cpu-baseline > /tmp/prof_bench.json 2>/tmp/prof.err
+   f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); cp "$f" /root/repo/gpurun_out/${R}_rocprofv3_kernel_stats_bench_steps3.csv; cp /tmp/prof_bench.json /root/repo/gpurun_out/${R}_rocprofv3_kernel_stats_bench_steps3_bench.json; head -12 "$f" | cut -c1-200) ;;
+pmc)
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc && UMGEN_DEBUG_OAR_STEPS=1101:1105 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/pmc.log 2>&1
+   f=$(find /tmp/pmc -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python /root/repo/tools/pmc_summary.py "$f" > /root/repo/gpurun_out/${R}_pmc_fetch_size_engine.csv && head -4 /root/repo/gpurun_out/${R}_pmc_fetch_size_engine.csv) ;;
+pmcgemm)
+  bash tools/gemm_pmc.sh > gpurun_out/${R}_pmc_gemm_fc_353120x3072x768.txt 2>&1; tail -12 gpurun_out/${R}_pmc_gemm_fc_353120x3072x768.txt | cut -c1-300
+  bash tools/attn_pmc.sh > gpurun_out/${R}_pmc_attn_spatial_F20_S2207_H16.txt 2>&1; tail -8 gpurun_out/${R}_pmc_attn_spatial_F20_S2207_H16.txt | cut -c1-300 ;;
+pmcengine) bash tools/engine_pmc.sh > gpurun_out/${R}_pmc_engine_sq.txt 2>&1; tail -12 gpurun_out/${R}_pmc_engine_sq.txt | cut -c1-300 ;;
+gemm) python tools/gemm_bench.py ${GEMM_ARGS} > gpurun_out/${R}_gemm_bench.txt 2>&1; tail -40 gpurun_out/${R}_gemm_bench.txt ;;
+stamps) UMGEN_DEBUG_TIMING=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/${R}_engine_stamps.txt; grep "decode engine" gpurun_out/${R}_engine_stamps.txt | tail -3 ;;
+closed) python tools/closed_loop.py --frames 30 > gpurun_out/${R}_closed_loop.log 2>&1; tail -4 gpurun_out/${R}_closed_loop.log | cut -c1-600 ;;
+cpubase) python tools/cpu_baseline_full.py --runs 1 --frames 1 --threads 32 --out gpurun_out/${R}_cpu_baseline_full.json 2>&1 | tail -2 ;;
+ab:*) v=${s#ab:}
+  b ab_shipped python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${AB_ARGS}
+  b ab_$v env UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_$v.so python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${AB_ARGS} ;;
+*) echo "unknown session $s" ;;
+esac
+done

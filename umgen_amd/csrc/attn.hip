@@ -658,10 +658,136 @@ __global__ __launch_bounds__(128) void attn_spatial_valu_kernel(const T* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// spatial, fp32 on the matrix cores (parity mode): v_mfma_f32_32x32x2_f32 -- exact fp32 products and sums at the fp32 vector peak,
+// where the one-thread-per-query VALU kernel above reaches 8 TFLOP/s (it was 4.7 s of a 10.7 s fp32 frame).  Same arithmetic
+// contract (fp32 operands, fp32 softmax with expf, exact 1/l); another summation order of the keys, like every other attention here.
+//   workgroup = 4 waves x 32 queries of one (frame, head); keys in tiles of 32 through LDS, dim-major: Kt[48][33], Vt[48][33]
+//   S^T = K Q^T  ("swapped", so a query's scores are lane-local): A = K (row = key l % 32, k = dim 2 s + l / 32), B = Q^T held in
+//         24 registers per lane; C: column = query l % 32, row = key 8 (r / 4) + 4 (l / 32) + r % 4 -- 16 of the tile's 32 keys per lane,
+//         the other 16 in lane l ^ 32 (one exchange of the tile maximum per tile, the row sum is folded once at the end)
+//   O^T += V^T P^T: A = V^T (row = dim, k = key), B = P^T straight from the score registers: the MFMA step that consumes keys
+//         8 a + b (lanes < 32) and 8 a + 4 + b (lanes >= 32) takes register 4 a + b of every lane; 48 dims = one full and one
+//         half-used 32-row tile
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_spatial_f32_mfma_kernel(const float* __restrict__ qk, const float* __restrict__ vt, float* __restrict__ y,
+                                                                    int S, int S_pad, int H) {
+    __shared__ float sK[kHeadDim][33];
+    __shared__ float sV[kHeadDim][33];
+    const int E = H * kHeadDim;
+    const int f = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    const long ld = 2L * E;
+    const float* qbase = qk + (long)f * S * ld + h * kHeadDim;
+    const float* kbase = qbase + E;
+    const float* vbase = vt + ((long)f * H + h) * kHeadDim * S_pad;
+    const int qi = blockIdx.x * 128 + wave * 32 + l32;
+    const int qr = min(qi, S - 1);
+    float qreg[24];
+#pragma unroll
+    for (int s2 = 0; s2 < 24; ++s2) qreg[s2] = qbase[qr * ld + 2 * s2 + half];
+    f32x16_t o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    // staging: 384 float4 of K (32 keys x 12 chunks) and 384 float4 of V^T (48 dims x 8 chunks) per tile, 256 threads
+    float4 rk[2], rv[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + 256 * it;
+            if (e < 384) {
+                const int kk = e / 12, c = e % 12;
+                rk[it] = *reinterpret_cast<const float4*>(kbase + (long)min(k0 + kk, S - 1) * ld + 4 * c);
+                const int d = e / 8, c2 = e % 8;
+                rv[it] = *reinterpret_cast<const float4*>(vbase + (long)d * S_pad + k0 + 4 * c2);     // pad columns are zero (engine.hip)
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + 256 * it;
+            if (e < 384) {
+                const int kk = e / 12, c = e % 12;
+                sK[4 * c + 0][kk] = rk[it].x; sK[4 * c + 1][kk] = rk[it].y; sK[4 * c + 2][kk] = rk[it].z; sK[4 * c + 3][kk] = rk[it].w;
+                const int d = e / 8, c2 = e % 8;
+                sV[d][4 * c2 + 0] = rv[it].x; sV[d][4 * c2 + 1] = rv[it].y; sV[d][4 * c2 + 2] = rv[it].z; sV[d][4 * c2 + 3] = rv[it].w;
+            }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        stash();
+        __syncthreads();
+        if (k0 + 32 < S) fetch(k0 + 32);
+        f32x16_t sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int s2 = 0; s2 < 24; ++s2) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[2 * s2 + half][l32], qreg[s2], sc, 0, 0, 0);
+#endif
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            sc[r] = key < S ? sc[r] * kScale : -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float alpha = expf(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = expf(sc[r] - mn);
+            ps += sc[r];
+        }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4)
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                const int key = 8 * a4 + b4 + 4 * half;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[l32][key], sc[4 * a4 + b4], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[32 + (l32 & 15)][key], sc[4 * a4 + b4], o1, 0, 0, 0);
+            }
+#endif
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32);
+    if (qi < S) {
+        const float inv = 1.0f / l;
+        float* yr = y + ((long)f * S + qi) * E + h * kHeadDim;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {      // rows (dims) 8 q4 + 4 half + 0..3 of the 32-row tile
+            const float4 v = make_float4(o0[4 * q4] * inv, o0[4 * q4 + 1] * inv, o0[4 * q4 + 2] * inv, o0[4 * q4 + 3] * inv);
+            *reinterpret_cast<float4*>(yr + 8 * q4 + 4 * half) = v;
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) {      // dims 32 .. 47: rows 0 .. 15 of the second tile
+            const float4 v = make_float4(o1[4 * q4] * inv, o1[4 * q4 + 1] * inv, o1[4 * q4 + 2] * inv, o1[4 * q4 + 3] * inv);
+            *reinterpret_cast<float4*>(yr + 32 + 8 * q4 + 4 * half) = v;
+        }
+    }
+}
+
 template <typename T>
 void launch_attn_spatial_valu(hipStream_t s, const T* qk, const T* vt, T* y, int F, int S, int S_pad, int H) {
     dim3 grid((S + 127) / 128, H, F);
     hipLaunchKernelGGL(attn_spatial_valu_kernel<T>, grid, dim3(128), 0, s, qk, vt, y, S, S_pad, H);
+}
+void launch_attn_spatial_f32_mfma(hipStream_t s, const float* qk, const float* vt, float* y, int F, int S, int S_pad, int H) {
+    static const bool off = getenv("UMGEN_FP32_MFMA") && getenv("UMGEN_FP32_MFMA")[0] == '0';   // 0: the one-thread-per-query VALU kernel (A/B)
+    if (off) { launch_attn_spatial_valu<float>(s, qk, vt, y, F, S, S_pad, H); return; }
+    dim3 grid((S + 127) / 128, H, F);
+    hipLaunchKernelGGL(attn_spatial_f32_mfma_kernel, grid, dim3(256), 0, s, qk, vt, y, S, S_pad, H);
 }
 template void launch_attn_spatial_valu<float>(hipStream_t, const float*, const float*, float*, int, int, int, int);
 template void launch_attn_spatial_valu<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int);

@@ -45,7 +45,8 @@ int umgen_dbg_linear(int flags, const void* act, const void* W, const float* bia
 
 // spatial attention on q|k rows [F*S][2E] and v rows [F*S][E] (both row-major on the host; V is transposed on the device
 // through the same GEMM_VT-layout the engine uses).  y [F*S][E].
-int umgen_dbg_attn_spatial(int bf16, const void* qk, const void* v, int F, int S, int H, void* y) {
+int umgen_dbg_attn_spatial(int flags, const void* qk, const void* v, int F, int S, int H, void* y) {
+    const int bf16 = flags & 3;                 // precision code; flag 32 (fp32 only): the VALU kernel instead of the matrix-core one
     const int E = H * kHeadDim, S_pad = ((S + 63) / 64) * 64;
     const size_t es = bf16 ? 2 : 4;
     const size_t R = (size_t)F * S;
@@ -61,7 +62,8 @@ int umgen_dbg_attn_spatial(int bf16, const void* qk, const void* v, int F, int S
     if (up(dQK.p, qk, R * 2 * E * es) || up(dVT.p, vt.data(), vt.size())) return UMGEN_E_HIP;
     if (bf16 == 2) launch_attn_spatial_mfma<f16_t>(nullptr, (const f16_t*)dQK.p, (const f16_t*)dVT.p, (f16_t*)dY.p, F, S, S_pad, H);
     else if (bf16) launch_attn_spatial_mfma<bf16_t>(nullptr, (const bf16_t*)dQK.p, (const bf16_t*)dVT.p, (bf16_t*)dY.p, F, S, S_pad, H);
-    else launch_attn_spatial_valu<float>(nullptr, (const float*)dQK.p, (const float*)dVT.p, (float*)dY.p, F, S, S_pad, H);
+    else if (flags & 32) launch_attn_spatial_valu<float>(nullptr, (const float*)dQK.p, (const float*)dVT.p, (float*)dY.p, F, S, S_pad, H);   // flag 32: the VALU kernel
+    else launch_attn_spatial_f32_mfma(nullptr, (const float*)dQK.p, (const float*)dVT.p, (float*)dY.p, F, S, S_pad, H);
     if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
     return down(y, dY.p, R * E * es);
 }

@@ -274,7 +274,7 @@ template <typename T> struct Path;
 template <> struct Path<float> {
     static void gemm(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<float, float>(s, a); }
     static void attn_spatial(hipStream_t s, const float* qk, const float* vt, float* y, int F, int S, int Sp, int H) {
-        launch_attn_spatial_valu<float>(s, qk, vt, y, F, S, Sp, H);
+        launch_attn_spatial_f32_mfma(s, qk, vt, y, F, S, Sp, H);
     }
     static void gemm_w_f32act(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<float, float>(s, a); }
 };

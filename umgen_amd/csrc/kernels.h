@@ -50,6 +50,8 @@ template <typename T> void launch_layernorm(hipStream_t s, const float* x, long 
 // spatial (non-causal) attention inside each frame: qk [F*S][2E] row-major (q | k), vt [F][H][48][S_pad], y [F*S][E]
 template <typename TT> void launch_attn_spatial_mfma(hipStream_t s, const TT* qk, const TT* vt, TT* y, int F, int S, int S_pad, int H);   // TT = bf16_t / f16_t
 template <typename T> void launch_attn_spatial_valu(hipStream_t s, const T* qk, const T* vt, T* y, int F, int S, int S_pad, int H);
+// fp32 parity mode on v_mfma_f32_32x32x2_f32 (UMGEN_FP32_MFMA=0: the VALU kernel above)
+void launch_attn_spatial_f32_mfma(hipStream_t s, const float* qk, const float* vt, float* y, int F, int S, int S_pad, int H);
 // temporal causal attention over T frames per spatial position: qkv [B*T*S][3E] row-major, y [B*T*S][E]
 // Temporal attention over history slots [t0, t0 + Tn) held in the qkv rows; k | v of slots [0, t0) are read from `cache`
 // ([B][Tcap][S][2E], dtype T) and, when write != 0, the k | v rows of the new slots are appended to it (attn.hip).
