@@ -136,6 +136,11 @@ def main():
     ap.add_argument("--input-history", type=int, default=0,
                     help="history frames the rollout STARTS with (0 = the reference's setting: --history for video, 13 for control, "
                          "infer_fun.py:64-71 -- the control window then grows 13 -> 20 before it slides)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="dry run of the N > 1 path on ONE GPU: every rank uses cuda:0 and the one exchange runs over gloo (RCCL refuses "
+                         "two ranks on a device).  Exercises the launch contract, the partition, the gather, the max-over-ranks clock and "
+                         "the JSON line -- NOT a scaling measurement (the line says so); use --config tiny: two XCD-resident decode "
+                         "engines cannot share a GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     args = ap.parse_args()
@@ -149,9 +154,14 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from umgen_amd.engine import Engine
 
@@ -185,6 +195,8 @@ def main():
         return eng.rollout(toks, new_frames, cond_frames=T, input_cond_frames=T_in, seeds=seeds,
                            **control_of(scene_ids if scene_ids is not None else mine, new_frames))
 
+    gdev = "cpu" if (world == 1 or args.share_gpu) else "cuda"      # where the one all-gather of the path runs (RCCL: device buffers)
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -196,11 +208,11 @@ def main():
     sync()
     t0 = time.perf_counter()
     # the timed region: every rank's rollouts + the one exchange of the path (all-gather of the sampled tokens, north_star)
-    out = sharded_rollout(rollout_fn, scenes, base_seed=1000, batch=B, device="cuda" if world > 1 else "cpu", pass_ids=True, new_frames=args.steps)
+    out = sharded_rollout(rollout_fn, scenes, base_seed=1000, batch=B, device=gdev, pass_ids=True, new_frames=args.steps)
     assert out["map"].shape[0] == n_scenes
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=gdev if world > 1 else "cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -272,6 +284,8 @@ def main():
             "closed_loop": closed_loop_record(args.precision) if args.config == "large" else None,
             "decode_engine": int(engine_on), "engine_fallback": int(tm["engine_fallback"]),
         }
+        if args.share_gpu:
+            res["dry_run"] = f"{world} ranks SHARING cuda:0 over gloo: exercises the N > 1 code path only; value is not a scaling measurement"
         if tm["engine_fallback"]:
             print("bench.py: WARNING -- the XCD-resident decode engine was NOT used (census failed at umgen_create): this line measures the "
                   "five-launch decode layer, not the production path", file=sys.stderr)

@@ -146,3 +146,31 @@ def test_two_ranks_with_the_real_engine_equal_the_unsharded_rollout():
     for m in MOD_ORDER:
         assert got[m].shape == (n, 3, CONTENT_LEN[m])
         np.testing.assert_array_equal(got[m], ref[m], err_msg=m)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_contract_dry_run_on_one_gpu():
+    """The driver's N > 1 launch of bench.py (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), dry-run on the
+    one GPU a test box has: 2 ranks share cuda:0 over gloo (--share-gpu), 2 scenes per rank.  Checks the contract of the JSON line
+    (rank 0 only, n_gpus, whole-job value = all ranks' scenes / max-over-ranks time, scaling 'weak') and that the sharded rollout +
+    gather inside the timed region runs end to end."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--config", "tiny", "--history", "3",
+           "--share-gpu", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 0 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["scenes_per_gpu"] == 2 and "dry_run" in d
+    assert abs(d["value"] - 4 * 2207 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # 2 ranks x 2 scenes x 1 frame over the max-over-ranks time

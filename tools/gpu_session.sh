@@ -14,6 +14,7 @@
 #   gemm       isolated GEMM shapes (tools/gemm_bench.py)                                -> r04_gemm_bench.txt
 #   stamps     per-phase microseconds of an engine item                                  -> r04_engine_stamps.txt
 #   closed     30-frame greedy closed loop, 16-bit modes vs fp32 mode                    -> r04_closed_loop.json
+#   vq         umgen_vq_decode of the two production decoders, 20 frames              -> r04_vq_decode_time{,_valu}.json
 #   cpubase    the oracle over one whole UMGen_Large frame on this host (32 threads)     -> r04_cpu_baseline_full.json
 #   ab:<name>  bench.py --steps 3 with UMGEN_LIB_PATH=umgen_amd/libumgen_hip_<name>.so (tools/build_variant.sh) next to the shipped library
 cd "$(dirname "$0")/.." || exit 1
@@ -68,6 +69,8 @@ pmcengine) bash tools/engine_pmc.sh > gpurun_out/${R}_pmc_engine_sq.txt 2>&1; ta
 gemm) python tools/gemm_bench.py ${GEMM_ARGS} > gpurun_out/${R}_gemm_bench.txt 2>&1; tail -40 gpurun_out/${R}_gemm_bench.txt ;;
 stamps) UMGEN_DEBUG_TIMING=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/${R}_engine_stamps.txt; grep "decode engine" gpurun_out/${R}_engine_stamps.txt | tail -3 ;;
 closed) python tools/closed_loop.py --frames 30 > gpurun_out/${R}_closed_loop.log 2>&1; tail -4 gpurun_out/${R}_closed_loop.log | cut -c1-600 ;;
+vq) python tools/vq_time.py > gpurun_out/${R}_vq_decode_time.json 2>gpurun_out/${R}_vq_decode_time.err; cat gpurun_out/${R}_vq_decode_time.json
+    UMGEN_FP32_MFMA=0 python tools/vq_time.py > gpurun_out/${R}_vq_decode_time_valu.json 2>/dev/null; cat gpurun_out/${R}_vq_decode_time_valu.json ;;
 cpubase) python tools/cpu_baseline_full.py --runs 1 --frames 1 --threads 32 --out gpurun_out/${R}_cpu_baseline_full.json 2>&1 | tail -2 ;;
 ab:*) v=${s#ab:}
   b ab_shipped python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${AB_ARGS}
