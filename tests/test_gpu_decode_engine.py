@@ -19,15 +19,19 @@ pytestmark = pytest.mark.gpu
 
 
 def make(cfg, sd, engine_on, max_batch=1, graphs=True):
-    old = os.environ.get("UMGEN_DECODE_ENGINE")
+    """engine_on: the XCD-resident engine for EVERY batch size (its systolic / rounds schedules included: the batched decode layer that
+    takes 16 and more scenes by default is switched off), else the five-launch layer."""
+    old = {k: os.environ.get(k) for k in ("UMGEN_DECODE_ENGINE", "UMGEN_DECODE_BATCHED")}
     os.environ["UMGEN_DECODE_ENGINE"] = "1" if engine_on else "0"
+    os.environ["UMGEN_DECODE_BATCHED"] = "0"
     try:
         e = Engine(cfg, precision="bf16", max_batch=max_batch, max_cond_frames=4, use_graphs=graphs)
     finally:
-        if old is None:
-            del os.environ["UMGEN_DECODE_ENGINE"]
-        else:
-            os.environ["UMGEN_DECODE_ENGINE"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     e.load_state_dict(sd)
     e.finalize()
     return e
@@ -87,3 +91,95 @@ def test_engine_is_batch_invariant(setup, B, engine_on):
             if len(d):
                 bad.append((i, m, len(d), d[:3].tolist()))
     assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the batched decode layer (csrc/decode_batched.hip): 16 and more scenes per call, the scenes as the MFMA's B-columns
+# ---------------------------------------------------------------------------------------------------------------------
+def make_batched(cfg, sd, threshold, max_batch=1, precision="bf16"):
+    """UMGEN_DECODE_BATCHED=<threshold>: batches of at least that many scenes run the batched decode layer (1: every call does)."""
+    old = os.environ.get("UMGEN_DECODE_BATCHED")
+    os.environ["UMGEN_DECODE_BATCHED"] = str(threshold)
+    try:
+        e = Engine(cfg, precision=precision, max_batch=max_batch, max_cond_frames=4)
+    finally:
+        if old is None:
+            del os.environ["UMGEN_DECODE_BATCHED"]
+        else:
+            os.environ["UMGEN_DECODE_BATCHED"] = old
+    e.load_state_dict(sd)
+    e.finalize()
+    return e
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_batched_decode_layer_logits_match_the_five_launch_path_under_teacher_forcing(setup, precision):
+    """Same rounding points as the five-launch layer and the engine (16-bit weights and K/V cache, fp32 activations -- here as hi + lo
+    16-bit pairs on the matrix cores, 2^-17 / 2^-22 relative), another fp32 summation order: teacher-forced logits within the
+    north-star's 1e-3 (observed ~1e-4), at most a handful of sampled tokens on the other side of a near-tie."""
+    cfg, sd = setup
+    scene = synthetic_scene(31, n_frames=2)
+    window = {m: scene[m][0] for m in MOD_ORDER}
+    old = os.environ.get("UMGEN_DECODE_ENGINE")
+    os.environ["UMGEN_DECODE_ENGINE"] = "0"
+    try:
+        ref = make_batched(cfg, sd, 0, precision=precision)          # 0: never batched -> five launches per layer
+    finally:
+        if old is None:
+            del os.environ["UMGEN_DECODE_ENGINE"]
+        else:
+            os.environ["UMGEN_DECODE_ENGINE"] = old
+    toks_ref, tr_ref = ref.frame(window, frame_idx=0, seed=3, trace=True)
+    assert ref.timings()["decode_engine"] == 0 and ref.timings()["decode_batched"] == 0
+    ref.close()
+    e = make_batched(cfg, sd, 1, precision=precision)
+    toks, tr = e.frame(window, frame_idx=0, seed=3, trace=True, forced=toks_ref)
+    assert e.timings()["decode_batched"] == 1 and e.timings()["decode_engine"] == 0
+    e.close()
+    worst = 0.0
+    for m in ("map", "bbox3d", "image"):
+        worst = max(worst, float(np.abs(tr[f"logits_{m}"] - tr_ref[f"logits_{m}"]).max()))
+        np.testing.assert_allclose(tr[f"logits_{m}"], tr_ref[f"logits_{m}"], atol=1e-3, rtol=0, err_msg=m)
+    print(f"batched decode layer vs launches ({precision}): max |dlogit| = {worst:.2e}, sampled != forced: {tr['counters']['sampled_ne_forced']}")
+    assert tr["counters"]["sampled_ne_forced"] <= 4, tr["counters"]
+
+
+@pytest.mark.parametrize("B", [2, 17, 33, 64])
+def test_batched_decode_layer_is_batch_invariant(setup, B):
+    """A scene's outputs are a function of its own MFMA column and their summation order does not depend on how many columns are in
+    flight: a batch of B scenes (1 .. 4 column blocks of 16, ragged last block) == the B one-scene runs of the same path, bit for bit."""
+    cfg, sd = setup
+    scenes = [synthetic_scene(40 + i, n_frames=2) for i in range(B)]
+    seeds = [100 + i for i in range(B)]
+    e = make_batched(cfg, sd, 1, max_batch=B)
+    single = [e.rollout(scenes[i], 1, cond_frames=3, input_cond_frames=2, seeds=[seeds[i]]) for i in range(min(B, 20))]
+    both = e.rollout({m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=seeds)
+    assert e.timings()["decode_batched"] == 1
+    # the scenes beyond the first 20: one-scene runs of a few of them (every column block, incl. the ragged last one)
+    extra = sorted(set(range(B)) & {21, 31, 32, 47, 48, 63})
+    single_extra = {i: e.rollout(scenes[i], 1, cond_frames=3, input_cond_frames=2, seeds=[seeds[i]]) for i in extra}
+    e.close()
+    bad = []
+    for i, ref in list(enumerate(single)) + sorted(single_extra.items()):
+        for m in MOD_ORDER:
+            d = np.argwhere(both[m][i:i + 1] != ref[m])
+            if len(d):
+                bad.append((i, m, len(d), d[:3].tolist()))
+    assert not bad, bad
+
+
+def test_default_path_selection_by_batch_size(setup):
+    """Up to 15 scenes per call the XCD-resident engine takes the decode step, from 16 on the batched layer (UMGEN_DECODE_BATCHED moves
+    the threshold): umgen_timings says which one ran."""
+    cfg, sd = setup
+    e = Engine(cfg, precision="bf16", max_batch=16, max_cond_frames=4)
+    e.load_state_dict(sd)
+    e.finalize()
+    scenes = [synthetic_scene(40 + i, n_frames=2) for i in range(16)]
+    e.rollout({m: np.concatenate([s[m] for s in scenes[:15]]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(15)))
+    t = e.timings()
+    assert t["decode_engine"] == 1 and t["decode_batched"] == 0
+    e.rollout({m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(16)))
+    t = e.timings()
+    assert t["decode_engine"] == 0 and t["decode_batched"] == 1
+    e.close()

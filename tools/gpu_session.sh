@@ -6,6 +6,7 @@
 #   smoke      __graft_entry__.smoke()
 #   bench      the default bench line (30 frames, CPU-baseline sample)                  -> r04_bench_full.json
 #   variants   fp16 / fp32 / batches / control / five-launch layer / 2x width lines       -> r04_bench_<name>.json
+#   batched    16 / 32 / 64 scenes per GPU on the batched decode layer, 32 on the engine  -> r04_bench_b{16,32,64,32_engine}.json
 #   control    configs[2] (control, 4 scenes, window 13 -> 20) with and without the slot-cache reuse (f-3) -> r04_bench_control_b4{,_nogrow}.json
 #   fp32ab     fp32 parity mode on the matrix cores vs the VALU kernel                   -> r04_bench_fp32{,_valu}.json
 #   stats      rocprofv3 --kernel-trace --stats of bench.py --steps 3                    -> r04_rocprofv3_kernel_stats_bench_steps3.csv
@@ -50,6 +51,15 @@ variants)
   b launches_plain env UMGEN_DECODE_ENGINE=0 UMGEN_OVERLAP=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline
   b wide2x python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x
   b wide2x_h40 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x --history 40 ;;
+batched)
+  b b16 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 16
+  b b32 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 32
+  b b64 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 64
+  b b16_engine env UMGEN_DECODE_BATCHED=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 16
+  b b32_engine env UMGEN_DECODE_BATCHED=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 32 ;;
+wide)
+  b wide2x python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x
+  b wide2x_h40 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x --history 40 ;;
 control)
   b control_b4 python bench.py --steps 30 --warmup 0 --no-cpu-baseline --batch 4 --task control
   b control_b4_nogrow env UMGEN_GROW_CACHE=0 python bench.py --steps 30 --warmup 0 --no-cpu-baseline --batch 4 --task control ;;
@@ -59,6 +69,9 @@ fp32ab)
 stats)
   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python /root/repo/bench.py --steps 3 --warmup 0 --no-cpu-baseline > /tmp/prof_bench.json 2>/tmp/prof.err
    f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); cp "$f" /root/repo/gpurun_out/${R}_rocprofv3_kernel_stats_bench_steps3.csv; cp /tmp/prof_bench.json /root/repo/gpurun_out/${R}_rocprofv3_kernel_stats_bench_steps3_bench.json; head -12 "$f" | cut -c1-200) ;;
+prof)   # rocprofv3 kernel statistics of bench.py ${PROF_ARGS} -> r04_prof_${PROF_NAME}.csv
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2 -- python /root/repo/bench.py --no-cpu-baseline ${PROF_ARGS} > /tmp/prof2_bench.json 2>/tmp/prof2.err
+   f=$(find /tmp/prof2 -name "*kernel_stats.csv" | head -1); cp "$f" /root/repo/gpurun_out/${R}_prof_${PROF_NAME:-x}.csv; head -14 "$f" | cut -c1-220) ;;
 pmc)
   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc && UMGEN_DEBUG_OAR_STEPS=1101:1105 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/pmc.log 2>&1
    f=$(find /tmp/pmc -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python /root/repo/tools/pmc_summary.py "$f" > /root/repo/gpurun_out/${R}_pmc_fetch_size_engine.csv && head -4 /root/repo/gpurun_out/${R}_pmc_fetch_size_engine.csv) ;;

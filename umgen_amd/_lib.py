@@ -14,12 +14,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # UMGEN_LIB_PATH selects an alternative build of the SAME library (kernel experiments with extra -D flags); never a fallback
 LIB_PATH = os.environ.get("UMGEN_LIB_PATH") or os.path.join(HERE, "libumgen_hip.so")
-SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "vqdec.hip", "debug_api.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "decode_batched.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "vqdec.hip", "debug_api.hip"]
 EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen_rollout", "umgen_frame",
            "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",
            "umgen_tokenize_ego", "umgen_detokenize_ego", "umgen_tokenize_boxes", "umgen_detokenize_boxes",
            "umgen_vq_create", "umgen_vq_load_tensor", "umgen_vq_finalize", "umgen_vq_decode", "umgen_vq_last_error", "umgen_vq_destroy",
-           "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench", "umgen_dbg_oar_step", "umgen_dbg_sample_topk"]
+           "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench", "umgen_dbg_oar_step", "umgen_dbg_sample_topk", "umgen_dbg_batched_layer_bench"]
 
 PREC_FP32, PREC_BF16, PREC_FP16 = 0, 1, 2
 DT_F32, DT_BF16, DT_F16, DT_F64 = 0, 1, 2, 3
@@ -62,7 +62,8 @@ class Timings(C.Structure):
                 ("gemm_ms", C.c_double), ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("oar_bytes", C.c_double),
                 ("attn_ms", C.c_double), ("attn_launches", C.c_int64), ("attn_flops", C.c_double),
                 ("bg_ms", C.c_double), ("overlapped_frames", C.c_int64),
-                ("layers_ms", C.c_double), ("layers_launches", C.c_int64), ("decode_engine", C.c_int32), ("engine_fallback", C.c_int32)]
+                ("layers_ms", C.c_double), ("layers_launches", C.c_int64), ("decode_engine", C.c_int32), ("engine_fallback", C.c_int32),
+                ("decode_batched", C.c_int32), ("reserved0", C.c_int32)]
 
 
 def hipcc_path() -> str:
@@ -231,6 +232,7 @@ def load_library() -> C.CDLL:
     lib.umgen_dbg_gemm_bench.argtypes = [i32, i32, i32, i32, i32, fp]
     lib.umgen_dbg_oar_step.argtypes = [vp, i32, i32, fp, fp, i32, i32]
     lib.umgen_dbg_sample_topk.argtypes = [fp, i32, i32, i32, C.c_float, fp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.umgen_dbg_batched_layer_bench.argtypes = [i32, i32, i32, i32, fp]
     lib.umgen_vq_create.argtypes = [C.POINTER(VQConfig), C.POINTER(vp)]
     lib.umgen_vq_load_tensor.argtypes = [vp, C.c_char_p, fp, i64p, i32]
     lib.umgen_vq_finalize.argtypes = [vp]

@@ -202,4 +202,56 @@ int umgen_dbg_sample_topk(const float* logits, int n, int V, int k, float temp, 
     return down(overflow, dO.p, 4);
 }
 
+// Timing hook of the batched decode layer's kernels (decode_batched.hip) on random data: one BlockOAR layer's five launches at M scenes and
+// KV length L, `iters` times back to back; us[0..4] = average microseconds of q|k|v, attention, c_proj, c_fc, mlp c_proj (HIP events
+// around each launch), us[5] = the five as one sequence.
+int umgen_dbg_batched_layer_bench(int prec, int M, int L, int iters, float* us) {
+    const int E = 768, H = 16, Lmax = 2304;
+    if (prec != 1 && prec != 2) return UMGEN_E_INVALID;
+    if (M < 1 || M > kRowsMaxM || L < 1 || L >= Lmax) return UMGEN_E_INVALID;
+    const size_t wsz = (size_t)12 * E * E * 2, csz = (size_t)M * 2 * H * Lmax * kHeadDim * 2;
+    DevBuf dW(wsz), dC(csz), dx((size_t)64 * E * 4), dxr((size_t)64 * E * 4), dq((size_t)64 * E * 4), da((size_t)64 * E * 4), dh((size_t)64 * 4 * E * 4), dln((size_t)E * 4), db((size_t)4 * E * 4), dlen(16);
+    if (!dW.p || !dC.p || !dx.p || !dxr.p || !dq.p || !da.p || !dh.p || !dln.p || !db.p || !dlen.p) return UMGEN_E_NOMEM;
+    std::vector<unsigned short> hw(wsz / 2);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = (unsigned short)(0x3c00 + (i * 2654435761u >> 24)) & (prec == 1 ? 0x3cff : 0x2fff);   // small positive values
+    std::vector<float> hx((size_t)64 * E, 0.25f), hl(E, 1.f), hb(4 * E, 0.f);
+    for (size_t i = 0; i < hx.size(); ++i) hx[i] = 0.25f + 1e-3f * (float)(i % 97);
+    if (up(dW.p, hw.data(), wsz) || up(dx.p, hx.data(), hx.size() * 4) || up(dxr.p, hx.data(), hx.size() * 4) || hipMemset(da.p, 0, (size_t)64 * E * 4) != hipSuccess || hipMemset(dh.p, 0, (size_t)64 * 4 * E * 4) != hipSuccess || up(dln.p, hl.data(), E * 4) || up(db.p, hb.data(), 4 * E * 4)) return UMGEN_E_HIP;
+    if (hipMemset(dC.p, 0, csz) != hipSuccess || hipMemcpy(dlen.p, &L, 4, hipMemcpyHostToDevice) != hipSuccess) return UMGEN_E_HIP;
+    hipStream_t st;
+    if (hipStreamCreate(&st) != hipSuccess) return UMGEN_E_HIP;
+    const char* Wq = (const char*)dW.p;
+    auto run = [&](int which, auto tag) {
+        typedef decltype(tag) TT;
+        RowsArgs r{};
+        r.M = M; r.E = E;
+        switch (which) {
+            case 0: r.x = (float*)dx.p; r.ln_w = (float*)dln.p; r.W = Wq; r.bias = (float*)db.p; r.N = 3 * E; r.K = E; r.mode = ROWS_QKV; r.out = (float*)dq.p; r.ldo = E;
+                    r.cache = dC.p; r.scene_stride = (long)2 * H * Lmax * kHeadDim; r.d_len = (int*)dlen.p; r.Lmax = Lmax; launch_rows_mfma<TT>(st, r); break;
+            case 1: launch_attn_decode_batched<TT>(st, (float*)dq.p, (const TT*)dC.p, (long)2 * H * Lmax * kHeadDim, M, H, Lmax, (int*)dlen.p, (float*)da.p); break;
+            case 2: r.x = (float*)da.p; r.W = Wq + (size_t)3 * E * E * 2; r.bias = (float*)db.p; r.N = E; r.K = E; r.mode = ROWS_RESID; r.out = (float*)dxr.p; r.ldo = E; r.out_frag = (float*)dx.p; launch_rows_mfma<TT>(st, r); break;
+            case 3: r.x = (float*)dx.p; r.ln_w = (float*)dln.p; r.W = Wq + (size_t)4 * E * E * 2; r.N = 4 * E; r.K = E; r.mode = ROWS_GELU; r.out_frag = (float*)dh.p; launch_rows_mfma<TT>(st, r); break;
+            default: r.x = (float*)dh.p; r.W = Wq + (size_t)8 * E * E * 2; r.N = E; r.K = 4 * E; r.mode = ROWS_RESID; r.out = (float*)dxr.p; r.ldo = E; r.out_frag = (float*)dx.p; launch_rows_mfma<TT>(st, r); break;
+        }
+    };
+    auto run_p = [&](int which) { if (prec == 2) run(which, f16_t{}); else run(which, bf16_t{}); };
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int which = 0; which <= 5; ++which) {
+        for (int w = 0; w < 3; ++w) { if (which < 5) run_p(which); else for (int k = 0; k < 5; ++k) run_p(k); }
+        hipEventRecord(e0, st);
+        for (int i = 0; i < iters; ++i) { if (which < 5) run_p(which); else for (int k = 0; k < 5; ++k) run_p(k); }
+        hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) return UMGEN_E_HIP;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        us[which] = ms * 1000.f / (float)iters;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipStreamDestroy(st);
+    return UMGEN_OK;
+}
+
 }  // extern "C"

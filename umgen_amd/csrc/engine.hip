@@ -144,6 +144,11 @@ struct umgen_engine {
         return es->ok ? es : nullptr;
     }
     double gemm_flops_pending = 0, attn_flops_pending = 0;
+    // Batched decode layer (decode_batched.hip) from `batched_min` scenes per launch on (UMGEN_DECODE_BATCHED=n; 0 = never): the weights
+    // once per step for the whole batch, the scenes as the matrix-core instruction's B-columns
+    int batched_min = 16;
+    float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;   // fragment-major x / attention output [64 E], gelu(c_fc) [64 x 4E] of the batched layer
+    bool use_batched(int B) const { return tsz == 2 && batched_min > 0 && B >= batched_min && B <= kRowsMaxM && E % 32 == 0 && E <= 768; }
     hipError_t launch_status = hipSuccess;   // first refused kernel launch of the frame (hipGetLastError behind the GEMM launches): fails the frame
 
     int fail(int code, const char* fmt, ...) {
@@ -489,6 +494,31 @@ template <typename T>
 int oar_layers(umgen_engine* e, int B, int ns) {
     const int E = e->E, H = e->H;
     const int* d_len = &e->d_state->step;
+    if constexpr (sizeof(T) == 2) {
+        if (e->use_batched(B)) {      // five launches per layer for the whole batch: LN + q|k|v, attention, c_proj (+x), LN + c_fc + GELU, mlp c_proj (+x)
+            // activations between the launches are fragment-major (decode_batched.hip); x also stays row-major in xdec (sampler, residual)
+            launch_rows_to_frag(e->stream, e->xdec, E, B, E, e->xfrag);
+            for (size_t li = 0; li < e->oar.size(); ++li) {
+                const SubW& w = e->oar[e->dbg_same_layer ? 0 : li];
+                T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
+                RowsArgs r{};
+                r.x = e->xfrag; r.M = B; r.ln_w = w.ln_a; r.W = w.attn.Wqkv; r.bias = w.attn.bqkv; r.N = 3 * E; r.K = E; r.mode = ROWS_QKV;
+                r.out = e->qdec; r.ldo = E; r.cache = cache; r.scene_stride = e->kv_scene_stride; r.d_len = d_len; r.Lmax = e->Lmax; r.E = E;
+                launch_rows_mfma<T>(e->stream, r);
+                launch_attn_decode_batched<T>(e->stream, e->qdec, cache, e->kv_scene_stride, B, H, e->Lmax, d_len, e->afrag);
+                RowsArgs p{};
+                p.x = e->afrag; p.M = B; p.W = w.attn.Wo; p.bias = w.attn.bo; p.N = E; p.K = E; p.mode = ROWS_RESID; p.out = e->xdec; p.ldo = E; p.out_frag = e->xfrag; p.E = E;
+                launch_rows_mfma<T>(e->stream, p);
+                RowsArgs f{};
+                f.x = e->xfrag; f.M = B; f.ln_w = w.ln_b; f.W = w.mlp.Wfc; f.N = 4 * E; f.K = E; f.mode = ROWS_GELU; f.out_frag = e->hfrag; f.E = E;
+                launch_rows_mfma<T>(e->stream, f);
+                RowsArgs q{};
+                q.x = e->hfrag; q.M = B; q.W = w.mlp.Wproj; q.N = E; q.K = 4 * E; q.mode = ROWS_RESID; q.out = e->xdec; q.ldo = E; q.out_frag = e->xfrag; q.E = E;
+                launch_rows_mfma<T>(e->stream, q);
+            }
+            return 0;
+        }
+    }
     if (const umgen_engine::EngStream* es = sizeof(T) == 2 ? e->eng_for(e->stream) : nullptr) {
         OarEngineArgs a{};
         a.layers = e->d_layers; a.n_layers = (int)e->oar.size();
@@ -635,7 +665,16 @@ int enqueue_step(umgen_engine* e, int B, int mod, int ns, const umgen_trace* tr,
     } else {
         const void* head = mod == 1 ? e->head_ar_map : (mod == 2 ? e->head_ar_box : e->head_ar_img);
         const int V = mod == 1 ? e->cfg.map_vocab : (mod == 2 ? e->cfg.bbox3d_vocab : e->cfg.img_vocab);
-        gemv<T>(e, e->xdec, E, e->ln_oar, head, nullptr, V, E, B, GEMV_OUT_F32, e->logits, sa.ld_logits);
+        bool head_done = false;
+        if constexpr (sizeof(T) == 2) {
+            if (e->use_batched(B)) {
+                RowsArgs r{};
+                r.x = e->xfrag; r.M = B; r.ln_w = e->ln_oar; r.W = head; r.N = V; r.K = E; r.mode = ROWS_F32; r.out = e->logits; r.ldo = sa.ld_logits; r.E = E;   // (xfrag: the last layer's copy of x)
+                launch_rows_mfma<T>(e->stream, r);
+                head_done = true;
+            }
+        }
+        if (!head_done) gemv<T>(e, e->xdec, E, e->ln_oar, head, nullptr, V, E, B, GEMV_OUT_F32, e->logits, sa.ld_logits);
         // (head_tar_bbox3d on the conditioning rows, UMGen.py:1087,1103: the rows do not depend on the decoded tokens, so all 660
         //  positions were multiplied once before the loop -- tar_head_logits -- instead of one GEMV launch per bbox3d step)
         if (tr) {
@@ -885,8 +924,9 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
     }
     const bool graphs = e->cfg.use_graphs && !tr && !e->profiling;   // profiled frames time every decode step's layer kernel(s) with events
-    const umgen_engine::EngStream* eng = sizeof(T) == 2 ? e->eng_for(st) : nullptr;
-    const int eng_ng = eng ? eng->NG : 0;     // the engine's grid depends on the stream's XCDs: graphs are per (B, NG)
+    const bool batched = sizeof(T) == 2 && e->use_batched(B);       // the batched decode layer takes the step (oar_layers)
+    const umgen_engine::EngStream* eng = (sizeof(T) == 2 && !batched) ? e->eng_for(st) : nullptr;
+    const int eng_ng = eng ? eng->NG : (batched ? -2 : 0);     // the engine's grid depends on the stream's XCDs: graphs are per (B, NG)
     if (graphs && (e->step_graph_B != B || e->step_graph_NG != eng_ng)) {
         for (auto& row : e->step_graph)
             for (auto& g : row)
@@ -900,13 +940,13 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         else if (j >= kBoxC0 && j < kBoxEos) mod = 2;
         else if (j >= kImgC0 && j < kImgEos) mod = 3;
         const int ns = attn_nsplit(j + 1);          // key splits over the j cached keys + the new one
-        const int gkey = eng ? 0 : ns;              // the engine derives its key geometry from the device-side step
+        const int gkey = (eng || batched) ? 0 : ns;   // the engine / the batched layer derive their key geometry from the device-side step
         if (graphs) {
             // With the decode engine a step is 3 kernel nodes and ~600 us, and a graph launch costs ~7 us on the device (the gap between
             // the sampler of one replay and the engine of the next, rocprofv3 kernel trace): runs of steps of the same kind are replayed
             // 16 or 4 at a time (gkey 1 / 2; the engine derives everything else from the device-side step counter).
             int run = 1;
-            if (eng) {
+            if (eng || batched) {
                 int same = 1;
                 while (same < 16 && j + same < j_end) {
                     const int jn = j + same;
@@ -916,7 +956,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                 }
                 run = same >= 16 ? 16 : (same >= 4 ? 4 : 1);
             }
-            hipGraphExec_t& ge = e->step_graph[mod][eng ? (run == 16 ? 2 : (run == 4 ? 1 : 0)) : gkey];
+            hipGraphExec_t& ge = e->step_graph[mod][(eng || batched) ? (run == 16 ? 2 : (run == 4 ? 1 : 0)) : gkey];
             if (!ge) {
                 hipGraph_t g;
                 HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -970,6 +1010,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->tm.total_ms += ms;
     e->tm.frames += 1;
     e->tm.decode_engine = eng ? 1 : 0;
+    e->tm.decode_batched = batched ? 1 : 0;
     e->tm.engine_fallback = e->eng_fallback ? 1 : 0;
     if (use_px) e->tm.overlapped_frames += 1;
     if (e->profiling) {
@@ -1398,6 +1439,13 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (int rc = dalloc(e, &e->part, 3 * Bm * e->H * kAttnRec)) return rc;
     HIPCHK(e, hipMemset(e->part, 0, 3 * Bm * e->H * kAttnRec * sizeof(float)));   // never-written split slots are read with weight 0
     if (int rc = dalloc(e, &e->hdec, 3 * Bm * 4 * E)) return rc;
+    if (int rc = dalloc(e, &e->xfrag, (size_t)kRowsMaxM * E)) return rc;
+    if (int rc = dalloc(e, &e->afrag, (size_t)kRowsMaxM * E)) return rc;
+    if (int rc = dalloc(e, &e->hfrag, (size_t)kRowsMaxM * 4 * E)) return rc;
+    HIPCHK(e, hipMemset(e->xfrag, 0, (size_t)kRowsMaxM * E * 4));       // (columns past the batch are computed, never stored: keep them finite)
+    HIPCHK(e, hipMemset(e->afrag, 0, (size_t)kRowsMaxM * E * 4));
+    HIPCHK(e, hipMemset(e->hfrag, 0, (size_t)kRowsMaxM * 4 * E * 4));
+    if (const char* bd = getenv("UMGEN_DECODE_BATCHED")) e->batched_min = atoi(bd);
     if (int rc = dalloc(e, &e->logits, 3 * Bm * 8192)) return rc;
     if (int rc = dalloc(e, &e->logits_tar, Bm * kNBox * (size_t)cfg->bbox3d_vocab)) return rc;
     e->kv_scene_stride = (long)e->Lmax * 2 * E;

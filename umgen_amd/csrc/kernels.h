@@ -108,6 +108,32 @@ struct GemvResidArgs {
 template <typename T> void launch_gemv_resid(hipStream_t s, const GemvResidArgs& a);
 
 // ------------------------------------------------------------------------------------------------
+// batched decode layer for many scenes per GPU (decode_batched.hip): the scenes are the B-columns of the matrix-core instruction
+// ------------------------------------------------------------------------------------------------
+enum RowsMode {
+    ROWS_F32 = 0,    // out[m*ldo + n] = v
+    ROWS_GELU = 1,   // out[m*ldo + n] = gelu(v)
+    ROWS_QKV = 2,    // n < E: q[m][n] = v ; else K/V cache of scene m (head-major [2][H][Lmax][48]) at position *d_len
+    ROWS_RESID = 3   // out[m*ldo + n] += v
+};
+constexpr int kRowsMaxM = 64;      // scenes per rows_mfma launch (4 column blocks of 16)
+struct RowsArgs {
+    const float* x; int M;             // fp32 activations of the M <= kRowsMaxM scenes, FRAGMENT-MAJOR (decode_batched.hip: frag_index; 64 K floats)
+    const float* ln_w;                 // ROWS_QKV / _GELU / _F32: LayerNorm (weight only) of every scene's K values first (K <= 768)
+    const void* W; const float* bias; int N, K;   // weights [N][K] of the 16-bit type, K % 32 == 0
+    int mode;
+    float* out; long ldo;              // row-major outputs: q rows (ROWS_QKV), x (ROWS_RESID: read-modify-write), logits (ROWS_F32)
+    float* out_frag;                   // fragment-major outputs: gelu(c_fc) (ROWS_GELU), the copy of x the next launch streams (ROWS_RESID)
+    void* cache; long scene_stride; const int* d_len; int Lmax; int E;   // ROWS_QKV
+};
+template <typename TT> void launch_rows_mfma(hipStream_t s, const RowsArgs& a);
+void launch_rows_to_frag(hipStream_t s, const float* x, long ldx, int M, int K, float* xf);   // row-major [M][K] -> fragment-major
+// y (fragment-major) of scene b, columns h*48 .. = softmax(q_bh . K_bh^T / sqrt(48)) V_bh over keys 0 .. *d_len of the head-major decode cache,
+// one workgroup per (scene, head); q row-major [B][E]
+template <typename TT> void launch_attn_decode_batched(hipStream_t s, const float* q, const TT* cache, long scene_stride, int B, int H, int Lmax,
+                                                        const int* d_len, float* y);
+
+// ------------------------------------------------------------------------------------------------
 // XCD-resident decode engine (oar_engine.hip): all BlockOAR layers of one decode step in one launch, bf16 weights, n_embd 768
 // ------------------------------------------------------------------------------------------------
 constexpr int kEngE = 768, kEngH = 16;         // the width the engine is built for (UMGen_Large); other widths use the launches above
