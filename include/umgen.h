@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define UMGEN_ABI_VERSION 1
+#define UMGEN_ABI_VERSION 2   /* 2: umgen_rollout takes given_map / given_bbox3d; umgen_timings::decode_batched */
 
 enum {
     UMGEN_OK = 0,
@@ -107,7 +107,7 @@ typedef struct umgen_timings {
     int32_t decode_engine;  /* 1 when the last frame's decode steps ran on the XCD-resident decode engine */
     int32_t engine_fallback; /* 1 when this configuration would use the decode engine (16-bit mode, n_embd 768) but its census failed at
                               * umgen_create: the five-launch decode layer runs instead (a warning is printed at create) */
-    int32_t decode_batched; /* 1 when the last frame's decode steps ran on the batched decode layer (16 and more scenes per call: the scenes
+    int32_t decode_batched; /* 1 when the last frame's decode steps ran on the batched decode layer (32 and more scenes per call: the scenes
                               * as the matrix-core instruction's columns, csrc/decode_batched.hip) */
     int32_t reserved0;
 } umgen_timings;
@@ -130,11 +130,19 @@ int umgen_finalize_weights(umgen_engine *e);
  *   ctrl_pose/ctrl_bbox3d : NULL, or [B][T_ctl][3] / [B][T_ctl][660] control tokens (init_tokens; -1 = free).  Either may be given
  *                           alone: pose only (ego controlled), bbox3d only with control_test (agents controlled, the ego net
  *                           infers the pose; UMGen.py:1438-1473), or both (the reference's control pickles)
+ *   given_map / given_bbox3d : NULL, or [B][T_ctl][1024] / [B][T_ctl][660] tokens of the new frames that are GIVEN, not generated
+ *                           (init_tokens["map"], init_tokens["bbox3d"] without control_test: infer_oar_net's predefined-token prefix,
+ *                           UMGen.py:1184-1201 -- "use the predefined tokens and don't infer these tokens any more").  They must continue
+ *                           the pose prefix in scene order: the map, or the map and the boxes (the reference concatenates whatever is
+ *                           given back to back, so boxes without the map would sit on the map's positions: refused).  The decode loop
+ *                           replays the given positions (no head, no sampler) and starts sampling behind them; the given tokens are
+ *                           returned verbatim (UMGen.py:1640-1651).  given_bbox3d and control_test exclude each other.
  *   out_*                 : [B][T_in + new_frames][S_mod], caller-allocated
  */
 int umgen_rollout(umgen_engine *e, int32_t B, int32_t T_in, int32_t new_frames, int32_t cond_frames,
                   const int64_t *pose, const int64_t *map, const int64_t *bbox3d, const int64_t *image,
                   int32_t T_ctl, const int64_t *ctrl_pose, const int64_t *ctrl_bbox3d, int32_t control_test,
+                  const int64_t *given_map, const int64_t *given_bbox3d,
                   const umgen_sampling *sampling,
                   int64_t *out_pose, int64_t *out_map, int64_t *out_bbox3d, int64_t *out_image);
 

@@ -548,11 +548,20 @@ class OracleUMGen:
         cond[:, bs:bs + TOKEN_LEN["bbox3d"]] = x_box[:, -1, bs:bs + TOKEN_LEN["bbox3d"]]
         if tr is not None:
             tr.setdefault("cond", []).append(cond[0].numpy().copy())
-        res = self._oar(cond, ego, inputs, control_slots, seed, frame_idx, forced)
+        # modalities GIVEN for this frame besides the pose (infer_oar_net, UMGen.py:1184-1201: "use the predefined tokens and don't infer
+        # these tokens any more"): they must continue the pose prefix in scene order -- map, or map + bbox3d; image tokens are dropped by
+        # _inference (UMGen.py:1512-1520), bbox3d under control_test was consumed above (UMGen.py:1473)
+        given = {}
+        if init is not None:
+            if init.get("map") is not None:
+                given["map"] = init["map"][0, -1]
+            if init.get("bbox3d") is not None and not control_test:
+                given["bbox3d"] = init["bbox3d"][0, -1]
+        res = self._oar(cond, ego, inputs, control_slots, seed, frame_idx, forced, given)
         return res
 
     # ---- the OAR decode loop (infer_oar_net + sample_next_token, UMGen.py:1029-1273) --------------
-    def _oar(self, cond, ego, prev_tokens, control_slots, seed, frame_idx, forced):
+    def _oar(self, cond, ego, prev_tokens, control_slots, seed, frame_idx, forced, given=None):
         cfg = self.cfg
         w = self.w
         tr = self.trace
@@ -565,13 +574,26 @@ class OracleUMGen:
         pose_emb = self.fouier_pe[ego[:, 0]]                                              # [1,3,C] bf16
         prefix = torch.cat([axe[0][None, None], pose_emb.float(), axe[1][None, None]], dim=1)  # [1,5,C]
         res = {"pose": [int(t) for t in ego.view(-1)], "map": [], "bbox3d": [], "image": []}
+        given = given or {}
+        if "bbox3d" in given and "map" not in given:
+            raise ValueError("init_tokens must continue the pose prefix in scene order (map, or map + bbox3d): the reference concatenates "
+                             "the given modalities back to back (UMGen.py:1190-1201), so bbox3d without map lands on the map positions")
+        if "map" in given:       # get_mod_emb_pre + add_bos_eos of the given tokens (UMGen.py:1194-1196): GMLP(codebook) rows, no position table
+            tm = given["map"].view(-1)
+            prefix = torch.cat([prefix, axe[BOS_EOS["map"][0]][None, None], self._gmlp(tm, "map")[None], axe[BOS_EOS["map"][1]][None, None]], dim=1)
+            res["map"] = [int(t) for t in tm]
+        if "bbox3d" in given:
+            tb = given["bbox3d"].view(-1)
+            prefix = torch.cat([prefix, axe[BOS_EOS["bbox3d"][0]][None, None], w["transformer.be.weight"][tb][None], axe[BOS_EOS["bbox3d"][1]][None, None]], dim=1)
+            res["bbox3d"] = [int(t) for t in tb]
+        exist = prefix.shape[1]                                                             # exist_seq_len (UMGen.py:1199)
         decoded_boxes: List[np.ndarray] = []
         kv = [None] * cfg.n_oar_layer
-        x_in = torch.cat([task, prefix], dim=1) + cond[:, :6]                               # first call: 6 tokens
+        x_in = torch.cat([task, prefix], dim=1) + cond[:, :exist + 1]                       # first call: task + the whole given prefix
         head = {"map": "head_ar_map", "bbox3d": "head_ar_bbox3d", "image": "head_ar_img"}
         logit_trace = {"map": [], "bbox3d": [], "image": []} if tr is not None else None
         prev_box = prev_tokens["bbox3d"][0, -1].numpy()
-        for pos in range(6, SEQ_LEN + 1):                     # pos == curr_seq_len (1-based)
+        for pos in range(exist + 1, SEQ_LEN + 1):             # pos == curr_seq_len (1-based)
             if pos == SEQ_LEN:
                 break  # img-eos: the reference still runs a forward whose output is unused (UMGen.py:1209)
             x = x_in
@@ -608,7 +630,7 @@ class OracleUMGen:
                     nxt = w["transformer.be.weight"][t][None]
             x_in = nxt + cond[:, pos:pos + 1]
         if tr is not None:
-            tr.setdefault("logits", []).append({m: np.stack(v) for m, v in logit_trace.items()})
+            tr.setdefault("logits", []).append({m: (np.stack(v) if v else np.zeros((0, 0), np.float32)) for m, v in logit_trace.items()})
         return {m: np.asarray(v, dtype=np.int64) for m, v in res.items()}
 
     def _sample_bbox(self, lg, cond_row, pos, prev_box, control_slots, seed, frame_idx, u):

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import refimport  # noqa: E402
 from umgen_amd.config import tiny_config  # noqa: E402
-from umgen_amd.synth import synthetic_control, synthetic_scene  # noqa: E402
+from umgen_amd.synth import synthetic_control, synthetic_given_map, synthetic_scene  # noqa: E402
 from umgen_amd.weights import synthetic_state_dict  # noqa: E402
 
 LOGIT_POS = {"map": [0, 1, 511, 1023], "bbox3d": [0, 9, 10, 11, 330, 659], "image": [0, 255, 511]}
@@ -33,7 +33,9 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
     scene = synthetic_scene(scene_id, n_frames=input_cond_frames)
     tokens = {k: torch.from_numpy(v) for k, v in scene.items()}
     init = None
-    if control == "bbox3d":   # agent control only: the ego net infers the pose; control tokens for the first two new frames
+    if control == "map":      # the map of every new frame is given (predefined-token prefix of infer_oar_net); not control mode
+        init = {"map": torch.from_numpy(synthetic_given_map(scene_id, n_frames=new_frames)["map"])}
+    elif control == "bbox3d":   # agent control only: the ego net infers the pose; control tokens for the first two new frames
         init = {"bbox3d": torch.from_numpy(synthetic_control(scene_id, n_frames=2)["bbox3d"])}
     elif control:
         init = {k: torch.from_numpy(v) for k, v in synthetic_control(scene_id, n_frames=new_frames).items()}
@@ -65,15 +67,17 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
 
     out = model.inference(new_frames=new_frames, cond_frames=cond_frames, pred_task="pose_map_bbox3d_image",
                           input_cond_tokens=tokens, init_tokens=init, input_cond_frames=input_cond_frames,
-                          control_test=bool(control), cond_on_par=True, infer_from_gt=False)
+                          control_test=bool(control) and control != "map", cond_on_par=True, infer_from_gt=False)
     blob = {f"out_{m}": out[m].astype(np.int16) for m in out}
     blob["cond_rows"] = np.stack(rec["cond"]).astype(np.float32)
     if rec["ego_logits"]:
         blob["ego_logits"] = np.stack(rec["ego_logits"]).astype(np.float32)
     for m in LOGIT_POS:
-        blob[f"logits_{m}"] = np.stack(rec["logits"][m]).astype(np.float32)
-    blob["meta"] = np.array([weight_seed, scene_id, cond_frames, input_cond_frames, new_frames, 2 if control == "bbox3d" else int(control)],
-                            dtype=np.int64)   # last entry: 0 video, 1 pose + bbox3d control, 2 bbox3d-only control (2 control frames)
+        if rec["logits"][m]:
+            blob[f"logits_{m}"] = np.stack(rec["logits"][m]).astype(np.float32)
+    blob["meta"] = np.array([weight_seed, scene_id, cond_frames, input_cond_frames, new_frames,
+                             3 if control == "map" else (2 if control == "bbox3d" else int(control))],
+                            dtype=np.int64)   # last entry: 0 video, 1 pose + bbox3d control, 2 bbox3d-only control (2 control frames), 3 map given
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **blob)
     print("wrote", path, {k: v.shape for k, v in blob.items()})
@@ -90,7 +94,9 @@ def main():
              # growing window over several frames (configs[2]'s shape in small: 2 -> 6 history frames, then it slides): the engine's
              # slot-cache reuse runs on frames 1..4 of these rollouts
              ("tiny_grow_control_greedy", dict(weight_seed=4, scene_id=3, cond_frames=6, input_cond_frames=2, new_frames=6, control=True)),
-             ("tiny_grow_boxctl_greedy", dict(weight_seed=5, scene_id=4, cond_frames=5, input_cond_frames=2, new_frames=5, control="bbox3d"))]
+             ("tiny_grow_boxctl_greedy", dict(weight_seed=5, scene_id=4, cond_frames=5, input_cond_frames=2, new_frames=5, control="bbox3d")),
+             # the map of the new frames given as init_tokens: the decode loop starts behind a 1031-position prefix (UMGen.py:1184-1201)
+             ("tiny_mapgiven_greedy", dict(weight_seed=6, scene_id=5, cond_frames=3, input_cond_frames=2, new_frames=2, control="map"))]
     for name, kw in cases:
         if not only or name in only:
             run_case(name, cfg, **kw)

@@ -34,17 +34,18 @@ def make_engine(cfg, seed, precision, max_batch=1):
     return e
 
 
-@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy"])
+@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy", "tiny_mapgiven_greedy"])
 def test_fp32_greedy_rollout_is_token_exact_vs_reference_golden(name):
     """fp32 parity mode: the whole rollout (ego net, 3 TAR stacks, 2206-step OAR loop, rule constraint, control with pose +
-    bbox3d tokens and with bbox3d tokens alone) reproduces the token sequences recorded from the reference itself, bit for bit."""
+    bbox3d tokens and with bbox3d tokens alone, the map of every new frame GIVEN as init_tokens -- infer_oar_net's predefined-token
+    prefix, UMGen.py:1184-1201) reproduces the token sequences recorded from the reference itself, bit for bit."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
     cfg = tiny_config().greedy()
     e = make_engine(cfg, ws, "fp32")
     scene = synthetic_scene(sid, n_frames=icf)
     init = golden_init_tokens(sid, nf, ctl)
-    out = e.rollout(scene, nf, cond_frames=cf, input_cond_frames=icf, init_tokens=init, control_test=bool(ctl), seeds=[0])
+    out = e.rollout(scene, nf, cond_frames=cf, input_cond_frames=icf, init_tokens=init, control_test=ctl in (1, 2), seeds=[0])
     for m in MOD_ORDER:
         np.testing.assert_array_equal(out[m], g[f"out_{m}"].astype(np.int64), err_msg=m)
     e.close()
@@ -276,8 +277,10 @@ def test_edge_cases_single_history_frame_zero_new_frames_and_errors(oc):
     ctl = synthetic_control(30, n_frames=1)
     with pytest.raises(UMGenError, match="without control_test"):
         e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"bbox3d": ctl["bbox3d"]}, control_test=False)     # bbox3d tokens need control_test
-    with pytest.raises(UMGenError, match="not supported"):
-        e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"pose": ctl["pose"], "map": scene["map"]})
+    with pytest.raises(UMGenError, match="not supported"):       # image tokens are dropped by the reference's own decode loop (UMGen.py:1512-1520)
+        e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"pose": ctl["pose"], "image": scene["image"]})
+    with pytest.raises(UMGenError, match="given map token 8192"):
+        e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"map": np.full((1, 1, 1024), 8192)})
     with pytest.raises(UMGenError, match="shape"):
         e.rollout(scene, 1, cond_frames=2, input_cond_frames=1, init_tokens={"pose": ctl["pose"], "bbox3d": ctl["bbox3d"][:, :, :600]})
     ctl_bad = {"pose": ctl["pose"].copy(), "bbox3d": ctl["bbox3d"].copy()}

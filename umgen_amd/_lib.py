@@ -208,7 +208,7 @@ def load_library() -> C.CDLL:
     lib.umgen_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.umgen_load_tensor.argtypes = [vp, C.c_char_p, vp, i32, i64p, i32]
     lib.umgen_finalize_weights.argtypes = [vp]
-    lib.umgen_rollout.argtypes = [vp, i32, i32, i32, i32, i64p, i64p, i64p, i64p, i32, i64p, i64p, i32,
+    lib.umgen_rollout.argtypes = [vp, i32, i32, i32, i32, i64p, i64p, i64p, i64p, i32, i64p, i64p, i32, i64p, i64p,
                                   C.POINTER(Sampling), i64p, i64p, i64p, i64p]
     lib.umgen_frame.argtypes = [vp, i32, i64p, i64p, i64p, i64p, i64p, i64p, i32, C.POINTER(Sampling), i32,
                                 C.POINTER(Trace), i64p, i64p, i64p, i64p]

@@ -146,7 +146,7 @@ struct umgen_engine {
     double gemm_flops_pending = 0, attn_flops_pending = 0;
     // Batched decode layer (decode_batched.hip) from `batched_min` scenes per launch on (UMGEN_DECODE_BATCHED=n; 0 = never): the weights
     // once per step for the whole batch, the scenes as the matrix-core instruction's B-columns
-    int batched_min = 16;
+    int batched_min = 32;
     float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;   // fragment-major x / attention output [64 E], gelu(c_fc) [64 x 4E] of the batched layer
     bool use_batched(int B) const { return tsz == 2 && batched_min > 0 && B >= batched_min && B <= kRowsMaxM && E % 32 == 0 && E <= 768; }
     hipError_t launch_status = hipSuccess;   // first refused kernel launch of the frame (hipGetLastError behind the GEMM launches): fails the frame
@@ -600,6 +600,8 @@ struct FrameIO {
     int cond_cap = 0;                            // window cap (cond_frames) of the rollout; 0 = single frame, nothing follows
     bool next_follows = false;                   // another frame of the same rollout follows: run its prefix pass beside the decode
     bool next_has_ctrl_pose = false;             // ... and its pose is given, so the ego net's prefix is not needed
+    const int* given_map = nullptr;              // host [B][1024] or nullptr: the new frame's map is given (predefined-token prefix)
+    const int* given_box = nullptr;              // host [B][660] or nullptr: ... and its boxes (only behind a given map)
 };
 
 // Does the prefix pass that ran beside the previous frame's decode cover exactly this window's slots 0..P-1 ?
@@ -830,7 +832,12 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     for (int b = 0; b < B; ++b) {
         for (int a = 0; a < 3; ++a) tok0[(size_t)b * kTokPerFrame + a] = ego[b * 3 + a];
         memcpy(&prevbox[(size_t)b * kNBox], io.box + ((size_t)b * Tn + (Tn - 1)) * kNBox, kNBox * sizeof(int));
+        if (io.given_map) memcpy(&tok0[(size_t)b * kTokPerFrame + kOffMap], io.given_map + (size_t)b * kNMap, kNMap * sizeof(int));
+        if (io.given_box) memcpy(&tok0[(size_t)b * kTokPerFrame + kOffBox], io.given_box + (size_t)b * kNBox, kNBox * sizeof(int));
     }
+    // scene positions whose tokens are GIVEN (UMGen.py:1184-1201): the pose prefix always; the map, or the map and the boxes, when the
+    // caller provides them.  Their steps replay the token (fixed_token_kernel), the sampled steps start behind them.
+    const int given_end = io.given_box ? kBoxEos + 1 : (io.given_map ? kMapEos + 1 : kPoseEos + 1);
     HIPCHK(e, hipMemcpyAsync(e->d_tokens, tok0.data(), tok0.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->d_prev_box, prevbox.data(), prevbox.size() * 4, hipMemcpyHostToDevice, st));
     if (io.control_slot) HIPCHK(e, hipMemcpyAsync(e->d_control, io.control_slot, (size_t)B * kSlots, hipMemcpyHostToDevice, st));
@@ -935,10 +942,11 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         e->step_graph_NG = eng_ng;
     }
     for (int j = j_begin; j < j_end; ++j) {   // the img-eos step (j = 2206) produces nothing that is consumed
-        int mod = 0;
-        if (j >= kMapC0 && j < kMapEos) mod = 1;
-        else if (j >= kBoxC0 && j < kBoxEos) mod = 2;
-        else if (j >= kImgC0 && j < kImgEos) mod = 3;
+        auto kind_of = [given_end](int jj) {
+            if (jj < given_end) return 0;
+            return (jj >= kMapC0 && jj < kMapEos) ? 1 : (jj >= kBoxC0 && jj < kBoxEos) ? 2 : (jj >= kImgC0 && jj < kImgEos) ? 3 : 0;
+        };
+        const int mod = kind_of(j);
         const int ns = attn_nsplit(j + 1);          // key splits over the j cached keys + the new one
         const int gkey = (eng || batched) ? 0 : ns;   // the engine / the batched layer derive their key geometry from the device-side step
         if (graphs) {
@@ -949,9 +957,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
             if (eng || batched) {
                 int same = 1;
                 while (same < 16 && j + same < j_end) {
-                    const int jn = j + same;
-                    const int mn = (jn >= kMapC0 && jn < kMapEos) ? 1 : (jn >= kBoxC0 && jn < kBoxEos) ? 2 : (jn >= kImgC0 && jn < kImgEos) ? 3 : 0;
-                    if (mn != mod) break;
+                    if (kind_of(j + same) != mod) break;
                     ++same;
                 }
                 run = same >= 16 ? 16 : (same >= 4 ? 4 : 1);
@@ -1691,8 +1697,8 @@ int umgen_frame(umgen_engine* e, int32_t T, const int64_t* pose, const int64_t* 
 // UMGen.inference (UMGen.py:1542-1671)
 int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, int32_t cond_frames, const int64_t* pose,
                   const int64_t* map, const int64_t* bbox3d, const int64_t* image, int32_t T_ctl, const int64_t* ctrl_pose,
-                  const int64_t* ctrl_bbox3d, int32_t control_test, const umgen_sampling* sampling, int64_t* out_pose,
-                  int64_t* out_map, int64_t* out_bbox3d, int64_t* out_image) {
+                  const int64_t* ctrl_bbox3d, int32_t control_test, const int64_t* given_map, const int64_t* given_bbox3d,
+                  const umgen_sampling* sampling, int64_t* out_pose, int64_t* out_map, int64_t* out_bbox3d, int64_t* out_image) {
     if (!e) return UMGEN_E_INVALID;
     if (!e->finalized) return e->fail(UMGEN_E_STATE, "umgen_finalize_weights has not been called");
     if (B < 1 || B > e->cfg.max_batch) return e->fail(UMGEN_E_INVALID, "B=%d out of range [1,%d]", B, e->cfg.max_batch);
@@ -1704,6 +1710,14 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
     if ((ctrl_pose || ctrl_bbox3d) && T_ctl < 1) return e->fail(UMGEN_E_INVALID, "control tokens given with T_ctl=%d", T_ctl);
     if (ctrl_pose) { if (int rc = check_tokens(e, "control pose", ctrl_pose, (size_t)B * T_ctl * 3, e->cfg.pose_vocab, false)) return rc; }
     if (ctrl_bbox3d) { if (int rc = check_tokens(e, "control bbox3d", ctrl_bbox3d, (size_t)B * T_ctl * kNBox, e->cfg.bbox3d_vocab, true)) return rc; }
+    // given (not generated) modalities of the new frames: infer_oar_net's predefined-token prefix (UMGen.py:1184-1201)
+    if ((given_map || given_bbox3d) && T_ctl < 1) return e->fail(UMGEN_E_INVALID, "given tokens with T_ctl=%d", T_ctl);
+    if (given_bbox3d && !given_map)
+        return e->fail(UMGEN_E_UNSUPPORTED, "init_tokens['bbox3d'] without init_tokens['map'] (and without control_test): the reference concatenates the given "
+                                            "modalities back to back behind the pose, so the boxes would sit on the map's positions -- not a meaningful path");
+    if (given_bbox3d && (ctrl_bbox3d || control_test)) return e->fail(UMGEN_E_INVALID, "given bbox3d tokens and bbox3d control exclude each other");
+    if (given_map) { if (int rc = check_tokens(e, "given map", given_map, (size_t)B * T_ctl * kNMap, e->cfg.map_vocab, false)) return rc; }
+    if (given_bbox3d) { if (int rc = check_tokens(e, "given bbox3d", given_bbox3d, (size_t)B * T_ctl * kNBox, e->cfg.bbox3d_vocab, false)) return rc; }
     e->tm = umgen_timings{};
     e->overlap_suspended = false;
     const int T_out = T_in + new_frames;
@@ -1728,6 +1742,8 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
     // applying after their last frame (get_mod_tokens returns None past the end).
     bool have_ctl = (ctrl_pose != nullptr) && T_ctl > 0;
     bool have_box = (ctrl_bbox3d != nullptr) && T_ctl > 0;
+    bool have_given = (given_map != nullptr) && T_ctl > 0;   // like every init_tokens entry: None past its last frame (get_mod_tokens), and gone
+                                                              // for good with the pose tokens (UMGen.py:1613-1619)
     std::vector<int> frame_out((size_t)B * kTokPerFrame);
     for (int idx = 0; idx < new_frames; ++idx) {
         if (T_cur > cond_frames) {   // sliding window (UMGen.py:1600-1603)
@@ -1740,8 +1756,20 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
             }
             T_cur = cond_frames;
         }
-        if (have_ctl && idx >= T_ctl) { have_ctl = false; have_box = false; control_test = 0; }   // control tokens exhausted (UMGen.py:1613-1619)
+        if (have_ctl && idx >= T_ctl) { have_ctl = false; have_box = false; have_given = false; control_test = 0; }   // control tokens exhausted (UMGen.py:1613-1619)
         if (have_box && idx >= T_ctl) have_box = false;
+        if (have_given && idx >= T_ctl) have_given = false;
+        std::vector<int> gm, gb;
+        if (have_given) {
+            gm.resize((size_t)B * kNMap);
+            for (int b = 0; b < B; ++b)
+                for (int i = 0; i < kNMap; ++i) gm[(size_t)b * kNMap + i] = (int)given_map[((size_t)b * T_ctl + idx) * kNMap + i];
+            if (given_bbox3d) {
+                gb.resize((size_t)B * kNBox);
+                for (int b = 0; b < B; ++b)
+                    for (int i = 0; i < kNBox; ++i) gb[(size_t)b * kNBox + i] = (int)given_bbox3d[((size_t)b * T_ctl + idx) * kNBox + i];
+            }
+        }
         std::vector<int> cp;
         std::vector<unsigned char> cs;
         if (have_ctl) {
@@ -1766,6 +1794,8 @@ int umgen_rollout(umgen_engine* e, int32_t B, int32_t T_in, int32_t new_frames, 
         io.cond_cap = cond_frames;
         io.next_follows = idx + 1 < new_frames;
         io.next_has_ctrl_pose = have_ctl && idx + 1 < T_ctl;
+        io.given_map = gm.empty() ? nullptr : gm.data();
+        io.given_box = gb.empty() ? nullptr : gb.data();
         if (int rc = run_frame_any(e, io)) return rc;
         // append (UMGen.py:1636-1666): control pose tokens are copied verbatim; everything else is what was generated
         const int off[4] = {0, kOffMap, kOffBox, kOffImg};

@@ -544,8 +544,13 @@ __device__ inline void write_next_input(const SampleArgs& a, int b, const float*
 __global__ __launch_bounds__(256) void fixed_token_kernel(SampleArgs a) {
     const int b = blockIdx.x, j = a.st->step, E = a.tb.E;
     const int aux = fixed_aux_id(j);
+    const int* toks = a.tokens + (long)b * kTokPerFrame;
     if (aux >= 0) write_next_input(a, b, j, a.tb.axe + (long)aux * E, nullptr);
-    else write_next_input(a, b, j, nullptr, a.tb.fouier_pe + (long)a.tokens[(long)b * kTokPerFrame + (j - 1)] * E);
+    else if (j < kPoseEos) write_next_input(a, b, j, nullptr, a.tb.fouier_pe + (long)toks[j - 1] * E);
+    // GIVEN map / bbox3d tokens (infer_oar_net's predefined-token prefix, UMGen.py:1184-1201): get_mod_emb_pre of the given token --
+    // the GMLP(codebook) row / the be row, no position table -- exactly what sample_token_kernel feeds back for a sampled one
+    else if (j < kMapEos) write_next_input(a, b, j, a.tb.gmap + (long)toks[kOffMap + (j - kMapC0)] * E, nullptr);
+    else write_next_input(a, b, j, a.tb.be + (long)toks[kOffBox + (j - kBoxC0)] * E, nullptr);
     finish_step(a.st);
 }
 void launch_fixed_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchKernelGGL(fixed_token_kernel, dim3(B), dim3(256), 0, s, a); }

@@ -34,7 +34,7 @@ class Engine:
         self.precision = precision
         self.max_batch = max_batch
         c = _lib.Config(
-            abi_version=1, n_embd=cfg.n_embd, n_head=cfg.n_head, n_ego_tar_layer=cfg.n_ego_tar_layer,
+            abi_version=2, n_embd=cfg.n_embd, n_head=cfg.n_head, n_ego_tar_layer=cfg.n_ego_tar_layer,
             n_ego_ca_layer=cfg.n_ego_ca_layer, n_map_tar_layer=cfg.n_map_tar_layer, n_box_tar_layer=cfg.n_box_tar_layer,
             n_tar_layer=cfg.n_tar_layer, n_oar_layer=cfg.n_oar_layer, pose_vocab=cfg.pose_vocab_size,
             map_vocab=cfg.map_vocab_size, bbox3d_vocab=cfg.bbox3d_vocab_size, img_vocab=cfg.img_vocab_size,
@@ -122,18 +122,29 @@ class Engine:
             if arrs[m].shape != (B, T_in, CONTENT_LEN[m]):
                 raise UMGenError(f"tokens[{m}] has shape {arrs[m].shape}, expected {(B, T_in, CONTENT_LEN[m])}")
         outs = {m: np.empty((B, T_in + new_frames, CONTENT_LEN[m]), dtype=np.int64) for m in MOD_ORDER}
-        cp = cb = None
+        cp = cb = gm = gb = None
         T_ctl = 0
         if init_tokens is not None:
-            extra = [k for k, v in init_tokens.items() if v is not None and k not in ("pose", "bbox3d")]
-            if extra:   # the reference would condition infer_oar_net on them (init_mods); this engine does not implement that
-                raise UMGenError(f"init_tokens for {extra} are not supported (only 'pose' and 'bbox3d' control tokens)")
+            # init_tokens["image"] is dropped by the reference before the decode loop ("to avoid image token as init tokens",
+            # UMGen.py:1512-1520) but still copied into the output (1640-1651): not a generation path -- refused rather than imitated
+            extra = [k for k, v in init_tokens.items() if v is not None and k not in ("pose", "bbox3d", "map")]
+            if extra:
+                raise UMGenError(f"init_tokens for {extra} are not supported (pose / bbox3d control tokens, given map / map + bbox3d tokens)")
         if init_tokens is not None and init_tokens.get("pose") is not None:
             cp = _i64(init_tokens["pose"])
             if cp.ndim != 3 or cp.shape[0] != B or cp.shape[2] != CONTENT_LEN["pose"]:
                 raise UMGenError(f"init_tokens['pose'] has shape {cp.shape}, expected ({B}, T_ctl, {CONTENT_LEN['pose']})")
             T_ctl = cp.shape[1]
-        if init_tokens is not None and init_tokens.get("bbox3d") is not None:   # with or without pose tokens (UMGen.py:1458-1473)
+        if init_tokens is not None and init_tokens.get("map") is not None:      # the map of every new frame is GIVEN (UMGen.py:1184-1201)
+            gm = _i64(init_tokens["map"])
+            if gm.ndim != 3 or gm.shape[0] != B or gm.shape[2] != CONTENT_LEN["map"] or (T_ctl and gm.shape[1] != T_ctl):
+                raise UMGenError(f"init_tokens['map'] has shape {gm.shape}, expected ({B}, {T_ctl or 'T'}, {CONTENT_LEN['map']})")
+            T_ctl = gm.shape[1]
+        if init_tokens is not None and init_tokens.get("bbox3d") is not None and not control_test and gm is not None:
+            gb = _i64(init_tokens["bbox3d"])                                     # boxes given too (behind a given map)
+            if gb.shape != (B, T_ctl, CONTENT_LEN["bbox3d"]):
+                raise UMGenError(f"init_tokens['bbox3d'] has shape {gb.shape}, expected {(B, T_ctl, CONTENT_LEN['bbox3d'])}")
+        elif init_tokens is not None and init_tokens.get("bbox3d") is not None:   # with or without pose tokens (UMGen.py:1458-1473)
             cb = _i64(init_tokens["bbox3d"])
             if cp is None:
                 if cb.ndim != 3 or cb.shape[0] != B or cb.shape[2] != CONTENT_LEN["bbox3d"]:
@@ -144,7 +155,7 @@ class Engine:
         smp, keep = self._sampling(sampling or self.cfg, seeds if seeds is not None else [0] * B)
         self._check(self.lib.umgen_rollout(
             self._h, B, T_in, new_frames, cond_frames, _p64(arrs["pose"]), _p64(arrs["map"]), _p64(arrs["bbox3d"]),
-            _p64(arrs["image"]), T_ctl, _p64(cp), _p64(cb), int(control_test), C.byref(smp),
+            _p64(arrs["image"]), T_ctl, _p64(cp), _p64(cb), int(control_test), _p64(gm), _p64(gb), C.byref(smp),
             _p64(outs["pose"]), _p64(outs["map"]), _p64(outs["bbox3d"]), _p64(outs["image"])), "rollout")
         del keep
         return outs

@@ -149,7 +149,7 @@ class UMGen(nn.Module):
         init = None
         if init_tokens is not None:
             init = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
-                    for k, v in init_tokens.items() if v is not None}      # (the engine rejects anything but pose / bbox3d)
+                    for k, v in init_tokens.items() if v is not None}      # (pose / bbox3d control, given map / map + bbox3d; the engine rejects anything else)
         B = toks["pose"].shape[0]
         if B > self._engine_args["max_batch"]:      # extension over the reference (B = 1): several scenes per call
             self._recreate(max_batch=B)

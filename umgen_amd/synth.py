@@ -50,9 +50,18 @@ def synthetic_control(scene_id: int, n_frames: int = 30, slot: Optional[int] = 3
     return {"pose": pose, "bbox3d": box.reshape(1, n_frames, -1)}
 
 
+def synthetic_given_map(scene_id: int, n_frames: int = 2) -> Dict[str, np.ndarray]:
+    """init_tokens that GIVE the map of every new frame (infer_oar_net's predefined-token prefix, UMGen.py:1184-1201): map [1,n,1024]."""
+    rng = np.random.Generator(np.random.PCG64(7000 + scene_id))
+    return {"map": rng.integers(0, 8192, size=(1, n_frames, 1024), dtype=np.int64)}
+
+
 def golden_init_tokens(scene_id: int, new_frames: int, control: int) -> Optional[Dict[str, np.ndarray]]:
     """init_tokens of a recorded golden case (tests/golden/make_golden.py, meta[5]): 0 video, 1 pose + bbox3d control for every new
-    frame, 2 bbox3d-only control (the ego net infers the pose) for the first two new frames."""
+    frame, 2 bbox3d-only control (the ego net infers the pose) for the first two new frames, 3 the map of every new frame given
+    (the ego net infers the pose, the decode loop starts behind the map)."""
+    if control == 3:
+        return synthetic_given_map(scene_id, n_frames=new_frames)
     if control == 2:
         return {"bbox3d": synthetic_control(scene_id, n_frames=2)["bbox3d"]}
     return synthetic_control(scene_id, n_frames=new_frames) if control else None
