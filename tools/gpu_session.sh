@@ -38,7 +38,7 @@ b() { name=$1; shift; "$@" > gpurun_out/${R}_bench_$name.json 2> gpurun_out/${R}
 for s in "$@"; do
 echo "=== session $s"
 case $s in
-tests) timeout 2400 python -m pytest tests -x -q -m gpu ${PYTEST_K:+-k "$PYTEST_K"} --durations=8 > gpurun_out/${R}_pytest_gpu.log 2>&1; tail -25 gpurun_out/${R}_pytest_gpu.log ;;
+tests) timeout 2400 python -m pytest tests -x -q -m gpu ${PYTEST_K:+-k "$PYTEST_K"} --durations=8 -rP > gpurun_out/${R}_pytest_gpu.log 2>&1; grep -E "passed|failed|error" gpurun_out/${R}_pytest_gpu.log | tail -5; grep -E "^(UMGen_Large|full_width|deep|tiny|batched|engine vs)" gpurun_out/${R}_pytest_gpu.log | cut -c1-400 | tail -30 ;;
 smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
 bench) b full python bench.py ;;
 quick) b quick python bench.py --steps 5 --warmup 1 --no-cpu-baseline ;;
