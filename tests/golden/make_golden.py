@@ -33,8 +33,10 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
     scene = synthetic_scene(scene_id, n_frames=input_cond_frames)
     tokens = {k: torch.from_numpy(v) for k, v in scene.items()}
     init = None
-    if control == "map":      # the map of every new frame is given (predefined-token prefix of infer_oar_net); not control mode
+    if control in ("map", "map+bbox3d"):   # the map (and the boxes) of every new frame given (predefined-token prefix of infer_oar_net); not control mode
         init = {"map": torch.from_numpy(synthetic_given_map(scene_id, n_frames=new_frames)["map"])}
+        if control == "map+bbox3d":       # boxes: the synthetic scene generator's box layout of another scene id, all new frames
+            init["bbox3d"] = torch.from_numpy(synthetic_scene(900 + scene_id, n_frames=new_frames)["bbox3d"])
     elif control == "bbox3d":   # agent control only: the ego net infers the pose; control tokens for the first two new frames
         init = {"bbox3d": torch.from_numpy(synthetic_control(scene_id, n_frames=2)["bbox3d"])}
     elif control:
@@ -67,7 +69,7 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
 
     out = model.inference(new_frames=new_frames, cond_frames=cond_frames, pred_task="pose_map_bbox3d_image",
                           input_cond_tokens=tokens, init_tokens=init, input_cond_frames=input_cond_frames,
-                          control_test=bool(control) and control != "map", cond_on_par=True, infer_from_gt=False)
+                          control_test=bool(control) and control not in ("map", "map+bbox3d"), cond_on_par=True, infer_from_gt=False)
     blob = {f"out_{m}": out[m].astype(np.int16) for m in out}
     blob["cond_rows"] = np.stack(rec["cond"]).astype(np.float32)
     if rec["ego_logits"]:
@@ -76,8 +78,8 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
         if rec["logits"][m]:
             blob[f"logits_{m}"] = np.stack(rec["logits"][m]).astype(np.float32)
     blob["meta"] = np.array([weight_seed, scene_id, cond_frames, input_cond_frames, new_frames,
-                             3 if control == "map" else (2 if control == "bbox3d" else int(control))],
-                            dtype=np.int64)   # last entry: 0 video, 1 pose + bbox3d control, 2 bbox3d-only control (2 control frames), 3 map given
+                             4 if control == "map+bbox3d" else 3 if control == "map" else (2 if control == "bbox3d" else int(control))],
+                            dtype=np.int64)   # last entry: 0 video, 1 pose + bbox3d control, 2 bbox3d-only control (2 control frames), 3 map given, 4 map + bbox3d given
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **blob)
     print("wrote", path, {k: v.shape for k, v in blob.items()})
@@ -96,7 +98,8 @@ def main():
              ("tiny_grow_control_greedy", dict(weight_seed=4, scene_id=3, cond_frames=6, input_cond_frames=2, new_frames=6, control=True)),
              ("tiny_grow_boxctl_greedy", dict(weight_seed=5, scene_id=4, cond_frames=5, input_cond_frames=2, new_frames=5, control="bbox3d")),
              # the map of the new frames given as init_tokens: the decode loop starts behind a 1031-position prefix (UMGen.py:1184-1201)
-             ("tiny_mapgiven_greedy", dict(weight_seed=6, scene_id=5, cond_frames=3, input_cond_frames=2, new_frames=2, control="map"))]
+             ("tiny_mapgiven_greedy", dict(weight_seed=6, scene_id=5, cond_frames=3, input_cond_frames=2, new_frames=2, control="map")),
+             ("tiny_mapboxgiven_greedy", dict(weight_seed=7, scene_id=6, cond_frames=3, input_cond_frames=2, new_frames=2, control="map+bbox3d"))]
     for name, kw in cases:
         if not only or name in only:
             run_case(name, cfg, **kw)

@@ -151,6 +151,27 @@ def test_16bit_teacher_forced_frame_at_production_width_lies_inside_the_oracle_e
         assert dist[m] <= bar["logits"], (m, dist)
 
 
+def test_batched_decode_layer_lies_inside_the_oracle_ensemble_at_depth():
+    """The batched decode layer (32 and more scenes per call: csrc/decode_batched.hip, the scenes as the MFMA's columns) facing the
+    ORACLE, not another engine path: the `deep` production-width frame (10 BlockOAR layers) teacher-forced through it
+    (UMGEN_DECODE_BATCHED=1 sends a single scene down the same kernels; its results do not depend on the batch) must lie within
+    2 x the spread of the rounding-aware oracle's accumulation-order ensemble, like the XCD-resident engine."""
+    from tests.test_gpu_parity import check_inside_ensemble
+    for precision in ("bf16", "fp16"):
+        ens = np.load(os.path.join(GOLD, f"ensemble_deep_{precision}_engine.npz"))
+        cfg = width_config("deep")
+        scene = synthetic_scene(SCENE_ID, n_frames=2)
+        forced = {m: ens[f"tok_{m}"].astype(np.int64) for m in MOD_ORDER}
+        with env(UMGEN_DECODE_BATCHED=1):
+            e = Engine(cfg, precision=precision, max_cond_frames=4)
+        e.load_state_dict(synthetic_state_dict(cfg, seed=WEIGHT_SEED))
+        e.finalize()
+        toks, tr = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, trace=True, forced=forced)
+        assert e.timings()["decode_batched"] == 1 and e.timings()["decode_engine"] == 0
+        e.close()
+        check_inside_ensemble(ens, tr, COND_ROWS, LOGIT_POS, f"deep {precision} (batched decode layer)")
+
+
 def test_bf16_teacher_forced_logits_at_2x_width_vs_rounding_aware_oracle_golden():
     """Config #5's doubled width (E=1536, H=32; five-launch decode layer) in bf16 against one run of the rounding-aware oracle
     (no ensemble at this width: one oracle frame takes ~10 CPU minutes): 1.5e-2 absolute / 4e-3 relative rms on logits, every

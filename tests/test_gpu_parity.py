@@ -34,10 +34,10 @@ def make_engine(cfg, seed, precision, max_batch=1):
     return e
 
 
-@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy", "tiny_mapgiven_greedy"])
+@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy", "tiny_mapgiven_greedy", "tiny_mapboxgiven_greedy"])
 def test_fp32_greedy_rollout_is_token_exact_vs_reference_golden(name):
     """fp32 parity mode: the whole rollout (ego net, 3 TAR stacks, 2206-step OAR loop, rule constraint, control with pose +
-    bbox3d tokens and with bbox3d tokens alone, the map of every new frame GIVEN as init_tokens -- infer_oar_net's predefined-token
+    bbox3d tokens and with bbox3d tokens alone, the map -- or the map and the boxes -- of every new frame GIVEN as init_tokens -- infer_oar_net's predefined-token
     prefix, UMGen.py:1184-1201) reproduces the token sequences recorded from the reference itself, bit for bit."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]

@@ -59,9 +59,11 @@ def synthetic_given_map(scene_id: int, n_frames: int = 2) -> Dict[str, np.ndarra
 def golden_init_tokens(scene_id: int, new_frames: int, control: int) -> Optional[Dict[str, np.ndarray]]:
     """init_tokens of a recorded golden case (tests/golden/make_golden.py, meta[5]): 0 video, 1 pose + bbox3d control for every new
     frame, 2 bbox3d-only control (the ego net infers the pose) for the first two new frames, 3 the map of every new frame given
-    (the ego net infers the pose, the decode loop starts behind the map)."""
+    (the ego net infers the pose, the decode loop starts behind the map), 4 the map and the boxes given."""
     if control == 3:
         return synthetic_given_map(scene_id, n_frames=new_frames)
+    if control == 4:      # the map and the boxes of every new frame given (boxes: the scene generator's layout of another scene id)
+        return {"map": synthetic_given_map(scene_id, n_frames=new_frames)["map"], "bbox3d": synthetic_scene(900 + scene_id, n_frames=new_frames)["bbox3d"]}
     if control == 2:
         return {"bbox3d": synthetic_control(scene_id, n_frames=2)["bbox3d"]}
     return synthetic_control(scene_id, n_frames=new_frames) if control else None
