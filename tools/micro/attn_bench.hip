@@ -40,10 +40,10 @@ int main(int argc, char** argv) {
     for (int v : variants) {
         g_attn_variant = v;
         hipMemset(dy, 0, ny * 2);
-        for (int i = 0; i < 3; ++i) launch_attn_spatial_bf16_mfma(nullptr, dqk, dvt, dy, F, S, S_pad, H);
+        for (int i = 0; i < 3; ++i) launch_attn_spatial_mfma<bf16_t>(nullptr, dqk, dvt, dy, F, S, S_pad, H);
         const int reps = 20;
         hipEventRecord(e0, nullptr);
-        for (int i = 0; i < reps; ++i) launch_attn_spatial_bf16_mfma(nullptr, dqk, dvt, dy, F, S, S_pad, H);
+        for (int i = 0; i < reps; ++i) launch_attn_spatial_mfma<bf16_t>(nullptr, dqk, dvt, dy, F, S, S_pad, H);
         hipEventRecord(e1, nullptr);
         if (hipEventSynchronize(e1) != hipSuccess) { printf("variant %d: launch failed\n", v); return 1; }
         float ms = 0.f;

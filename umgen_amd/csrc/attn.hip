@@ -576,6 +576,7 @@ void launch_attn_spatial_mfma(hipStream_t s, const TT* qk, const TT* vt, TT* y, 
         const int nw = ((OPT) & 8192) ? 8 : 4, nq2 = (S + nw * QT * 16 - 1) / (nw * QT * 16); \
         hipLaunchKernelGGL((attn_spatial_mfma2_kernel<QT, OPT>), dim3(pairs * nq2), dim3(nw * 64), 0, s, qk, vt, y, S, S_pad, H, nq2, F * H); \
         return; }
+    if constexpr (sizeof(TT) == 2 && !__is_same(TT, f16_t)) {   // (the variant kernels exist for bf16 only)
     switch (g_attn_variant) {
         UMGEN_ATTN_CASE(1) UMGEN_ATTN_CASE(2) UMGEN_ATTN_CASE(3) UMGEN_ATTN_CASE(7) UMGEN_ATTN_CASE(11) UMGEN_ATTN_CASE(15)
         UMGEN_ATTN_CASE(19) UMGEN_ATTN_CASE(23) UMGEN_ATTN_CASE(27) UMGEN_ATTN_CASE(31) UMGEN_ATTN_CASE(32)
@@ -584,6 +585,7 @@ void launch_attn_spatial_mfma(hipStream_t s, const TT* qk, const TT* vt, TT* y, 
         UMGEN_ATTN_CASE(4096) UMGEN_ATTN_CASE(4099) UMGEN_ATTN_CASE(4103) UMGEN_ATTN_CASE(4107) UMGEN_ATTN_CASE(4115)
         UMGEN_ATTN_CASE(12288) UMGEN_ATTN_CASE(12291) UMGEN_ATTN_CASE(12295)
         default: break;
+    }
     }
 #undef UMGEN_ATTN_CASE
 #endif
