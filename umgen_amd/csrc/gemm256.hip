@@ -17,7 +17,6 @@
 //     wave so that global memory sees whole 256-byte token-row pieces; no workgroup barrier inside the epilogue.
 // Accumulation order of every output element: k ascending in steps of 32 inside the MFMA, the same for every tile position, so
 // results do not depend on which other rows are in the launch (scenes stay batch-invariant).
-#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -42,7 +41,7 @@ struct Src { unsigned p[2][2], q[2][2]; };   // element offsets of this lane's 1
 constexpr bool STAGGER = UMGEN_GEMM256_STAGGER;
 
 template <int MODE, typename TT>
-__global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int nJ, int splitI, int desync_ticks) {
+__global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int nJ, int splitI) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     typedef typename Mma16<TT>::vec vec8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,16 +60,6 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
     const int count = ni * nj;
     int t = lb;
     if (t >= count) return;
-    // DESYNCHRONISED WORKGROUPS.  Every workgroup's tile takes the same time, so 256 persistent workgroups that start together stay in
-    // lockstep: all of them are in their k-loops together (HBM idle), then all of them write their 128 KB (STORE) or read-modify-write
-    // their 512 KB (RESID) together -- a 33 / 134 MB burst that drains at ~4.5 TB/s while every matrix core waits (measured: the
-    // epilogue of a K = 768 tile costs 5 k-tiles' worth in STORE mode and 18 in RESID mode, profiles/r03_gemm_bench_256tile_stagger.txt).
-    // A start offset of (local index % 4) quarter tiles spreads the memory phases of the workgroups over each other's k-loops.
-    if (desync_ticks > 0) {
-        const long long t0 = wall_clock64();
-        const long long wait = (long long)(lb & 3) * desync_ticks;
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
     auto make_src = [&](int tt) {
         const int ti = i0 + tt % ni, tj = j0 + tt / ni;
         Src s;
@@ -347,16 +336,10 @@ void launch_gemm256(hipStream_t s, const GemmArgs& a) {
     // feature split over the XCDs only when the weight matrix would not stay in one 4 MB L2 and the feature tiles divide evenly
     const int splitI = (nI % 2 == 0 && (size_t)a.Mi * a.K * 2 > (size_t)(3u << 20)) ? 2 : 1;
     const dim3 grid(n_cu), block(512);
-    // start offsets (100 MHz ticks per quarter tile): only when a workgroup has enough tiles for the offset to pay (UMGEN_GEMM256_DESYNC=
-    // ticks per k-tile and quarter, 0 = off)
-    static const int desync_per_kt = getenv("UMGEN_GEMM256_DESYNC") ? atoi(getenv("UMGEN_GEMM256_DESYNC")) : 45;
-    static const int desync_min_tiles = getenv("UMGEN_GEMM256_DESYNC_MIN") ? atoi(getenv("UMGEN_GEMM256_DESYNC_MIN")) : 4;
-    const long tiles_per_wg = ((long)nI * nJ + n_cu - 1) / n_cu;
-    const int desync = tiles_per_wg >= desync_min_tiles ? desync_per_kt * (a.K / HK) : 0;
     switch (a.mode) {
-        case GEMM_STORE: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE, TT>), grid, block, kLds256, s, a, nI, nJ, splitI, desync); break;
-        case GEMM_RESID: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_RESID, TT>), grid, block, kLds256, s, a, nI, nJ, splitI, desync); break;
-        default: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE_F32, TT>), grid, block, kLds256, s, a, nI, nJ, splitI, desync); break;
+        case GEMM_STORE: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE, TT>), grid, block, kLds256, s, a, nI, nJ, splitI); break;
+        case GEMM_RESID: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_RESID, TT>), grid, block, kLds256, s, a, nI, nJ, splitI); break;
+        default: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE_F32, TT>), grid, block, kLds256, s, a, nI, nJ, splitI); break;
     }
 }
 template void launch_gemm256<bf16_t>(hipStream_t, const GemmArgs&);
