@@ -7,6 +7,7 @@
 #   bench      the default bench line (30 frames, CPU-baseline sample)                  -> r04_bench_full.json
 #   variants   fp16 / fp32 / batches / control / five-launch layer / 2x width lines       -> r04_bench_<name>.json
 #   batched    16 / 32 / 64 scenes per GPU on the batched decode layer, 32 on the engine  -> r04_bench_b{16,32,64,32_engine}.json
+#   lanes      decode-lane sweep of the batched layer at 16 / 32 / 64 scenes                  -> r04_bench_b{16,32,64}_lanes<n>.json
 #   control    configs[2] (control, 4 scenes, window 13 -> 20) with and without the slot-cache reuse (f-3) -> r04_bench_control_b4{,_nogrow}.json
 #   fp32ab     fp32 parity mode on the matrix cores vs the VALU kernel                   -> r04_bench_fp32{,_valu}.json
 #   stats      rocprofv3 --kernel-trace --stats of bench.py --steps 3                    -> r04_rocprofv3_kernel_stats_bench_steps3.csv
@@ -57,6 +58,10 @@ batched)
   b b64 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 64
   b b16_engine env UMGEN_DECODE_BATCHED=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 16
   b b32_engine env UMGEN_DECODE_BATCHED=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 32 ;;
+lanes)   # decode lanes (sub-batches of the batched layer on their own streams): lane count sweep at 16 / 32 / 64 scenes
+  for n in ${LANES_B32:-1 2 4 8}; do b b32_lanes$n env UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 32; done
+  for n in ${LANES_B64:-2 4 8}; do b b64_lanes$n env UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 64; done
+  for n in ${LANES_B16:-2 4}; do b b16_lanes$n env UMGEN_DECODE_BATCHED=16 UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 16; done ;;
 wide)
   b wide2x python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x
   b wide2x_h40 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x --history 40 ;;

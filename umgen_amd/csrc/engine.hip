@@ -148,7 +148,34 @@ struct umgen_engine {
     // once per step for the whole batch, the scenes as the matrix-core instruction's B-columns
     int batched_min = 32;
     float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;   // fragment-major x / attention output [64 E], gelu(c_fc) [64 x 4E] of the batched layer
-    bool use_batched(int B) const { return tsz == 2 && batched_min > 0 && B >= batched_min && B <= kRowsMaxM && E % 32 == 0 && E <= 768; }
+    bool use_batched(int B) const {      // (in_lanes: a lane's sub-batch of a batch that qualified)
+        return tsz == 2 && (in_lanes || (batched_min > 0 && B >= batched_min)) && B <= kRowsMaxM && E % 32 == 0 && E <= 768;
+    }
+    // Decode LANES: the scenes of a batch are independent until the frame is complete (own K/V rows, own sampler state, own RNG
+    // stream), and a batched layer launch for <= 16 scenes is latency-bound (5 dependent launches per layer, 48 - 96 workgroups each,
+    // 34 us per layer whatever the batch is) while its attention launch is the only part at the HBM roof.  The batch is therefore cut
+    // into `lanes` sub-batches, each with its own stream, OarState, fragment buffers and step graphs, forked once behind the TAR stacks
+    // and joined once before the token download: one lane's weight GEMMs run in the shadow of another lane's K/V stream.  Tokens are
+    // those of the single-lane batched layer bit for bit (a scene's column never mixes with another's, decode_batched.hip).
+    static constexpr int kMaxLanes = 8;
+    struct DecLane {
+        hipStream_t s = nullptr;
+        hipEvent_t done = nullptr;
+        OarState* st = nullptr;
+        float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;
+        hipGraphExec_t graph[4][3] = {};
+    };
+    DecLane lane[kMaxLanes];
+    hipEvent_t ev_lane_fork = nullptr;
+    int lanes_env = -1;                  // UMGEN_DECODE_LANES=n: n lanes whenever the batched layer runs (1 = off); -1: by batch size
+    int lane_graph_B = 0, lane_graph_n = 0;
+    bool in_lanes = false;               // enqueueing a lane's steps (a profiled frame times them around the graph launches, not inside enqueue_step)
+    int lane_count(int B) const {
+        if (!use_batched(B) || !lane[0].s) return 1;
+        int n = lanes_env > 0 ? lanes_env : std::max(1, B / 8);    // 8 scenes per lane up to 32 scenes, 4 lanes beyond
+        if (lanes_env <= 0) n = std::min(n, 4);
+        return std::max(1, std::min(std::min(n, kMaxLanes), B));
+    }
     hipError_t launch_status = hipSuccess;   // first refused kernel launch of the frame (hipGetLastError behind the GEMM launches): fails the frame
 
     int fail(int code, const char* fmt, ...) {
@@ -633,12 +660,45 @@ void decode_pose_shift(const int* pose, const int* ego, int B, int Tn, std::vect
             }
 }
 
+// What a decode step reads and writes per scene, as the engine's members: a decode lane swaps in the view of its sub-batch (scenes
+// b0 .. b0 + nb - 1 of every per-scene array, its own stream / step state / fragment buffers) around enqueue_step.
+struct DecView {
+    hipStream_t stream;
+    float *xdec, *qdec, *logits, *logits_tar, *cond, *xfrag, *afrag, *hfrag;
+    void* kvcache;
+    int *d_tokens, *d_prev_box, *d_nboxes;
+    unsigned char* d_control;
+    double* d_boxes;
+    unsigned long long* d_seeds;
+    OarState* d_state;
+};
+DecView current_view(const umgen_engine* e) {
+    return DecView{e->stream, e->xdec, e->qdec, e->logits, e->logits_tar, e->cond, e->xfrag, e->afrag, e->hfrag, e->kvcache,
+                   e->d_tokens, e->d_prev_box, e->d_nboxes, e->d_control, e->d_boxes, e->d_seeds, e->d_state};
+}
+void apply_view(umgen_engine* e, const DecView& v) {
+    e->stream = v.stream; e->xdec = v.xdec; e->qdec = v.qdec; e->logits = v.logits; e->logits_tar = v.logits_tar; e->cond = v.cond;
+    e->xfrag = v.xfrag; e->afrag = v.afrag; e->hfrag = v.hfrag; e->kvcache = v.kvcache; e->d_tokens = v.d_tokens; e->d_prev_box = v.d_prev_box;
+    e->d_nboxes = v.d_nboxes; e->d_control = v.d_control; e->d_boxes = v.d_boxes; e->d_seeds = v.d_seeds; e->d_state = v.d_state;
+}
+DecView lane_view(const umgen_engine* e, const DecView& all, const umgen_engine::DecLane& ln, int b0) {
+    const long E = e->E;
+    DecView v = all;
+    v.stream = ln.s; v.d_state = ln.st; v.xfrag = ln.xfrag; v.afrag = ln.afrag; v.hfrag = ln.hfrag;
+    v.xdec = all.xdec + b0 * E; v.qdec = all.qdec + b0 * E; v.logits = all.logits + (long)b0 * 8192;
+    v.logits_tar = all.logits_tar + (long)b0 * kNBox * e->cfg.bbox3d_vocab; v.cond = all.cond + (long)b0 * kSeq * E;
+    v.kvcache = static_cast<unsigned char*>(all.kvcache) + (size_t)b0 * e->kv_scene_stride * e->tsz;
+    v.d_tokens = all.d_tokens + (long)b0 * kTokPerFrame; v.d_prev_box = all.d_prev_box + (long)b0 * kNBox; v.d_nboxes = all.d_nboxes + b0;
+    v.d_control = all.d_control + (long)b0 * kSlots; v.d_boxes = all.d_boxes + (long)b0 * 64 * 10; v.d_seeds = all.d_seeds + b0;
+    return v;
+}
+
 // kernels of one decode step of kind mod (0 fixed token, 1 map, 2 bbox3d, 3 image) for B scenes
 template <typename T>
 int enqueue_step(umgen_engine* e, int B, int mod, int ns, const umgen_trace* tr, int j) {
     const int E = e->E;
     hipStream_t st = e->stream;
-    const bool time_layers = e->profiling && !e->in_capture;
+    const bool time_layers = e->profiling && !e->in_capture && !e->in_lanes;
     if (time_layers) {
         if (e->layer_ev_used == e->layer_ev.size()) {
             hipEvent_t a0, a1;
@@ -860,6 +920,8 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     OarState s0{j_begin, io.frame_idx, forced ? 1 : 0, io.control_slot ? 1 : 0, 0, e->eng_epoch, sp};
     e->eng_epoch += (unsigned)(kImgEos + 1) * kEpochPerStep;
     HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+    const int n_lanes = (sizeof(T) == 2 && !tr) ? e->lane_count(B) : 1;      // decode lanes: every lane steps its own copy of the state
+    for (int l = 0; l < n_lanes && n_lanes > 1; ++l) HIPCHK(e, hipMemcpyAsync(e->lane[l].st, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
 
     // Step 2: the three TAR stacks (UMGen.py:1484-1494) and the conditioning rows (1496-1511)
     WindowTokens ws{e->d_pose_shift, e->d_map, e->d_box, e->d_img, B, Tc, Tn, t0};
@@ -941,6 +1003,85 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         e->step_graph_B = B;
         e->step_graph_NG = eng_ng;
     }
+    if (n_lanes > 1) {
+        // Decode lanes (umgen_engine::DecLane): fork behind the first input, every lane replays the step runs for its scenes on its own
+        // stream, join before the token download.  Step runs are graphs in every mode but --no-graphs (a profiled frame times lane 0's
+        // runs around the graph launches: eager launches of n lanes x 182 kernels per step would measure the host).
+        auto kind_of = [given_end](int jj) {
+            if (jj < given_end) return 0;
+            return (jj >= kMapC0 && jj < kMapEos) ? 1 : (jj >= kBoxC0 && jj < kBoxEos) ? 2 : (jj >= kImgC0 && jj < kImgEos) ? 3 : 0;
+        };
+        const bool lane_graphs = e->cfg.use_graphs;
+        if (e->lane_graph_B != B || e->lane_graph_n != n_lanes) {
+            for (auto& ln : e->lane)
+                for (auto& row : ln.graph)
+                    for (auto& g : row)
+                        if (g) { hipGraphExecDestroy(g); g = nullptr; }
+            e->lane_graph_B = B;
+            e->lane_graph_n = n_lanes;
+        }
+        const DecView all = current_view(e);
+        struct RestoreView { umgen_engine* e; DecView v; ~RestoreView() { apply_view(e, v); e->in_lanes = false; e->in_capture = false; } } restore_view{e, all};
+        e->in_lanes = true;
+        HIPCHK(e, hipEventRecord(e->ev_lane_fork, st));
+        int b0s[umgen_engine::kMaxLanes], nbs[umgen_engine::kMaxLanes];
+        for (int l = 0, b0 = 0; l < n_lanes; ++l) {
+            nbs[l] = B / n_lanes + (l < B % n_lanes ? 1 : 0);
+            b0s[l] = b0;
+            b0 += nbs[l];
+            HIPCHK(e, hipStreamWaitEvent(e->lane[l].s, e->ev_lane_fork, 0));
+        }
+        for (int j = j_begin; j < j_end; ++j) {
+            const int mod = kind_of(j);
+            int same = 1;
+            while (same < 16 && j + same < j_end && kind_of(j + same) == mod) ++same;
+            const int run = !lane_graphs ? 1 : (same >= 16 ? 16 : (same >= 4 ? 4 : 1));
+            const int ri = run == 16 ? 2 : (run == 4 ? 1 : 0);
+            for (int l = 0; l < n_lanes; ++l) {
+                umgen_engine::DecLane& ln = e->lane[l];
+                apply_view(e, lane_view(e, all, ln, b0s[l]));
+                const bool timed = e->profiling && l == 0;
+                if (timed) {
+                    if (e->layer_ev_used == e->layer_ev.size()) {
+                        hipEvent_t a0, a1;
+                        hipEventCreate(&a0);
+                        hipEventCreate(&a1);
+                        e->layer_ev.emplace_back(a0, a1);
+                    }
+                    hipEventRecord(e->layer_ev[e->layer_ev_used].first, ln.s);
+                }
+                if (lane_graphs) {
+                    hipGraphExec_t& ge = ln.graph[mod][ri];
+                    if (!ge) {
+                        hipGraph_t g;
+                        HIPCHK(e, hipStreamBeginCapture(ln.s, hipStreamCaptureModeThreadLocal));
+                        e->in_capture = true;
+                        int crc = 0;
+                        for (int r = 0; r < run && !crc; ++r) crc = enqueue_step<T>(e, nbs[l], mod, 1, nullptr, 0);
+                        e->in_capture = false;
+                        if (crc) return crc;   // (run_frame_any ends the open capture)
+                        HIPCHK(e, hipStreamEndCapture(ln.s, &g));
+                        HIPCHK(e, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                        HIPCHK(e, hipGraphDestroy(g));
+                    }
+                    HIPCHK(e, hipGraphLaunch(ge, ln.s));
+                } else if (int rc = enqueue_step<T>(e, nbs[l], mod, 1, nullptr, j)) {
+                    return rc;
+                }
+                if (timed) {
+                    hipEventRecord(e->layer_ev[e->layer_ev_used++].second, ln.s);
+                    e->tm.layers_launches += run - 1;      // (the frame's bookkeeping below adds one per event pair)
+                }
+                e->tm.oar_kernels += (int64_t)run * (5 * (int64_t)e->oar.size() + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
+            }
+            j += run - 1;
+        }
+        for (int l = 0; l < n_lanes; ++l) {
+            HIPCHK(e, hipEventRecord(e->lane[l].done, e->lane[l].s));
+            HIPCHK(e, hipStreamWaitEvent(st, e->lane[l].done, 0));
+        }
+        j_begin = j_end;     // (the single-stream loop below has nothing left to do)
+    }
     for (int j = j_begin; j < j_end; ++j) {   // the img-eos step (j = 2206) produces nothing that is consumed
         auto kind_of = [given_end](int jj) {
             if (jj < given_end) return 0;
@@ -1017,6 +1158,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     e->tm.frames += 1;
     e->tm.decode_engine = eng ? 1 : 0;
     e->tm.decode_batched = batched ? 1 : 0;
+    e->tm.decode_lanes = batched ? n_lanes : 0;
     e->tm.engine_fallback = e->eng_fallback ? 1 : 0;
     if (use_px) e->tm.overlapped_frames += 1;
     if (e->profiling) {
@@ -1067,7 +1209,8 @@ int run_frame_any(umgen_engine* e, const FrameIO& io) {
         // A failed frame may have left a stream capture open, async copies in flight that read this call's host buffers, and a
         // background pass the next call would wait for: drain everything and forget the pass (the error message is kept).
         const std::string msg = e->err;
-        for (hipStream_t s : {e->stream, e->full_stream, e->bg_stream, e->side_stream[0], e->side_stream[1]}) {
+        for (hipStream_t s : {e->stream, e->full_stream, e->bg_stream, e->side_stream[0], e->side_stream[1], e->lane[0].s, e->lane[1].s, e->lane[2].s,
+                              e->lane[3].s, e->lane[4].s, e->lane[5].s, e->lane[6].s, e->lane[7].s}) {
             if (!s) continue;
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
@@ -1452,6 +1595,21 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     HIPCHK(e, hipMemset(e->afrag, 0, (size_t)kRowsMaxM * E * 4));
     HIPCHK(e, hipMemset(e->hfrag, 0, (size_t)kRowsMaxM * 4 * E * 4));
     if (const char* bd = getenv("UMGEN_DECODE_BATCHED")) e->batched_min = atoi(bd);
+    if (const char* dl = getenv("UMGEN_DECODE_LANES")) e->lanes_env = atoi(dl);
+    if (e->tsz == 2 && Bm >= 2 && e->lanes_env != 1) {      // decode lanes: streams, step states and fragment buffers (1.2 MB per lane)
+        for (auto& ln : e->lane) {
+            HIPCHK(e, hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
+            HIPCHK(e, hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+            if (int rc = dalloc(e, &ln.st, (size_t)1)) return rc;
+            if (int rc = dalloc(e, &ln.xfrag, (size_t)kRowsMaxM * E)) return rc;
+            if (int rc = dalloc(e, &ln.afrag, (size_t)kRowsMaxM * E)) return rc;
+            if (int rc = dalloc(e, &ln.hfrag, (size_t)kRowsMaxM * 4 * E)) return rc;
+            HIPCHK(e, hipMemset(ln.xfrag, 0, (size_t)kRowsMaxM * E * 4));
+            HIPCHK(e, hipMemset(ln.afrag, 0, (size_t)kRowsMaxM * E * 4));
+            HIPCHK(e, hipMemset(ln.hfrag, 0, (size_t)kRowsMaxM * 4 * E * 4));
+        }
+        HIPCHK(e, hipEventCreateWithFlags(&e->ev_lane_fork, hipEventDisableTiming));
+    }
     if (int rc = dalloc(e, &e->logits, 3 * Bm * 8192)) return rc;
     if (int rc = dalloc(e, &e->logits_tar, Bm * kNBox * (size_t)cfg->bbox3d_vocab)) return rc;
     e->kv_scene_stride = (long)e->Lmax * 2 * E;
@@ -1877,6 +2035,14 @@ int umgen_destroy(umgen_engine* e) {
     for (auto& row : e->step_graph)
         for (auto& g : row)
             if (g) hipGraphExecDestroy(g);
+    for (auto& ln : e->lane) {
+        for (auto& row : ln.graph)
+            for (auto& g : row)
+                if (g) hipGraphExecDestroy(g);
+        if (ln.s) { hipStreamSynchronize(ln.s); hipStreamDestroy(ln.s); }
+        if (ln.done) hipEventDestroy(ln.done);
+    }
+    if (e->ev_lane_fork) hipEventDestroy(e->ev_lane_fork);
     for (void* p : e->allocs) hipFree(p);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : e->gemm_ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
