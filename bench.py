@@ -247,8 +247,15 @@ def main():
         ach = layer_bytes / (layers_us * 1e-6) / 1e9 if layers_us > 0 else 0.0
         oar_gbs = (tm["oar_bytes"] / (tm["oar_ms"] * 1e-3) / 1e9) if tm["oar_ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic_per_launch(engine_on and B == 1 and args.config == "large")
-        kname = ("umgen::oar_engine_kernel (XCD-resident decode engine: the 36 BlockOAR layers of a decode step in one launch)" if engine_on else
-                 "OAR decode layers as launches (gemv_ln_kernel x72, attn_partial_kernel x36, gemv_resid_kernel x72 per step)")
+        lanes = int(tm.get("decode_lanes", 0))
+        if engine_on:
+            kname = "umgen::oar_engine_kernel (XCD-resident decode engine: the 36 BlockOAR layers of a decode step in one launch)"
+        elif tm.get("decode_batched"):
+            kname = ("batched decode layer (rows_mfma_kernel x144 + attn_decode_batched_kernel x36 per step and lane; scenes as the MFMA's B-columns)" +
+                     (f", {lanes} decode lanes on their own streams: avg_launch_us = lane 0's whole step (layers + head + sampler) in the profiled frame, "
+                      "all lanes running" if lanes > 1 else ""))
+        else:
+            kname = "OAR decode layers as launches (gemv_ln_kernel x72, attn_partial_kernel x36, gemv_resid_kernel x72 per step)"
         res = {
             "metric": "scene_tokens_per_sec", "value": value, "unit": "scene-tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
@@ -282,7 +289,8 @@ def main():
             "prefill_ms_unoverlapped": {"ego": tp["ego_ms"], "tar": tp["tar_ms"]},
             "weight_load_s": t_load,
             "closed_loop": closed_loop_record(args.precision) if args.config == "large" else None,
-            "decode_engine": int(engine_on), "engine_fallback": int(tm["engine_fallback"]),
+            "decode_engine": int(engine_on), "engine_fallback": int(tm["engine_fallback"]), "decode_batched": int(tm.get("decode_batched", 0)),
+            "decode_lanes": lanes,
         }
         if args.share_gpu:
             res["dry_run"] = f"{world} ranks SHARING cuda:0 over gloo: exercises the N > 1 code path only; value is not a scaling measurement"

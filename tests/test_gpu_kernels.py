@@ -77,6 +77,30 @@ def test_linear_256_tile_kernel(prec, R, N, K, gelu, resid):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("R,N,K,gelu,resid", [(9000, 768, 3072, 0, 1), (5000, 3072, 768, 1, 0), (2049, 768, 768, 0, 0)])
+def test_linear_256_tile_kernel_row_chunks(monkeypatch, R, N, K, gelu, resid):
+    """The 256-tile kernel addresses its operands with 32-bit element offsets; more token rows than 2^31 / ld elements (16 scenes' K = 3072
+    activations) go out as several launches on whole-tile row chunks (launch_gemm256).  With the chunk size forced down to 2048 rows the
+    outputs are bit-identical to the one-launch form and to the 128-tile kernels."""
+    rng = np.random.default_rng(R + N + K + 1)
+    act = rng.standard_normal((R, K), dtype=np.float32)
+    W = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal((N,), dtype=np.float32) * 0.1
+    x0 = rng.standard_normal((R, N), dtype=np.float32) if resid else None
+    a_in, w_in = bits16(act, 1), bits16(W, 1)
+    outs = []
+    for flag, chunk in ((16, "2048"), (16, None), (32, None)):
+        if chunk:
+            monkeypatch.setenv("UMGEN_DEBUG_GEMM256_MAX_ROWS", chunk)
+        else:
+            monkeypatch.delenv("UMGEN_DEBUG_GEMM256_MAX_ROWS", raising=False)
+        out = x0.copy() if resid else np.zeros((R, N), dtype=np.uint16)
+        check(lib().umgen_dbg_linear(1 | flag, vp(a_in), vp(w_in), fp(bias), R, N, K, gelu, resid, vp(out)))
+        outs.append(out)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("R,N,K,gelu,resid", [(2207, 768, 768, 0, 1), (4500, 2304, 768, 0, 0), (3000, 3072, 768, 1, 0), (1031, 768, 3072, 0, 1),
                                                (8192, 3072, 16, 1, 0), (130, 1028, 768, 0, 0), (257, 768, 770, 0, 0), (300, 132, 37, 0, 0)])
 def test_fp32_mfma_gemm_is_the_fma_chain(R, N, K, gelu, resid):

@@ -162,6 +162,8 @@ int umgen_dbg_gemm_bench(int R, int N, int K, int mode, int iters, float* ms) {
     return 0;
 }
 
+int umgen_dbg_gemm_stamps(unsigned long long* out16) { return gemm256_read_stamps(out16); }
+
 // few-row linear: out[M][N] = LN(x[M][K]; ln_w) . W[N][K]^T + bias, optional GELU.  W dtype bf16/fp32, activations fp32.
 int umgen_dbg_gemv(int bf16, const float* x, const float* ln_w, const void* W, const float* bias, int M, int N, int K, int gelu, float* out) {
     const size_t es = bf16 ? 2 : 4;

@@ -172,8 +172,10 @@ struct umgen_engine {
     bool in_lanes = false;               // enqueueing a lane's steps (a profiled frame times them around the graph launches, not inside enqueue_step)
     int lane_count(int B) const {
         if (!use_batched(B) || !lane[0].s) return 1;
-        int n = lanes_env > 0 ? lanes_env : std::max(1, B / 8);    // 8 scenes per lane up to 32 scenes, 4 lanes beyond
-        if (lanes_env <= 0) n = std::min(n, 4);
+        // measured (profiles/r04_lanes_sweep.txt): lanes of 16 scenes (one full column block of the matrix-core instruction) are best --
+        // 32 scenes 2132 / 1829 / 2040 us per step on 1 / 2 / 4 lanes, 64 scenes 3284 / 2689 / 2532 on 1 / 2 / 4; the device runs four
+        // streams' kernels at a time (8 lanes: two rounds, 3784 / 4063 us)
+        int n = lanes_env > 0 ? lanes_env : std::min(4, std::max(1, B / 16));
         return std::max(1, std::min(std::min(n, kMaxLanes), B));
     }
     hipError_t launch_status = hipSuccess;   // first refused kernel launch of the frame (hipGetLastError behind the GEMM launches): fails the frame

@@ -17,6 +17,8 @@
 //     wave so that global memory sees whole 256-byte token-row pieces; no workgroup barrier inside the epilogue.
 // Accumulation order of every output element: k ascending in steps of 32 inside the MFMA, the same for every tile position, so
 // results do not depend on which other rows are in the launch (scenes stay batch-invariant).
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -39,6 +41,16 @@ struct Src { unsigned p[2][2], q[2][2]; };   // element offsets of this lane's 1
 #define UMGEN_GEMM256_STAGGER 1
 #endif
 constexpr bool STAGGER = UMGEN_GEMM256_STAGGER;
+// Measurement builds only (tools/build_variant.sh; the shipped library has neither): UMGEN_G256_EPI = 1 keeps the epilogue's LDS pass but
+// drops its global stores, 2 stores without the nontemporal hint, 3 drops the residual epilogue's reads; UMGEN_G256_STAMPS accumulates
+// wall-clock ticks (100 MHz) of one workgroup's k-loops / first k-tiles / epilogues, read back by umgen_dbg_gemm_stamps.
+#ifndef UMGEN_G256_EPI
+#define UMGEN_G256_EPI 0
+#endif
+constexpr int EPI = UMGEN_G256_EPI;
+#ifdef UMGEN_G256_STAMPS
+__device__ unsigned long long g256_stamps[16];
+#endif
 
 template <int MODE, typename TT>
 __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int nJ, int splitI) {
@@ -95,9 +107,16 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
     // group issues its fragment reads and its share of a refill, the other group's 16 MFMAs own the matrix pipe (MI355X playbook: the
     // wave role split is what lets LDS reads, LDS-DMA and MFMAs overlap inside one workgroup).  Both groups pass the same number
     // of barriers: this one here, its counterpart for the first group behind the last tile.
-    if (STAGGER && wi == 1) __builtin_amdgcn_s_barrier();
+    // The stagger is per OUTPUT TILE: the second group takes its extra barrier at the top of every tile, the first group its counterpart
+    // right behind the tile's last MFMA block -- so both groups enter the epilogue together.  (Staggered across tiles -- rounds 3 / 4a --
+    // the second group's last phase waited for the first group's whole epilogue and then ran its own while the first group stood at the
+    // next tile's first barrier: the two epilogues ran one behind the other, 2 x 2.9 us per tile in STORE mode, 2 x 6.5 with the GELU,
+    // 2 x 10.9 with the residual read-modify-write; profiles/r04_gemm_stamps_before.txt.)
 
     unsigned char* stage = lds + kRing + wave * kStage;
+#ifdef UMGEN_G256_STAMPS
+    unsigned long long st_main = 0, st_k0 = 0, st_epi = 0, st_n = 0, st_t0 = 0, st_t1 = 0;
+#endif
     while (true) {
         const int tn = t + nloc;
         const bool has_next = tn < count;
@@ -108,7 +127,14 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (STAGGER && wi == 1) __builtin_amdgcn_s_barrier();
+#ifdef UMGEN_G256_STAMPS
+        st_t0 = wall_clock64();
+#endif
         for (int kt = 0; kt < nkt; ++kt) {
+#ifdef UMGEN_G256_STAMPS
+            if (kt == 1) st_k0 += wall_clock64() - st_t0;
+#endif
             const int par = kt & 1;
             const unsigned char* sP = lds + (par * 4 + wi) * kSlot;                      // this wave's P half (128 features)
             const unsigned char* sQ = lds + (par * 4 + 2 + (wj >> 1)) * kSlot + (wj & 1) * 64 * 128;   // its 64 tokens inside a Q half
@@ -197,18 +223,23 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
         }
+        if (STAGGER && wi == 0) __builtin_amdgcn_s_barrier();
+#ifdef UMGEN_G256_STAMPS
+        st_t1 = wall_clock64();
+        st_main += st_t1 - st_t0;
+#endif
         // ---------------- epilogue of this wave's 128 features x 64 tokens (private LDS strip, no workgroup barrier) ----------------
         const int ti = i0 + t % ni, tj = j0 + t / ni;
         const int fbase = ti * TM + wi * 128;            // first feature of the wave
         const int tbase = tj * TM + wj * 64;             // first token of the wave
         // bias of this lane's 32 features (the fragment registers are free now); one wait for all eight loads
-        float bv[8][4];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            if (a.bias) load4(a.bias + fbase + m * 16 + 4 * g, bv[m]);
-            else { bv[m][0] = 0.f; bv[m][1] = 0.f; bv[m][2] = 0.f; bv[m][3] = 0.f; }
-        }
         if (MODE == GEMM_STORE) {
+            float bv[8][4];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (a.bias) load4(a.bias + fbase + m * 16 + 4 * g, bv[m]);
+                else { bv[m][0] = 0.f; bv[m][1] = 0.f; bv[m][2] = 0.f; bv[m][3] = 0.f; }
+            }
             TT* out = reinterpret_cast<TT*>(a.out);
             auto run = [&](auto gelu_tag) {
                 constexpr bool GELU = decltype(gelu_tag)::value;
@@ -232,9 +263,10 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
                         uint4 v = *reinterpret_cast<const uint4*>(stage + tl * 256 + pos * 8);
                         if (tl & 1) v = make_uint4(v.z, v.w, v.x, v.y);
                         const int token = tbase + n * 16 + tl;
-                        if (token < a.Nj) {
+                        if (token < a.Nj && (EPI != 1 || a.ldo < 0)) {
                             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                            __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(out + (long)token * a.ldo + fbase + 8 * q));
+                            if (EPI == 2) *reinterpret_cast<u32x4*>(out + (long)token * a.ldo + fbase + 8 * q) = u32x4{v.x, v.y, v.z, v.w};
+                            else __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(out + (long)token * a.ldo + fbase + 8 * q));
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next n overwrites it
@@ -243,36 +275,45 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
             if (a.gelu) run(std::true_type{}); else run(std::false_type{});
         } else {   // GEMM_RESID (x += acc + bias) / GEMM_STORE_F32: fp32 rows, 64 features per pass
             float* out = reinterpret_cast<float*>(a.out);
+            // bias of the 4 features this lane holds BEHIND the strip transposition (the same acc + bias, added there: 8 registers instead of 32)
+            float4 b4[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                b4[hf] = a.bias ? *reinterpret_cast<const float4*>(a.bias + fbase + hf * 64 + 4 * (lane & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // the read-modify-write's loads run TWO 16-token passes ahead of their use (the fragment registers are free now): the wave
+            // waits for a memory round trip twice per tile instead of four times
+            float4 xob[2][2][4];
+            auto load_xo = [&](int n, float4 (&dst)[2][4]) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int token = min(tbase + n * 16 + it * 4 + (lane >> 4), a.Nj - 1);
+                        dst[hf][it] = *reinterpret_cast<const float4*>(out + (long)token * a.ldo + fbase + hf * 64 + 4 * (lane & 15));
+                    }
+            };
+            if (MODE == GEMM_RESID && EPI != 3) { load_xo(0, xob[0]); load_xo(1, xob[1]); }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                // the read-modify-write's loads of both 64-feature passes go out first: one memory round trip per 16 tokens
-                float4 xo[2][4];
-                if (MODE == GEMM_RESID) {
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                        for (int it = 0; it < 4; ++it) {
-                            const int token = min(tbase + n * 16 + it * 4 + (lane >> 4), a.Nj - 1);
-                            xo[hf][it] = *reinterpret_cast<const float4*>(out + (long)token * a.ldo + fbase + hf * 64 + 4 * (lane & 15));
-                        }
-                }
+                float4 (&xo)[2][4] = xob[n & 1];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
                     for (int mm = 0; mm < 4; ++mm) {
                         const int m = hf * 4 + mm;
-                        const float4 o = make_float4(acc[m][n][0] + bv[m][0], acc[m][n][1] + bv[m][1], acc[m][n][2] + bv[m][2], acc[m][n][3] + bv[m][3]);
+                        const float4 o = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
                         *reinterpret_cast<float4*>(stage + frow * 256 + (((mm * 4 + g) ^ frow) << 4)) = o;   // 16-byte granule p of token t at p ^ t
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int tl = it * 4 + (lane >> 4), q = lane & 15;
-                        const float4 v = *reinterpret_cast<const float4*>(stage + tl * 256 + ((q ^ tl) << 4));
+                        float4 v = *reinterpret_cast<const float4*>(stage + tl * 256 + ((q ^ tl) << 4));
+                        v = make_float4(v.x + b4[hf].x, v.y + b4[hf].y, v.z + b4[hf].z, v.w + b4[hf].w);
                         const int token = tbase + n * 16 + tl;
-                        if (token < a.Nj) {
+                        if (token < a.Nj && (EPI != 1 || a.ldo < 0)) {
                             float* x = out + (long)token * a.ldo + fbase + hf * 64 + 4 * q;
-                            if (MODE == GEMM_RESID) {
+                            if (MODE == GEMM_RESID && EPI != 3) {
                                 const float4 c = xo[hf][it];
                                 *reinterpret_cast<float4*>(x) = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);   // x + (acc + bias), as every other residual epilogue
                             } else {
@@ -282,24 +323,49 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                if (MODE == GEMM_RESID && EPI != 3 && n + 2 < 4) load_xo(n + 2, xob[n & 1]);
             }
         }
+#ifdef UMGEN_G256_STAMPS
+        st_epi += wall_clock64() - st_t1;
+        st_n += 1;
+#endif
         if (!has_next) break;
         t = tn;
         cur = nxt;
     }
-    if (STAGGER && wi == 0) __builtin_amdgcn_s_barrier();
+#ifdef UMGEN_G256_STAMPS
+    if (blockIdx.x == 9 && lane == 0 && (wave == 0 || wave == 4)) {
+        atomicAdd(&g256_stamps[wi * 8 + 0], st_main);
+        atomicAdd(&g256_stamps[wi * 8 + 1], st_k0);
+        atomicAdd(&g256_stamps[wi * 8 + 2], st_epi);
+        atomicAdd(&g256_stamps[wi * 8 + 3], st_n);
+    }
+#endif
 }
 
 }  // namespace
 
 size_t gemm256_lds_bytes() { return (size_t)kLds256; }
 
+// measurement builds (UMGEN_G256_STAMPS): ticks of workgroup 9, wave 0 / wave 4: [k-loops, first k-tiles, epilogues, tiles] x 2; reset
+int gemm256_read_stamps(unsigned long long* out16) {
+#ifdef UMGEN_G256_STAMPS
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g256_stamps), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g256_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+#else
+    (void)out16;
+    return -2;
+#endif
+}
+
 // true when the 256-tile kernel can run this GEMM (otherwise the caller keeps the 128-tile kernels of gemm.hip)
 bool gemm256_supported(const GemmArgs& a) {
     if (a.batch != 1 || (a.mode != GEMM_STORE && a.mode != GEMM_RESID && a.mode != GEMM_STORE_F32)) return false;
     if (a.Mi % TM != 0 || a.K % (2 * HK) != 0 || a.K < 2 * HK) return false;
-    if ((long)a.Nj * a.ldq >= (1L << 32) / 2 || (long)a.Mi * a.ldp >= (1L << 32) / 2) return false;   // 32-bit element offsets
+    if ((long)a.Mi * a.ldp >= (1L << 31) || (long)TM * a.ldq >= (1L << 31)) return false;   // 32-bit element offsets (token rows: chunked by the launcher)
     return true;
 }
 
@@ -332,6 +398,22 @@ void launch_gemm256(hipStream_t s, const GemmArgs& a) {
     if (dev < 0 || dev >= 64) dev = 0;
     if (!g_ncu256[dev]) (void)gemm256_prepare();   // a caller that skipped the per-device prepare (debug hooks): do it here, for this device
     const int n_cu = g_ncu256[dev] ? g_ncu256[dev] : 256;
+    // The kernel addresses its operands with 32-bit element offsets: token rows beyond 2^31 / ldq elements (16 scenes' K = 3072
+    // activations, 64 scenes' K = 768 ones) go out as further launches on whole-tile row chunks -- every output element is computed
+    // exactly as in one launch (its accumulation order does not depend on the tile's position).
+    long max_rows = ((((1L << 31) - 1) / a.ldq) / TM) * TM;
+    if (const char* dbg = getenv("UMGEN_DEBUG_GEMM256_MAX_ROWS")) max_rows = std::max<long>(TM, std::min<long>(max_rows, (atol(dbg) / TM) * TM));   // test hook
+    if (a.Nj > max_rows) {
+        const size_t osz = a.mode == GEMM_STORE ? sizeof(TT) : sizeof(float);
+        for (long r0 = 0; r0 < a.Nj; r0 += max_rows) {
+            GemmArgs c = a;
+            c.Nj = (int)std::min<long>(max_rows, a.Nj - r0);
+            c.Q = reinterpret_cast<const TT*>(a.Q) + r0 * a.ldq;
+            c.out = reinterpret_cast<unsigned char*>(a.out) + (size_t)r0 * a.ldo * osz;
+            launch_gemm256<TT>(s, c);
+        }
+        return;
+    }
     const int nI = a.Mi / TM, nJ = (a.Nj + TM - 1) / TM;
     // feature split over the XCDs only when the weight matrix would not stay in one 4 MB L2 and the feature tiles divide evenly
     const int splitI = (nI % 2 == 0 && (size_t)a.Mi * a.K * 2 > (size_t)(3u << 20)) ? 2 : 1;

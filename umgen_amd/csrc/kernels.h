@@ -34,6 +34,7 @@ struct GemmArgs {
 // gemm256.hip: 256 x 256 x 64 deep-pipelined kernel (GEMM_STORE / RESID / STORE_F32, batch 1, Mi % 256 == 0, K % 128 == 0)
 bool gemm256_supported(const GemmArgs& a);
 hipError_t gemm256_prepare();                   // per device, behind hipSetDevice (dynamic-LDS attribute, CU count of that device)
+int gemm256_read_stamps(unsigned long long* out16);   // measurement builds only (-2 otherwise)
 template <typename TT> void launch_gemm256(hipStream_t s, const GemmArgs& a);
 template <typename TT> void launch_gemm_mfma(hipStream_t s, const GemmArgs& a);   // P, Q of the 16-bit type TT (bf16_t / f16_t), MFMA 16x16x32
 template <typename TP, typename TQ> void launch_gemm_valu(hipStream_t s, const GemmArgs& a);  // exact fp32 FMA chain
