@@ -88,6 +88,9 @@ gemm) python tools/gemm_bench.py ${GEMM_ARGS} > gpurun_out/${R}_gemm_bench.txt 2
 gemmexp)  # where a 256-tile's time goes (measurement builds of tools/build_variant.sh: stamps, epi1 = no global stores, epi2 = plain stores, epi3 = residual without its reads)
   UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_stamps.so python tools/gemm_stamps.py > gpurun_out/${R}_gemm_stamps.txt 2>&1; cat gpurun_out/${R}_gemm_stamps.txt
   for v in ${GEMM_VARIANTS:-epi1 epi2 epi3}; do [ -f umgen_amd/libumgen_hip_$v.so ] && { UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_$v.so python tools/gemm_bench.py ${GEMM_ARGS:-353120} > gpurun_out/${R}_gemm_bench_$v.txt 2>&1; echo "--- $v"; grep 256-tile gpurun_out/${R}_gemm_bench_$v.txt | cut -c1-90; }; done ;;
+gemmab)   # tools/gemm_bench.py with the shipped library and with measurement builds (GEMM_VARIANTS="fbalt desync2 ..."), same box
+  python tools/gemm_bench.py ${GEMM_ARGS} > gpurun_out/${R}_gemm_bench.txt 2>&1; echo "--- shipped"; grep 256-tile gpurun_out/${R}_gemm_bench.txt | cut -c1-90
+  for v in ${GEMM_VARIANTS}; do [ -f umgen_amd/libumgen_hip_$v.so ] && { UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_$v.so python tools/gemm_bench.py ${GEMM_ARGS} > gpurun_out/${R}_gemm_bench_$v.txt 2>&1; echo "--- $v"; grep 256-tile gpurun_out/${R}_gemm_bench_$v.txt | cut -c1-90; }; done ;;
 stamps) UMGEN_DEBUG_TIMING=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/${R}_engine_stamps.txt; grep "decode engine" gpurun_out/${R}_engine_stamps.txt | tail -3 ;;
 closed) python tools/closed_loop.py --frames 30 > gpurun_out/${R}_closed_loop.log 2>&1; tail -4 gpurun_out/${R}_closed_loop.log | cut -c1-600 ;;
 vq) python tools/vq_time.py > gpurun_out/${R}_vq_decode_time.json 2>gpurun_out/${R}_vq_decode_time.err; cat gpurun_out/${R}_vq_decode_time.json

@@ -35,7 +35,7 @@ constexpr int kLds256 = kRing + 8 * kStage;   // 160 KB: one workgroup per CU
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }   // byte offset in a slot
 
-struct Src { unsigned p[2][2], q[2][2]; };   // element offsets of this lane's 16-byte pieces: [half][segment group]
+struct Src { int ti, tj; };   // feature / token tile of an output tile (wave-uniform)
 
 #ifndef UMGEN_GEMM256_STAGGER
 #define UMGEN_GEMM256_STAGGER 1
@@ -48,6 +48,10 @@ constexpr bool STAGGER = UMGEN_GEMM256_STAGGER;
 #define UMGEN_G256_EPI 0
 #endif
 constexpr int EPI = UMGEN_G256_EPI;
+#ifndef UMGEN_G256_FBALT
+#define UMGEN_G256_FBALT 0
+#endif
+constexpr bool FBALT = UMGEN_G256_FBALT;
 #ifdef UMGEN_G256_STAMPS
 __device__ unsigned long long g256_stamps[16];
 #endif
@@ -72,35 +76,29 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
     const int count = ni * nj;
     int t = lb;
     if (t >= count) return;
-    auto make_src = [&](int tt) {
-        const int ti = i0 + tt % ni, tj = j0 + tt / ni;
-        Src s;
+    // a tile's operand rows are addressed from its (wave-uniform) tile indices at issue time: lane constants row0 / c8 + two integer
+    // multiply-adds per request instead of eight offset registers per tile in flight (the k-loop runs at the register limit)
+    const int row0 = wave * 8 + (lane >> 3);                       // row of this lane's 16-byte piece inside a 64-row segment group
+    const int c8 = ((lane & 7) ^ (row0 & 7)) * 8;                  // its XOR-swizzled k chunk (the same for row0 + 64: 64 % 8 == 0)
+    auto make_src = [&](int tt) { return Src{i0 + tt % ni, j0 + tt / ni}; };
+    auto issue = [&](int slot, bool isP, const Src& sr, int h, int k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-                const int row = (wave + 8 * sg) * 8 + (lane >> 3);
-                const int c = (lane & 7) ^ (row & 7);
-                s.p[h][sg] = (unsigned)((long)(ti * TM + h * 128 + row) * a.ldp + c * 8);
-                s.q[h][sg] = (unsigned)((long)min(tj * TM + h * 128 + row, a.Nj - 1) * a.ldq + c * 8);
-            }
-        return s;
-    };
-    auto issue = [&](int slot, const TT* base, const unsigned (&off)[2], int k0) {
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg)
-            __builtin_amdgcn_global_load_lds((const void*)(base + off[sg] + k0),
+        for (int sg = 0; sg < 2; ++sg) {
+            const int row = h * 128 + sg * 64 + row0;
+            const unsigned off = isP ? (unsigned)((sr.ti * TM + row) * a.ldp + c8) : (unsigned)(min(sr.tj * TM + row, a.Nj - 1) * a.ldq + c8);
+            __builtin_amdgcn_global_load_lds((const void*)((isP ? P : Q) + off + k0),
                                              (__attribute__((address_space(3))) void*)(lds + slot * kSlot + (wave + 8 * sg) * 1024), 16, 0, 0);
+        }
     };
     // ring slot of (k-tile parity, kind): kind 0 / 1 = P half 0 / 1, 2 / 3 = Q half 0 / 1
     Src cur = make_src(t);
     // prologue: k-tile 0 entirely, the Q halves of k-tile 1 (its P halves follow in phases 0 / 1 of k-tile 0)
-    issue(2, Q, cur.q[0], 0);
-    issue(3, Q, cur.q[1], 0);
-    issue(0, P, cur.p[0], 0);
-    issue(1, P, cur.p[1], 0);
-    issue(4 + 2, Q, cur.q[0], HK);
-    issue(4 + 3, Q, cur.q[1], HK);
+    issue(2, false, cur, 0, 0);
+    issue(3, false, cur, 1, 0);
+    issue(0, true, cur, 0, 0);
+    issue(1, true, cur, 1, 0);
+    issue(4 + 2, false, cur, 0, HK);
+    issue(4 + 3, false, cur, 1, HK);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // STAGGER: the waves of the second feature half (one per SIMD, like those of the first) run one barrier interval behind: while one
@@ -131,7 +129,13 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #ifdef UMGEN_G256_STAMPS
         st_t0 = wall_clock64();
 #endif
-        for (int kt = 0; kt < nkt; ++kt) {
+        // one k-tile = 4 phases; FX / FY: the registers of the token fragments of the first / second 32 tokens.  FBALT (build option, off:
+        // measured on the shapes of the stacks, profiles/r04_gemm_bench_fbalt.txt -- 4096^3 +3 %, the K = 768 shapes -3 .. +3 %, no net gain): the first-token
+        // fragments of k-tile kt + 1 are read in phase 3 of k-tile kt (into FY, free since phase 2) instead of its own phase 0, and the two
+        // register sets swap roles every k-tile: 8 / 4 / 8 / 4 fragment reads per phase instead of 12 / 4 / 8 / 0 (the wave group that
+        // reads shares the LDS with the LDS-DMA while the other group's 16 MFMAs run: 12 reads are 384 LDS clocks against 256 MFMA clocks).
+        // Their slot (Q of k-tile kt + 1) is retired one phase earlier for it, by a counted wait in phase 2.
+        auto ktile = [&](const int kt, vec8 (&FX)[2][2], vec8 (&FY)[2][2], auto preloaded_tag, auto preload_tag) {
 #ifdef UMGEN_G256_STAMPS
             if (kt == 1) st_k0 += wall_clock64() - st_t0;
 #endif
@@ -145,17 +149,23 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
             const Src& s2 = in2 ? cur : nxt;
             const int k1 = (in1 ? kt + 1 : kt + 1 - nkt) * HK, k2 = (in2 ? kt + 2 : kt + 2 - nkt) * HK;
             const int par1 = par ^ 1;
-            vec8 fa[4][2], fb0[2][2], fb1[2][2];
+            // (k-tile 0 of an output tile neither finds its fragments preloaded nor preloads: its phase-2 wait would sit right behind the
+            //  previous tile's stores, which vmcnt counts too)
+            constexpr bool preloaded = FBALT && decltype(preloaded_tag)::value;
+            const bool preload = FBALT && decltype(preload_tag)::value && in1;
+            vec8 fa[4][2];
             // ---------------- phase 0: quadrant (features 0..63, tokens 0..31) ----------------
+            if (!preloaded) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) fb0[n][kk] = *reinterpret_cast<const vec8*>(sQ + swz(n * 16 + frow, kk * 4 + g));
+                    for (int kk = 0; kk < 2; ++kk) FX[n][kk] = *reinterpret_cast<const vec8*>(sQ + swz(n * 16 + frow, kk * 4 + g));
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *reinterpret_cast<const vec8*>(sP + swz(m * 16 + frow, kk * 4 + g));
-            if (do1) issue(par1 * 4 + 0, P, s1.p[0], k1);
+            if (do1) issue(par1 * 4 + 0, true, s1, 0, k1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired BEFORE the barrier: the other wave group's next refill may target this slot
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -165,15 +175,15 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = Mma16<TT>::mfma(fa[m][kk], fb0[n][kk], acc[m][n]);
+                    for (int n = 0; n < 2; ++n) acc[m][n] = Mma16<TT>::mfma(fa[m][kk], FX[n][kk], acc[m][n]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---------------- phase 1: quadrant (features 0..63, tokens 32..63) ----------------
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) fb1[n][kk] = *reinterpret_cast<const vec8*>(sQ + swz((2 + n) * 16 + frow, kk * 4 + g));
-            if (do1) issue(par1 * 4 + 1, P, s1.p[1], k1);
+                for (int kk = 0; kk < 2; ++kk) FY[n][kk] = *reinterpret_cast<const vec8*>(sQ + swz((2 + n) * 16 + frow, kk * 4 + g));
+            if (do1) issue(par1 * 4 + 1, true, s1, 1, k1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired BEFORE the barrier: the other wave group's next refill may target this slot
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][2 + n] = Mma16<TT>::mfma(fa[m][kk], fb1[n][kk], acc[m][2 + n]);
+                    for (int n = 0; n < 2; ++n) acc[m][2 + n] = Mma16<TT>::mfma(fa[m][kk], FY[n][kk], acc[m][2 + n]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---------------- phase 2: quadrant (features 64..127, tokens 32..63) ----------------
@@ -191,7 +201,11 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *reinterpret_cast<const vec8*>(sP + swz((4 + m) * 16 + frow, kk * 4 + g));
-            if (do2) issue(par * 4 + 2, Q, s2.q[0], k2);       // (the Q slots of this k-tile: their last reads were phase 1's)
+            if (do2) issue(par * 4 + 2, false, s2, 0, k2);       // (the Q slots of this k-tile: their last reads were phase 1's)
+            if (preload) {     // the Q halves of k-tile kt + 1 (requested a k-tile ago) have landed: everything but this k-tile's 4 + 2 requests
+                if (do2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired BEFORE the barrier: the other wave group's next refill may target this slot
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -201,16 +215,24 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[4 + m][2 + n] = Mma16<TT>::mfma(fa[m][kk], fb1[n][kk], acc[4 + m][2 + n]);
+                    for (int n = 0; n < 2; ++n) acc[4 + m][2 + n] = Mma16<TT>::mfma(fa[m][kk], FY[n][kk], acc[4 + m][2 + n]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---------------- phase 3: quadrant (features 64..127, tokens 0..31); the k-tile's one counted wait ----------------
+            if (preload) {     // first-token fragments of k-tile kt + 1 into the registers phase 2 was the last to use
+                const unsigned char* sQn = lds + (par1 * 4 + 2 + (wj >> 1)) * kSlot + (wj & 1) * 64 * 128;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) FY[n][kk] = *reinterpret_cast<const vec8*>(sQn + swz(n * 16 + frow, kk * 4 + g));
+            }
             if (do2) {
-                issue(par * 4 + 3, Q, s2.q[1], k2);
+                issue(par * 4 + 3, false, s2, 1, k2);
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all of k-tile kt + 1 has landed (only this k-tile's two Q refills may be in flight)
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if (FBALT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
@@ -219,9 +241,16 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[4 + m][n] = Mma16<TT>::mfma(fa[m][kk], fb0[n][kk], acc[4 + m][n]);
+                    for (int n = 0; n < 2; ++n) acc[4 + m][n] = Mma16<TT>::mfma(fa[m][kk], FX[n][kk], acc[4 + m][n]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
+        };
+        vec8 fbA[2][2], fbB[2][2];
+        ktile(0, fbA, fbB, std::false_type{}, std::false_type{});      // (nkt is even and >= 2: the launcher)
+        ktile(1, fbB, fbA, std::false_type{}, std::true_type{});
+        for (int kt = 2; kt < nkt; kt += 2) {
+            ktile(kt, fbA, fbB, std::true_type{}, std::true_type{});
+            ktile(kt + 1, fbB, fbA, std::true_type{}, std::true_type{});
         }
         if (STAGGER && wi == 0) __builtin_amdgcn_s_barrier();
 #ifdef UMGEN_G256_STAMPS
