@@ -77,6 +77,35 @@ def test_linear_256_tile_kernel(prec, R, N, K, gelu, resid):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("F,S,N,K,chunk", [(3, 2207, 768, 768, None), (2, 300, 768, 128, None), (5, 256, 256, 256, None), (1, 2207, 768, 768, None),
+                                            (4, 1031, 768, 768, "2100"), (2, 7, 256, 128, None)])
+@pytest.mark.parametrize("prec", [1, 2])
+def test_linear_256_tile_kernel_v_transposed(monkeypatch, prec, F, S, N, K, chunk):
+    """The spatial attention's V^T ([frame][feature][padded tokens], GEMM_VT) on the 256-tile kernel: token tiles per frame, the frame's
+    ragged last tile, pad columns written as zeros, frames as launch chunks (hook) -- bit-identical to the 128-tile kernel's rows, and
+    equal to the fp64 product within the 16-bit rounding."""
+    rng = np.random.default_rng(F + S + N + K)
+    act = rng.standard_normal((F * S, K), dtype=np.float32)
+    W = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal((N,), dtype=np.float32) * 0.1
+    a_in, w_in = bits16(act, prec), bits16(W, prec)
+    S_pad = (S + 63) // 64 * 64
+    outs = []
+    for flag in (16, 32):
+        if chunk and flag == 16:
+            monkeypatch.setenv("UMGEN_DEBUG_GEMM256_MAX_ROWS", chunk)
+        else:
+            monkeypatch.delenv("UMGEN_DEBUG_GEMM256_MAX_ROWS", raising=False)
+        out = np.full((F, N, S_pad), 0x7fc0 if prec == 1 else 0x7e00, dtype=np.uint16)       # (the hook clears it: pad columns must come back zero)
+        check(lib().umgen_dbg_linear_vt(prec | flag, vp(a_in), vp(w_in), fp(bias), F, S, N, K, vp(out)))
+        outs.append(out)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert not outs[0][:, :, S:].any()
+    ref = (round16(act, prec).astype(np.float64) @ round16(W, prec).astype(np.float64).T + bias).reshape(F, S, N).transpose(0, 2, 1)
+    got = from_bits16(outs[0], prec)[:, :, :S]
+    np.testing.assert_allclose(got, ref, atol=1.2e-2 * EPS16[prec] * max(1.0, np.abs(ref).max()) + 2e-5, rtol=0)
+
+
 @pytest.mark.parametrize("R,N,K,gelu,resid", [(9000, 768, 3072, 0, 1), (5000, 3072, 768, 1, 0), (2049, 768, 768, 0, 0)])
 def test_linear_256_tile_kernel_row_chunks(monkeypatch, R, N, K, gelu, resid):
     """The 256-tile kernel addresses its operands with 32-bit element offsets; more token rows than 2^31 / ld elements (16 scenes' K = 3072

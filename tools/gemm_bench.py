@@ -15,6 +15,12 @@ for R in rows:
             rc = lib.umgen_dbg_gemm_bench(R, N, K, mode | bit, 10, C.byref(ms))
             line += f"  {tag} {ms.value*1e3:8.1f} us {2.0*R*N*K/ms.value/1e9:7.1f} TFLOP/s" if rc == 0 else f"  {tag} rc={rc}"
         print(line, flush=True)
+for F in (20, 160):      # the spatial attention's V transposed per frame (GEMM_VT): one / eight scenes' frames of 2207 tokens
+    line = f"v transposed   F={F:3d} S=2207 N= 768 K= 768:"
+    for tag, bit in (("256-tile", 32), ("128-tile", 64)):
+        rc = lib.umgen_dbg_gemm_vt_bench(F, 2207, 768, 768, bit, 10, C.byref(ms))
+        line += f"  {tag} {ms.value*1e3:8.1f} us {2.0*F*2207*768*768/ms.value/1e9:7.1f} TFLOP/s" if rc == 0 else f"  {tag} rc={rc}"
+    print(line, flush=True)
 for tag, bit in (("256-tile", 32), ("128-tile", 64)):
     rc = lib.umgen_dbg_gemm_bench(4096, 4096, 4096, bit, 20, C.byref(ms))
     print(f"square 4096^3 store {tag}: rc={rc} {ms.value*1e3:8.1f} us  {2.0*4096**3/ms.value/1e9:7.1f} TFLOP/s", flush=True)

@@ -43,6 +43,27 @@ int umgen_dbg_linear(int flags, const void* act, const void* W, const float* bia
     return down(out, dO.p, osz);
 }
 
+// V^T GEMM of the spatial attention (GEMM_VT): act [F*S][K] rows, W [N][K], bias [N] -> out [F][N][S_pad] of the operand type
+// (S_pad = S rounded up to 64; pad columns are zero).  flag 16: force the 256 x 256 kernel, 32: the 128-tile kernels only.
+int umgen_dbg_linear_vt(int flags, const void* act, const void* W, const float* bias, int F, int S, int N, int K, void* out) {
+    const int prec = flags & 3;
+    if (prec != 1 && prec != 2) return UMGEN_E_UNSUPPORTED;
+    const int S_pad = ((S + 63) / 64) * 64;
+    const size_t R = (size_t)F * S, osz = (size_t)F * N * S_pad * 2;
+    DevBuf dA(R * K * 2), dW((size_t)N * K * 2), dB((size_t)N * 4), dO(osz);
+    if (!dA.p || !dW.p || !dB.p || !dO.p) return UMGEN_E_NOMEM;
+    if (up(dA.p, act, R * K * 2) || up(dW.p, W, (size_t)N * K * 2)) return UMGEN_E_HIP;
+    if (bias && up(dB.p, bias, (size_t)N * 4)) return UMGEN_E_HIP;
+    (void)hipMemset(dO.p, 0, osz);
+    GemmArgs g{};
+    g.P = dA.p; g.Q = dW.p; g.Mi = S; g.Nj = N; g.K = K; g.ldp = K; g.ldq = K; g.strideP = (long)S * K; g.strideQ = 0; g.batch = F;
+    g.mode = GEMM_VT; g.bias = bias ? (const float*)dB.p : nullptr; g.out = dO.p; g.ldo = S_pad; g.H = N / kHeadDim;
+    g.tile256 = (flags & 16) ? 1 : ((flags & 32) ? -1 : 0);
+    if (prec == 2) launch_gemm_mfma<f16_t>(nullptr, g); else launch_gemm_mfma<bf16_t>(nullptr, g);
+    if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
+    return down(out, dO.p, osz);
+}
+
 // spatial attention on q|k rows [F*S][2E] and v rows [F*S][E] (both row-major on the host; V is transposed on the device
 // through the same GEMM_VT-layout the engine uses).  y [F*S][E].
 int umgen_dbg_attn_spatial(int flags, const void* qk, const void* v, int F, int S, int H, void* y) {
@@ -148,6 +169,38 @@ int umgen_dbg_gemm_bench(int R, int N, int K, int mode, int iters, float* ms) {
     g.P = dW.p; g.Q = dA.p; g.Mi = N; g.Nj = R; g.K = K; g.ldp = K; g.ldq = K; g.batch = 1;
     g.mode = mode & 15; g.gelu = (mode >> 4) & 1; g.out = dO.p; g.ldo = N;   // mode bit 4: erf-GELU epilogue
     g.tile256 = (mode & 64) ? -1 : ((mode & 32) ? 1 : 0);                     // bit 5: force the 256 x 256 kernel, bit 6: 128 x 128 kernels only
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    launch_gemm_mfma<bf16_t>(nullptr, g);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) launch_gemm_mfma<bf16_t>(nullptr, g);
+    (void)hipEventRecord(e1, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) return UMGEN_E_HIP;
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms = t / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// timing of the V^T GEMM (GEMM_VT) of F frames x S tokens; flag 32: force the 256-tile kernel, 64: the 128-tile kernels only
+int umgen_dbg_gemm_vt_bench(int F, int S, int N, int K, int flag, int iters, float* ms) {
+    const int S_pad = ((S + 63) / 64) * 64;
+    const size_t R = (size_t)F * S;
+    DevBuf dA(R * K * 2), dW((size_t)N * K * 2), dO((size_t)F * N * S_pad * 2);
+    if (!dA.p || !dW.p || !dO.p) return UMGEN_E_NOMEM;
+    std::vector<bf16_t> h(R * K);
+    unsigned x = 12345u;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = f32_to_bf16(((x >> 8) & 0xffff) / 32768.0f - 1.0f); }
+    if (up(dA.p, h.data(), h.size() * 2)) return UMGEN_E_HIP;
+    h.resize((size_t)N * K);
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = f32_to_bf16((((x >> 8) & 0xffff) / 32768.0f - 1.0f) * 0.05f); }
+    if (up(dW.p, h.data(), h.size() * 2)) return UMGEN_E_HIP;
+    (void)hipMemset(dO.p, 0, (size_t)F * N * S_pad * 2);
+    GemmArgs g{};
+    g.P = dA.p; g.Q = dW.p; g.Mi = S; g.Nj = N; g.K = K; g.ldp = K; g.ldq = K; g.strideP = (long)S * K; g.strideQ = 0; g.batch = F;
+    g.mode = GEMM_VT; g.out = dO.p; g.ldo = S_pad; g.H = N / kHeadDim;
+    g.tile256 = (flag & 64) ? -1 : ((flag & 32) ? 1 : 0);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     launch_gemm_mfma<bf16_t>(nullptr, g);

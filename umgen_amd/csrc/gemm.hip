@@ -465,6 +465,19 @@ void launch_gemm_mfma(hipStream_t s, const GemmArgs& a) {
         launch_gemm256<TT>(s, a);
         return;
     }
+    if (a.mode == GEMM_VT && a.tile256 >= 0) {
+        // V transposed: the 256-tile kernel takes it with the operand roles the other way round (its P rows are the weight rows, its Q
+        // rows the tokens -- the lanes of one accumulator register then hold 16 consecutive tokens of a feature, what a V^T row wants);
+        // token tiles per frame, frames as the batch.  Products and k order are those of this file's kernels: bit-identical rows.
+        GemmArgs v = a;
+        v.P = a.Q; v.Mi = a.Nj; v.ldp = a.ldq; v.strideP = a.strideQ;
+        v.Q = a.P; v.Nj = a.Mi; v.ldq = a.ldp; v.strideQ = a.strideP;
+        const long tiles = (long)(v.Mi / 256) * ((v.Nj + 255) / 256) * v.batch;
+        if (gemm256_supported(v) && (a.tile256 > 0 || tiles >= min_tiles256)) {
+            launch_gemm256<TT>(s, v);
+            return;
+        }
+    }
     const int nI = (a.Mi + BM - 1) / BM, nJ = (a.Nj + BN - 1) / BN;
     dim3 grid(((nJ + 7) / 8) * 8 * nI, 1, a.batch), block(256);
 #ifndef UMGEN_NO_PERSISTENT_GEMM

@@ -35,7 +35,7 @@ constexpr int kLds256 = kRing + 8 * kStage;   // 160 KB: one workgroup per CU
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }   // byte offset in a slot
 
-struct Src { int ti, tj; };   // feature / token tile of an output tile (wave-uniform)
+struct Src { int ti, trow0, tmax; };   // an output tile's feature tile, first token row and last addressable token row (wave-uniform)
 
 #ifndef UMGEN_GEMM256_STAGGER
 #define UMGEN_GEMM256_STAGGER 1
@@ -57,7 +57,7 @@ __device__ unsigned long long g256_stamps[16];
 #endif
 
 template <int MODE, typename TT>
-__global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int nJ, int splitI) {
+__global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int nJ, int splitI, int tpf) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     typedef typename Mma16<TT>::vec vec8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,12 +80,21 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
     // multiply-adds per request instead of eight offset registers per tile in flight (the k-loop runs at the register limit)
     const int row0 = wave * 8 + (lane >> 3);                       // row of this lane's 16-byte piece inside a 64-row segment group
     const int c8 = ((lane & 7) ^ (row0 & 7)) * 8;                  // its XOR-swizzled k chunk (the same for row0 + 64: 64 % 8 == 0)
-    auto make_src = [&](int tt) { return Src{i0 + tt % ni, j0 + tt / ni}; };
+    // GEMM_VT (V transposed per frame for the spatial attention, [frame][feature][S_pad tokens]): the token tiles are per FRAME -- tpf
+    // tiles of 256 for the frame's a.Nj tokens, frame z = tj / tpf -- so that a tile's tokens are contiguous in the output
+    auto make_src = [&](int tt) {
+        const int ti = i0 + tt % ni, tj = j0 + tt / ni;
+        if (MODE == GEMM_VT) {
+            const int z = tj / tpf, tl = tj - z * tpf;
+            return Src{ti, z * a.Nj + tl * TM, z * a.Nj + a.Nj - 1};
+        }
+        return Src{ti, tj * TM, a.Nj - 1};
+    };
     auto issue = [&](int slot, bool isP, const Src& sr, int h, int k0) {
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
             const int row = h * 128 + sg * 64 + row0;
-            const unsigned off = isP ? (unsigned)((sr.ti * TM + row) * a.ldp + c8) : (unsigned)(min(sr.tj * TM + row, a.Nj - 1) * a.ldq + c8);
+            const unsigned off = isP ? (unsigned)((sr.ti * TM + row) * a.ldp + c8) : (unsigned)(min(sr.trow0 + row, sr.tmax) * a.ldq + c8);
             __builtin_amdgcn_global_load_lds((const void*)((isP ? P : Q) + off + k0),
                                              (__attribute__((address_space(3))) void*)(lds + slot * kSlot + (wave + 8 * sg) * 1024), 16, 0, 0);
         }
@@ -302,6 +311,48 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
                 }
             };
             if (a.gelu) run(std::true_type{}); else run(std::false_type{});
+        } else if (MODE == GEMM_VT) {
+            // V transposed: out[(z * Mi + feature) * ldo + token] -- the lanes of one accumulator register hold 16 consecutive tokens of
+            // one feature already; 16 features x 64 tokens go through the strip (row pitch 144 B: the four feature groups of a request
+            // fall into different banks) and leave as 16-byte pieces of 8 tokens.  Tokens behind the frame's last one are written as
+            // zeros (the pad columns of a V^T row must be zero for the P.V product), pieces behind the padded row are skipped.
+            TT* out = reinterpret_cast<TT*>(a.out);
+            const int z = tj / tpf, tl = tj - z * tpf;
+            const int tok0 = tl * TM + wj * 64;
+            constexpr int PITCH = 144;
+            float bv[8][4];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (a.bias) load4(a.bias + fbase + m * 16 + 4 * g, bv[m]);
+                else { bv[m][0] = 0.f; bv[m][1] = 0.f; bv[m][2] = 0.f; bv[m][3] = 0.f; }
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<TT*>(stage + (4 * g + r) * PITCH + (n * 16 + frow) * 2) = Cvt<TT>::from_f(acc[m][n][r] + bv[m][r]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int piece = it * 64 + lane, f = piece >> 3, pc = piece & 7;
+                    uint4 v = *reinterpret_cast<const uint4*>(stage + f * PITCH + pc * 16);
+                    const int tk = tok0 + pc * 8, valid = a.Nj - tk;      // tokens of this piece inside the frame
+                    if (valid < 8) {
+                        v.x &= (valid > 0 ? 0xffffu : 0u) | (valid > 1 ? 0xffff0000u : 0u);
+                        v.y &= (valid > 2 ? 0xffffu : 0u) | (valid > 3 ? 0xffff0000u : 0u);
+                        v.z &= (valid > 4 ? 0xffffu : 0u) | (valid > 5 ? 0xffff0000u : 0u);
+                        v.w &= (valid > 6 ? 0xffffu : 0u) | (valid > 7 ? 0xffff0000u : 0u);
+                    }
+                    if (tk < a.ldo) {
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w},
+                                                    reinterpret_cast<u32x4*>(out + ((long)z * a.Mi + fbase + m * 16 + f) * a.ldo + tk));
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next m overwrites it
+            }
         } else {   // GEMM_RESID (x += acc + bias) / GEMM_STORE_F32: fp32 rows, 64 features per pass
             float* out = reinterpret_cast<float*>(a.out);
             // bias of the 4 features this lane holds BEHIND the strip transposition (the same acc + bias, added there: 8 registers instead of 32)
@@ -392,7 +443,11 @@ int gemm256_read_stamps(unsigned long long* out16) {
 
 // true when the 256-tile kernel can run this GEMM (otherwise the caller keeps the 128-tile kernels of gemm.hip)
 bool gemm256_supported(const GemmArgs& a) {
-    if (a.batch != 1 || (a.mode != GEMM_STORE && a.mode != GEMM_RESID && a.mode != GEMM_STORE_F32)) return false;
+    // (GEMM_VT arrives here in THIS kernel's operand roles -- P = the weight rows, Q = the frames' token rows, Nj tokens per frame,
+    //  batch = frames, strideQ = Nj * ldq, ldo = the padded row length -- see launch_gemm_mfma)
+    if (a.mode == GEMM_VT) {
+        if (a.batch < 1 || a.strideQ != (long)a.Nj * a.ldq || a.strideP != 0 || a.ldo % 8 != 0 || a.ldo < a.Nj) return false;
+    } else if (a.batch != 1 || (a.mode != GEMM_STORE && a.mode != GEMM_RESID && a.mode != GEMM_STORE_F32)) return false;
     if (a.Mi % TM != 0 || a.K % (2 * HK) != 0 || a.K < 2 * HK) return false;
     if ((long)a.Mi * a.ldp >= (1L << 31) || (long)TM * a.ldq >= (1L << 31)) return false;   // 32-bit element offsets (token rows: chunked by the launcher)
     return true;
@@ -412,7 +467,8 @@ hipError_t gemm256_prepare() {
     const void* fns[] = {
         reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE, bf16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_RESID, bf16_t>),
         reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE_F32, bf16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE, f16_t>),
-        reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_RESID, f16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE_F32, f16_t>)};
+        reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_RESID, f16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_STORE_F32, f16_t>),
+        reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_VT, bf16_t>), reinterpret_cast<const void*>(gemm16_256_kernel<GEMM_VT, f16_t>)};
     for (const void* f : fns) {
         hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLds256);
         if (rc != hipSuccess) return rc;
@@ -430,6 +486,20 @@ void launch_gemm256(hipStream_t s, const GemmArgs& a) {
     // The kernel addresses its operands with 32-bit element offsets: token rows beyond 2^31 / ldq elements (16 scenes' K = 3072
     // activations, 64 scenes' K = 768 ones) go out as further launches on whole-tile row chunks -- every output element is computed
     // exactly as in one launch (its accumulation order does not depend on the tile's position).
+    if (a.mode == GEMM_VT) {      // frames as the chunk unit: (frames x tokens per frame) x ldq elements stay below 2^31
+        const int tpf = (a.Nj + TM - 1) / TM;
+        int max_frames = (int)std::max<long>(1, ((1L << 31) - 1) / ((long)a.Nj * a.ldq));
+        if (const char* dbg = getenv("UMGEN_DEBUG_GEMM256_MAX_ROWS")) max_frames = std::max(1, std::min(max_frames, (int)(atol(dbg) / a.Nj)));   // test hook
+        for (int z0 = 0; z0 < a.batch; z0 += max_frames) {
+            GemmArgs c = a;
+            c.batch = std::min(max_frames, a.batch - z0);
+            c.Q = reinterpret_cast<const TT*>(a.Q) + (long)z0 * a.strideQ;
+            c.out = reinterpret_cast<TT*>(a.out) + (long)z0 * a.Mi * a.ldo;
+            const int nI = c.Mi / TM, nJ = c.batch * tpf;
+            hipLaunchKernelGGL((gemm16_256_kernel<GEMM_VT, TT>), dim3(n_cu), dim3(512), kLds256, s, c, nI, nJ, 1, tpf);
+        }
+        return;
+    }
     long max_rows = ((((1L << 31) - 1) / a.ldq) / TM) * TM;
     if (const char* dbg = getenv("UMGEN_DEBUG_GEMM256_MAX_ROWS")) max_rows = std::max<long>(TM, std::min<long>(max_rows, (atol(dbg) / TM) * TM));   // test hook
     if (a.Nj > max_rows) {
@@ -448,9 +518,9 @@ void launch_gemm256(hipStream_t s, const GemmArgs& a) {
     const int splitI = (nI % 2 == 0 && (size_t)a.Mi * a.K * 2 > (size_t)(3u << 20)) ? 2 : 1;
     const dim3 grid(n_cu), block(512);
     switch (a.mode) {
-        case GEMM_STORE: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE, TT>), grid, block, kLds256, s, a, nI, nJ, splitI); break;
-        case GEMM_RESID: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_RESID, TT>), grid, block, kLds256, s, a, nI, nJ, splitI); break;
-        default: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE_F32, TT>), grid, block, kLds256, s, a, nI, nJ, splitI); break;
+        case GEMM_STORE: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE, TT>), grid, block, kLds256, s, a, nI, nJ, splitI, 0); break;
+        case GEMM_RESID: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_RESID, TT>), grid, block, kLds256, s, a, nI, nJ, splitI, 0); break;
+        default: hipLaunchKernelGGL((gemm16_256_kernel<GEMM_STORE_F32, TT>), grid, block, kLds256, s, a, nI, nJ, splitI, 0); break;
     }
 }
 template void launch_gemm256<bf16_t>(hipStream_t, const GemmArgs&);
