@@ -462,20 +462,6 @@ void launch_gemm_mfma(hipStream_t s, const GemmArgs& a) {
     static const int min_tiles256 = getenv("UMGEN_GEMM256_MIN_TILES") ? atoi(getenv("UMGEN_GEMM256_MIN_TILES")) : 300;
     const long tiles256 = (long)(a.Mi / 256) * ((a.Nj + 255) / 256);
     if (a.tile256 >= 0 && gemm256_supported(a) && (a.tile256 > 0 || tiles256 >= min_tiles256 || (a.K >= 2048 && tiles256 >= min_tiles256 / 3))) {
-        // whole rounds of the persistent grid on the 256-tile kernel, the few token rows left over on the 128-tile kernels (gemm256.hip)
-        const long nJ = (a.Nj + 255) / 256, u = gemm256_whole_round_units(a);
-        if (u < nJ) {
-            const size_t osz = a.mode == GEMM_STORE ? sizeof(TT) : sizeof(float);
-            GemmArgs head = a, tail = a;
-            head.Nj = (int)(u * 256);
-            tail.Nj = a.Nj - head.Nj;
-            tail.Q = reinterpret_cast<const TT*>(a.Q) + (long)head.Nj * a.ldq;
-            tail.out = reinterpret_cast<unsigned char*>(a.out) + (size_t)head.Nj * a.ldo * osz;
-            tail.tile256 = -1;
-            launch_gemm256<TT>(s, head);
-            launch_gemm_mfma<TT>(s, tail);
-            return;
-        }
         launch_gemm256<TT>(s, a);
         return;
     }
@@ -488,18 +474,6 @@ void launch_gemm_mfma(hipStream_t s, const GemmArgs& a) {
         v.Q = a.P; v.Nj = a.Mi; v.ldq = a.ldp; v.strideQ = a.strideP;
         const long tiles = (long)(v.Mi / 256) * ((v.Nj + 255) / 256) * v.batch;
         if (gemm256_supported(v) && (a.tile256 > 0 || tiles >= min_tiles256)) {
-            const long u = gemm256_whole_round_units(v);       // frames that fill whole rounds; the other frames stay on the 128-tile kernel
-            if (u < a.batch) {
-                GemmArgs tail = a;
-                tail.batch = a.batch - (int)u;
-                tail.P = reinterpret_cast<const TT*>(a.P) + u * a.strideP;
-                tail.out = reinterpret_cast<TT*>(a.out) + u * (long)a.Nj * a.ldo;
-                tail.tile256 = -1;
-                v.batch = (int)u;
-                launch_gemm256<TT>(s, v);
-                launch_gemm_mfma<TT>(s, tail);
-                return;
-            }
             launch_gemm256<TT>(s, v);
             return;
         }

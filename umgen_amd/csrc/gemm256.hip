@@ -441,9 +441,6 @@ int gemm256_read_stamps(unsigned long long* out16) {
 #endif
 }
 
-static int g_ncu256[64] = {};
-static int g_ncu256_dev(int dev) { return g_ncu256[dev]; }
-
 // true when the 256-tile kernel can run this GEMM (otherwise the caller keeps the 128-tile kernels of gemm.hip)
 bool gemm256_supported(const GemmArgs& a) {
     // (GEMM_VT arrives here in THIS kernel's operand roles -- P = the weight rows, Q = the frames' token rows, Nj tokens per frame,
@@ -456,39 +453,9 @@ bool gemm256_supported(const GemmArgs& a) {
     return true;
 }
 
-// Whole rounds.  A launch's tiles are dealt to the XCDs (launch_gemm256: splitI feature groups x 8 / splitI token groups, qJ token tiles
-// each) and walked by the XCD's n_cu / 8 persistent workgroups: ceil(qJ x hI / 32) rounds of equal tiles, the last one often nearly
-// empty -- one scene's K = 768 projection is 3 x 173 tiles = 66 per XCD = 2.06 rounds, i.e. THREE (the q | k launch 4.1 -> 5, fc 8.25 -> 9).
-// Returns how many of the launch's token units (256-row token tiles; frames for GEMM_VT) fill one round less, when the rest is small
-// enough for the 128-tile kernels to take it in about one of THEIR rounds (<= 2 x n_cu tiles of 128 x 128) -- else all units.  The caller
-// (launch_gemm_mfma) sends the first units here and the rest to the 128-tile kernels: identical outputs (the kernels agree bit for bit),
-// one scene's GEMMs 8-33 % shorter.
-long gemm256_whole_round_units(const GemmArgs& a) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const int n_cu = (dev >= 0 && dev < 64 && g_ncu256_dev(dev)) ? g_ncu256_dev(dev) : 256;
-    const int nloc = n_cu / 8;
-    const bool vt = a.mode == GEMM_VT;
-    const int tpf = vt ? (a.Nj + TM - 1) / TM : 1;                       // token tiles per unit
-    const long units = vt ? a.batch : (a.Nj + TM - 1) / TM;
-    static const bool enabled = !(getenv("UMGEN_GEMM256_SPLIT") && getenv("UMGEN_GEMM256_SPLIT")[0] == '0');
-    if (!enabled) return units;
-    const int nI = a.Mi / TM;
-    const int splitI = (!vt && nI % 2 == 0 && (size_t)a.Mi * a.K * 2 > (size_t)(3u << 20)) ? 2 : 1;
-    const int gJ = 8 / splitI, hI = (nI + splitI - 1) / splitI;
-    auto rounds_of = [&](long u) { const long qJ = (u * tpf + gJ - 1) / gJ; return (qJ * hI + nloc - 1) / nloc; };
-    const long now = rounds_of(units);
-    if (now < 2) return units;
-    long u2 = ((now - 1) * nloc / hI) * gJ / tpf;                         // largest unit count whose XCD shares fit now - 1 rounds
-    while (u2 > 0 && rounds_of(u2) > now - 1) --u2;
-    if (u2 <= 0 || u2 >= units) return units;
-    const long rem_rows = vt ? (units - u2) * (long)a.Nj : (long)a.Nj - u2 * TM;
-    const long tiles128 = vt ? (units - u2) * ((a.Nj + 127) / 128) * (a.Mi / 128) : ((rem_rows + 127) / 128) * (a.Mi / 128);
-    return tiles128 <= 2L * n_cu ? u2 : units;
-}
-
 // Per DEVICE, before the first launch there (umgen_create / umgen_vq_create call it behind hipSetDevice): the 160 KB dynamic-LDS
 // attribute applies to the current device only, and the persistent grid is one workgroup per CU of THAT device.
+static int g_ncu256[64] = {};
 hipError_t gemm256_prepare() {
     int dev = 0;
     hipDeviceProp_t prop;

@@ -34,7 +34,6 @@ struct GemmArgs {
 // gemm256.hip: 256 x 256 x 64 deep-pipelined kernel (GEMM_STORE / RESID / STORE_F32, batch 1, Mi % 256 == 0, K % 128 == 0)
 bool gemm256_supported(const GemmArgs& a);
 hipError_t gemm256_prepare();                   // per device, behind hipSetDevice (dynamic-LDS attribute, CU count of that device)
-long gemm256_whole_round_units(const GemmArgs& a);   // token tiles (frames for GEMM_VT) that fill whole rounds of the persistent grid; the rest goes to the 128-tile kernels
 int gemm256_read_stamps(unsigned long long* out16);   // measurement builds only (-2 otherwise)
 template <typename TT> void launch_gemm256(hipStream_t s, const GemmArgs& a);
 template <typename TT> void launch_gemm_mfma(hipStream_t s, const GemmArgs& a);   // P, Q of the 16-bit type TT (bf16_t / f16_t), MFMA 16x16x32
