@@ -91,6 +91,13 @@ gemmexp)  # where a 256-tile's time goes (measurement builds of tools/build_vari
 gemmab)   # tools/gemm_bench.py with the shipped library and with measurement builds (GEMM_VARIANTS="fbalt desync2 ..."), same box
   python tools/gemm_bench.py ${GEMM_ARGS} > gpurun_out/${R}_gemm_bench.txt 2>&1; echo "--- shipped"; grep 256-tile gpurun_out/${R}_gemm_bench.txt | cut -c1-90
   for v in ${GEMM_VARIANTS}; do [ -f umgen_amd/libumgen_hip_$v.so ] && { UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_$v.so python tools/gemm_bench.py ${GEMM_ARGS} > gpurun_out/${R}_gemm_bench_$v.txt 2>&1; echo "--- $v"; grep 256-tile gpurun_out/${R}_gemm_bench_$v.txt | cut -c1-90; }; done ;;
+mintiles)  # threshold (output tiles) from which a GEMM launch takes the 256-tile kernel, one scene
+  for n in ${MIN_TILES:-150 300 600 1100}; do b mintiles$n env UMGEN_GEMM256_MIN_TILES=$n python bench.py --steps 4 --warmup 1 --no-cpu-baseline; done ;;
+split)  # whole rounds on the 256-tile kernel + the leftover rows on the 128-tile kernels (gemm256_whole_round_units) against one launch
+  for bsz in ${SPLIT_B:-1 4 8}; do
+    b split_b${bsz} python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch $bsz
+    b nosplit_b${bsz} env UMGEN_GEMM256_SPLIT=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch $bsz
+  done ;;
 stamps) UMGEN_DEBUG_TIMING=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/${R}_engine_stamps.txt; grep "decode engine" gpurun_out/${R}_engine_stamps.txt | tail -3 ;;
 closed) python tools/closed_loop.py --frames 30 > gpurun_out/${R}_closed_loop.log 2>&1; tail -4 gpurun_out/${R}_closed_loop.log | cut -c1-600 ;;
 vq) python tools/vq_time.py > gpurun_out/${R}_vq_decode_time.json 2>gpurun_out/${R}_vq_decode_time.err; cat gpurun_out/${R}_vq_decode_time.json
