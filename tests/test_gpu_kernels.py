@@ -77,13 +77,13 @@ def test_linear_256_tile_kernel(prec, R, N, K, gelu, resid):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("F,S,N,K,chunk", [(3, 2207, 768, 768, None), (2, 300, 768, 128, None), (5, 256, 256, 256, None), (1, 2207, 768, 768, None),
-                                            (4, 1031, 768, 768, "2100"), (2, 7, 256, 128, None)])
+@pytest.mark.parametrize("F,S,N,K,chunk", [(3, 2207, 768, 768, None), (2, 300, 768, 128, None), (5, 256, 768, 256, None), (1, 2207, 768, 768, None),
+                                            (4, 1031, 768, 768, "2100"), (2, 7, 768, 128, None), (3, 513, 1536, 256, None)])
 @pytest.mark.parametrize("prec", [1, 2])
 def test_linear_256_tile_kernel_v_transposed(monkeypatch, prec, F, S, N, K, chunk):
     """The spatial attention's V^T ([frame][feature][padded tokens], GEMM_VT) on the 256-tile kernel: token tiles per frame, the frame's
     ragged last tile, pad columns written as zeros, frames as launch chunks (hook) -- bit-identical to the 128-tile kernel's rows, and
-    equal to the fp64 product within the 16-bit rounding."""
+    equal to the fp64 product within the 16-bit rounding.  (N is a whole number of 48-wide heads and of 256-row tiles: 768, 1536.)"""
     rng = np.random.default_rng(F + S + N + K)
     act = rng.standard_normal((F * S, K), dtype=np.float32)
     W = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
