@@ -14,6 +14,9 @@
 #   pmc        rocprofv3 --pmc FETCH_SIZE of the decode engine at the mean KV length     -> r04_pmc_fetch_size_engine.csv
 #   pmcgemm    SQ / TA / TCC counters of the fc GEMM and the spatial attention          -> r04_pmc_gemm_*.txt, r04_pmc_attn_*.txt
 #   gemm       isolated GEMM shapes (tools/gemm_bench.py)                                -> r04_gemm_bench.txt
+#   gemmexp    where a 256-tile's time goes: tools/gemm_stamps.py on the stamps build + gemm_bench on the epi1/2/3 builds (tools/build_variant.sh) -> r04_gemm_stamps.txt, r04_gemm_bench_epi*.txt
+#   gemmab     tools/gemm_bench.py with the shipped library and with measurement builds GEMM_VARIANTS="..."   -> r04_gemm_bench{,_<variant>}.txt
+#   mintiles   one-scene bench by the tile count from which a launch takes the 256-tile kernel              -> r04_bench_mintiles<n>.json
 #   stamps     per-phase microseconds of an engine item                                  -> r04_engine_stamps.txt
 #   closed     30-frame greedy closed loop, 16-bit modes vs fp32 mode                    -> r04_closed_loop.json
 #   vq         umgen_vq_decode of the two production decoders, 20 frames              -> r04_vq_decode_time{,_valu}.json
