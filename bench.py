@@ -275,7 +275,9 @@ def main():
             "roofline_gemm": {"bound": "mfma", "achieved": gemm_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
                               "frac": gemm_tfs / MFMA_BF16_PEAK_TFS, "kernel": ("gemm16_256_kernel (256 x 256 tiles; launches under 300 tiles: gemm_bf16_pers_kernel / gemm_bf16_glds_kernel), TAR / ego stacks"
                                          if args.precision != "fp32" else "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32), TAR / ego stacks"),
-                              "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(1, tm["gemm_launches"])},
+                              "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(1, tm["gemm_launches"]),
+                              "clock_note": "peak is the nominal 2.4 GHz figure; inside these kernels' k-loops the chip sustains 1.46-1.71 GHz "
+                                            "(profiles/r04_gemm_stamps_clock.txt, measurement build; not measured in this run)"},
             "roofline_attn": {"bound": "mfma", "achieved": attn_tfs, "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
                               "frac": attn_tfs / MFMA_BF16_PEAK_TFS, "kernel": "attn_spatial_mfma_kernel",
                               "launches": tm["attn_launches"], "avg_launch_ms": tm["attn_ms"] / max(1, tm["attn_launches"])},

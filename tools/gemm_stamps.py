@@ -18,5 +18,5 @@ for R in rows:
         if rs == 0:
             for g in range(2):
                 n = max(1, st[g * 8 + 3])
-                line += f" | group {g}: tiles {n/11:.0f}/launch, per tile k-loop {st[g*8]/n/100:.2f} us (first k-tile {st[g*8+1]/n/100:.2f}, other k-tiles {(st[g*8]-st[g*8+1])/n/100/(K/64-1):.3f} each) epilogue {st[g*8+2]/n/100:.2f} us"
+                line += f" | group {g}: tiles {n/11:.0f}/launch, per tile k-loop {st[g*8]/n/100:.2f} us (first k-tile {st[g*8+1]/n/100:.2f}, other k-tiles {(st[g*8]-st[g*8+1])/n/100/(K/64-1):.3f} each) epilogue {st[g*8+2]/n/100:.2f} us, shader clock in the k-loops {st[g*8+4]/max(1,st[g*8])*100:.0f} MHz"
         print(line, flush=True)

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 
     unsigned char* stage = lds + kRing + wave * kStage;
 #ifdef UMGEN_G256_STAMPS
-    unsigned long long st_main = 0, st_k0 = 0, st_epi = 0, st_n = 0, st_t0 = 0, st_t1 = 0;
+    unsigned long long st_main = 0, st_k0 = 0, st_epi = 0, st_n = 0, st_t0 = 0, st_t1 = 0, st_c0 = 0, st_clk = 0;   // st_clk: shader-clock ticks (clock64) of the k-loops
 #endif
     while (true) {
         const int tn = t + nloc;
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
         if (STAGGER && wi == 1) __builtin_amdgcn_s_barrier();
 #ifdef UMGEN_G256_STAMPS
         st_t0 = wall_clock64();
+        st_c0 = clock64();
 #endif
         // one k-tile = 4 phases; FX / FY: the registers of the token fragments of the first / second 32 tokens.  FBALT (build option, off:
         // measured on the shapes of the stacks, profiles/r04_gemm_bench_fbalt.txt -- 4096^3 +3 %, the K = 768 shapes -3 .. +3 %, no net gain): the first-token
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #ifdef UMGEN_G256_STAMPS
         st_t1 = wall_clock64();
         st_main += st_t1 - st_t0;
+        st_clk += clock64() - st_c0;
 #endif
         // ---------------- epilogue of this wave's 128 features x 64 tokens (private LDS strip, no workgroup barrier) ----------------
         const int ti = i0 + t % ni, tj = j0 + t / ni;
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
         atomicAdd(&g256_stamps[wi * 8 + 1], st_k0);
         atomicAdd(&g256_stamps[wi * 8 + 2], st_epi);
         atomicAdd(&g256_stamps[wi * 8 + 3], st_n);
+        atomicAdd(&g256_stamps[wi * 8 + 4], st_clk);
     }
 #endif
 }
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 
 size_t gemm256_lds_bytes() { return (size_t)kLds256; }
 
-// measurement builds (UMGEN_G256_STAMPS): ticks of workgroup 9, wave 0 / wave 4: [k-loops, first k-tiles, epilogues, tiles] x 2; reset
+// measurement builds (UMGEN_G256_STAMPS): ticks of workgroup 9, wave 0 / wave 4: [k-loops, first k-tiles, epilogues, tiles, k-loops in shader clocks] x 2; reset
 int gemm256_read_stamps(unsigned long long* out16) {
 #ifdef UMGEN_G256_STAMPS
     unsigned long long z[16] = {};
