@@ -65,11 +65,6 @@ lanes)   # decode lanes (sub-batches of the batched layer on their own streams):
   for n in ${LANES_B32:-1 2 4 8}; do b b32_lanes$n env UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 32; done
   for n in ${LANES_B64:-2 4 8}; do b b64_lanes$n env UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 64; done
   for n in ${LANES_B16:-2 4}; do b b16_lanes$n env UMGEN_DECODE_BATCHED=16 UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 16; done ;;
-fused)   # batched layer with LayerNorm + q|k|v inside the attention launch (UMGEN_BATCHED_FUSED_QKV=1) against the five-launch form, same box
-  for bsz in ${FUSED_B:-32 64}; do
-    b b${bsz}_fusedqkv env UMGEN_BATCHED_FUSED_QKV=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch $bsz
-    b b${bsz}_unfused env UMGEN_BATCHED_FUSED_QKV=0 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch $bsz
-  done ;;
 wide)
   b wide2x python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x
   b wide2x_h40 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x --history 40 ;;

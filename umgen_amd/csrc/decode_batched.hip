@@ -309,138 +309,6 @@ __global__ __launch_bounds__(kABThreads) void attn_decode_batched_kernel(const f
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// LayerNorm + the head's q | k | v rows + decode attention in ONE launch per (scene, head) (UMGEN_BATCHED_FUSED_QKV; round 4).  With the
-// decode lanes the step is bound by the device's kernel dispatch / completion rate: this takes one of the layer's
-// five launches away.  A workgroup needs only ITS head's 144 weight rows of c_attn (221 KB out of the L2: the 16 scenes of a lane share
-// them) and the scene's 768 activations; the rows are VALU dot products on fp32 activations (lane l owns k = 12 l .. 12 l + 11, fmaf chain,
-// then a fixed xor-butterfly over the lanes): per scene and independent of the batch, like everything in this file.  The new token's k | v
-// row goes to the cache for the later steps and, rounded to the cache's 16 bits exactly as a reader would see it, into LDS for this step.
-// ---------------------------------------------------------------------------------------------------------------------------
-template <typename TT>
-__global__ __launch_bounds__(kABThreads) void attn_qkv_decode_batched_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
-                                                                            const TT* __restrict__ W, const float* __restrict__ bias, TT* __restrict__ cache,
-                                                                            long scene_stride, int H, int Lmax, const int* __restrict__ d_len, float* __restrict__ y) {
-    __shared__ float s_m[64], s_l[64], s_o[64][kHeadDim];
-    __shared__ __attribute__((aligned(16))) float s_x[768];     // LN(x) of the scene
-    __shared__ float s_qkv[3 * kHeadDim], s_red[2][kABWaves];
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int E = H * kHeadDim;                       // (launcher: E == 768 -- 3 values per thread, 12 per lane)
-    const int pos = *d_len, L = pos + 1;              // cached keys before this step; keys of this step (the new token's own row is key pos)
-    // ---- LayerNorm of the scene's row (weight only, eps 1e-5, two-pass; module.py:26-37) ----
-    const float* xr = x + (long)b * E;
-    const float x0 = xr[tid], x1 = xr[tid + 256], x2 = xr[tid + 512];
-    float part = wave_sum((x0 + x1) + x2);
-    if (lane == 0) s_red[0][wave] = part;
-    __syncthreads();
-    const float mean = (((s_red[0][0] + s_red[0][1]) + s_red[0][2]) + s_red[0][3]) / (float)E;
-    const float d0 = x0 - mean, d1 = x1 - mean, d2 = x2 - mean;
-    part = wave_sum((d0 * d0 + d1 * d1) + d2 * d2);
-    if (lane == 0) s_red[1][wave] = part;
-    __syncthreads();
-    const float rstd = 1.0f / sqrtf((((s_red[1][0] + s_red[1][1]) + s_red[1][2]) + s_red[1][3]) / (float)E + 1e-5f);
-    s_x[tid] = d0 * rstd * ln_w[tid];
-    s_x[tid + 256] = d1 * rstd * ln_w[tid + 256];
-    s_x[tid + 512] = d2 * rstd * ln_w[tid + 512];
-    __syncthreads();
-    // ---- the head's 144 rows: q_h | k_h | v_h, 36 per wave in batches of 12 (their 24-byte pieces requested together) ----
-    float xv[12];
-#pragma unroll
-    for (int i = 0; i < 12; i += 4) load4(s_x + 12 * lane + i, *reinterpret_cast<float(*)[4]>(&xv[i]));
-    constexpr int RB = 12;
-    for (int r0 = wave * 36; r0 < wave * 36 + 36; r0 += RB) {
-        float wv[RB][12];
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int r = r0 + j, n = (r / kHeadDim) * E + h * kHeadDim + r % kHeadDim;
-            const TT* wp = W + (long)n * E + 12 * lane;
-#pragma unroll
-            for (int i = 0; i < 12; i += 4) load4(wp + i, *reinterpret_cast<float(*)[4]>(&wv[j][i]));
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) acc = fmaf(wv[j][i], xv[i], acc);
-            acc = wave_sum(acc);
-            const int r = r0 + j;
-            if (lane == 0) s_qkv[r] = acc + bias[(r / kHeadDim) * E + h * kHeadDim + r % kHeadDim];
-        }
-    }
-    __syncthreads();
-    if (tid < 2 * kHeadDim) {      // the new token's k | v row: into the cache, and back into LDS as the 16-bit value a reader of the cache gets
-        const int sel = tid / kHeadDim, d = tid % kHeadDim;
-        const TT v16 = Cvt<TT>::from_f(s_qkv[kHeadDim + tid]);
-        cache[(long)b * scene_stride + (((long)sel * H + h) * Lmax + pos) * kHeadDim + d] = v16;
-        s_qkv[kHeadDim + tid] = Cvt<TT>::to_f(v16);
-    }
-    __syncthreads();
-    // ---- attention over keys 0 .. pos: as attn_decode_batched_kernel, the last key out of LDS ----
-    const int dpart = lane & 3, grp = lane >> 2;
-    const TT* kb = cache + (long)b * scene_stride + (long)h * Lmax * kHeadDim + 12 * dpart;
-    const TT* vb = kb + (long)H * Lmax * kHeadDim;
-    float qv[12];
-#pragma unroll
-    for (int d = 0; d < 12; ++d) qv[d] = s_qkv[12 * dpart + d];
-    float m = -INFINITY, l = 0.f, o[12];
-#pragma unroll
-    for (int d = 0; d < 12; ++d) o[d] = 0.f;
-    const int npass = (L + 63) / 64;
-    for (int p0 = 0; p0 < npass; p0 += kABFlight) {
-        float kf[kABFlight][12], vf[kABFlight][12];
-#pragma unroll
-        for (int f = 0; f < kABFlight; ++f) {
-            const int key = max(0, min(16 * (wave + 4 * (p0 + f)) + grp, pos - 1));      // cached rows only (row pos is in flight: LDS below)
-            const TT* kp = kb + (long)key * kHeadDim;
-            const TT* vp = vb + (long)key * kHeadDim;
-#pragma unroll
-            for (int d = 0; d < 12; d += 4) {
-                load4(kp + d, *reinterpret_cast<float(*)[4]>(&kf[f][d]));
-                load4(vp + d, *reinterpret_cast<float(*)[4]>(&vf[f][d]));
-            }
-        }
-#pragma unroll
-        for (int f = 0; f < kABFlight; ++f) {
-            const int key = 16 * (wave + 4 * (p0 + f)) + grp;
-            if (key == pos) {
-#pragma unroll
-                for (int d = 0; d < 12; ++d) { kf[f][d] = s_qkv[kHeadDim + 12 * dpart + d]; vf[f][d] = s_qkv[2 * kHeadDim + 12 * dpart + d]; }
-            }
-            float sc = 0.f;
-#pragma unroll
-            for (int d = 0; d < 12; ++d) sc = fmaf(qv[d], kf[f][d], sc);
-            sc += dpp_xor1(sc);
-            sc += dpp_xor2(sc);
-            if (key < L) {
-                sc *= kScaleQKb;
-                const float mn = fmaxf(m, sc);
-                const float alpha = __expf(m - mn), pr = __expf(sc - mn);
-                m = mn;
-                l = l * alpha + pr;
-#pragma unroll
-                for (int d = 0; d < 12; ++d) o[d] = fmaf(pr, vf[f][d], o[d] * alpha);
-            }
-        }
-    }
-    const int g = wave * 16 + grp;
-    if (dpart == 0) { s_m[g] = m; s_l[g] = l; }
-#pragma unroll
-    for (int d = 0; d < 12; ++d) s_o[g][12 * dpart + d] = o[d];
-    __syncthreads();
-    if (tid < kHeadDim) {
-        float mx = -INFINITY;
-        for (int i = 0; i < 64; ++i) mx = fmaxf(mx, s_m[i]);
-        float lt = 0.f, ot = 0.f;
-        for (int i = 0; i < 64; ++i) {
-            const float w = s_m[i] == -INFINITY ? 0.f : __expf(s_m[i] - mx);
-            lt = fmaf(s_l[i], w, lt);
-            ot = fmaf(s_o[i][tid], w, ot);
-        }
-        y[frag_index(b, h * kHeadDim + tid)] = ot / lt;
-    }
-}
-
 }  // namespace
 
 template <typename TT, int MODE, int NB, int RT, int JB, bool LN>
@@ -480,14 +348,6 @@ template <typename TT>
 void launch_attn_decode_batched(hipStream_t s, const float* q, const TT* cache, long scene_stride, int B, int H, int Lmax, const int* d_len, float* y) {
     hipLaunchKernelGGL((attn_decode_batched_kernel<TT>), dim3(H, B), dim3(kABThreads), 0, s, q, cache, scene_stride, H, Lmax, d_len, y);
 }
-template <typename TT>
-void launch_attn_qkv_decode_batched(hipStream_t s, const float* x, const float* ln_w, const void* Wqkv, const float* bqkv, TT* cache, long scene_stride, int B, int H,
-                                    int Lmax, const int* d_len, float* y) {
-    hipLaunchKernelGGL((attn_qkv_decode_batched_kernel<TT>), dim3(H, B), dim3(kABThreads), 0, s, x, ln_w, reinterpret_cast<const TT*>(Wqkv), bqkv, cache, scene_stride,
-                       H, Lmax, d_len, y);
-}
-template void launch_attn_qkv_decode_batched<bf16_t>(hipStream_t, const float*, const float*, const void*, const float*, bf16_t*, long, int, int, int, const int*, float*);
-template void launch_attn_qkv_decode_batched<f16_t>(hipStream_t, const float*, const float*, const void*, const float*, f16_t*, long, int, int, int, const int*, float*);
 template void launch_attn_decode_batched<bf16_t>(hipStream_t, const float*, const bf16_t*, long, int, int, int, const int*, float*);
 template void launch_attn_decode_batched<f16_t>(hipStream_t, const float*, const f16_t*, long, int, int, int, const int*, float*);
 

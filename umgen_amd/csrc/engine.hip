@@ -147,7 +147,6 @@ struct umgen_engine {
     // Batched decode layer (decode_batched.hip) from `batched_min` scenes per launch on (UMGEN_DECODE_BATCHED=n; 0 = never): the weights
     // once per step for the whole batch, the scenes as the matrix-core instruction's B-columns
     int batched_min = 32;
-    bool batched_fused_qkv = false;     // UMGEN_BATCHED_FUSED_QKV=1: LayerNorm + q|k|v rows inside the attention launch (decode_batched.hip)
     float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;   // fragment-major x / attention output [64 E], gelu(c_fc) [64 x 4E] of the batched layer
     bool use_batched(int B) const {      // (in_lanes: a lane's sub-batch of a batch that qualified)
         return tsz == 2 && (in_lanes || (batched_min > 0 && B >= batched_min)) && B <= kRowsMaxM && E % 32 == 0 && E <= 768;
@@ -531,15 +530,11 @@ int oar_layers(umgen_engine* e, int B, int ns) {
             for (size_t li = 0; li < e->oar.size(); ++li) {
                 const SubW& w = e->oar[e->dbg_same_layer ? 0 : li];
                 T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
-                if (e->batched_fused_qkv && E == 768) {      // LN + q|k|v + attention in one launch per (scene, head)
-                    launch_attn_qkv_decode_batched<T>(e->stream, e->xdec, w.ln_a, w.attn.Wqkv, w.attn.bqkv, cache, e->kv_scene_stride, B, H, e->Lmax, d_len, e->afrag);
-                } else {
-                    RowsArgs r{};
-                    r.x = e->xfrag; r.M = B; r.ln_w = w.ln_a; r.W = w.attn.Wqkv; r.bias = w.attn.bqkv; r.N = 3 * E; r.K = E; r.mode = ROWS_QKV;
-                    r.out = e->qdec; r.ldo = E; r.cache = cache; r.scene_stride = e->kv_scene_stride; r.d_len = d_len; r.Lmax = e->Lmax; r.E = E;
-                    launch_rows_mfma<T>(e->stream, r);
-                    launch_attn_decode_batched<T>(e->stream, e->qdec, cache, e->kv_scene_stride, B, H, e->Lmax, d_len, e->afrag);
-                }
+                RowsArgs r{};
+                r.x = e->xfrag; r.M = B; r.ln_w = w.ln_a; r.W = w.attn.Wqkv; r.bias = w.attn.bqkv; r.N = 3 * E; r.K = E; r.mode = ROWS_QKV;
+                r.out = e->qdec; r.ldo = E; r.cache = cache; r.scene_stride = e->kv_scene_stride; r.d_len = d_len; r.Lmax = e->Lmax; r.E = E;
+                launch_rows_mfma<T>(e->stream, r);
+                launch_attn_decode_batched<T>(e->stream, e->qdec, cache, e->kv_scene_stride, B, H, e->Lmax, d_len, e->afrag);
                 RowsArgs p{};
                 p.x = e->afrag; p.M = B; p.W = w.attn.Wo; p.bias = w.attn.bo; p.N = E; p.K = E; p.mode = ROWS_RESID; p.out = e->xdec; p.ldo = E; p.out_frag = e->xfrag; p.E = E;
                 launch_rows_mfma<T>(e->stream, p);
@@ -1603,7 +1598,6 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     HIPCHK(e, hipMemset(e->hfrag, 0, (size_t)kRowsMaxM * 4 * E * 4));
     if (const char* bd = getenv("UMGEN_DECODE_BATCHED")) e->batched_min = atoi(bd);
     if (const char* dl = getenv("UMGEN_DECODE_LANES")) e->lanes_env = atoi(dl);
-    if (const char* fq = getenv("UMGEN_BATCHED_FUSED_QKV")) e->batched_fused_qkv = fq[0] == '1';
     if (e->tsz == 2 && Bm >= 2 && e->lanes_env != 1) {      // decode lanes: streams, step states and fragment buffers (1.2 MB per lane)
         for (auto& ln : e->lane) {
             HIPCHK(e, hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));

@@ -134,10 +134,6 @@ void launch_rows_to_frag(hipStream_t s, const float* x, long ldx, int M, int K, 
 template <typename TT> void launch_attn_decode_batched(hipStream_t s, const float* q, const TT* cache, long scene_stride, int B, int H, int Lmax,
                                                         const int* d_len, float* y);
 
-// the same with LayerNorm + the head's q | k | v rows in front, in one launch (x row-major [B][E] fp32, E == 768; writes the new token's k | v cache row)
-template <typename TT> void launch_attn_qkv_decode_batched(hipStream_t s, const float* x, const float* ln_w, const void* Wqkv, const float* bqkv, TT* cache,
-                                                            long scene_stride, int B, int H, int Lmax, const int* d_len, float* y);
-
 // ------------------------------------------------------------------------------------------------
 // XCD-resident decode engine (oar_engine.hip): all BlockOAR layers of one decode step in one launch, bf16 weights, n_embd 768
 // ------------------------------------------------------------------------------------------------
