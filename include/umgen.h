@@ -107,7 +107,7 @@ typedef struct umgen_timings {
     int32_t decode_engine;  /* 1 when the last frame's decode steps ran on the XCD-resident decode engine */
     int32_t engine_fallback; /* 1 when this configuration would use the decode engine (16-bit mode, n_embd 768) but its census failed at
                               * umgen_create: the five-launch decode layer runs instead (a warning is printed at create) */
-    int32_t decode_batched; /* 1 when the last frame's decode steps ran on the batched decode layer (32 and more scenes per call: the scenes
+    int32_t decode_batched; /* 1 when the last frame's decode steps ran on the batched decode layer (24 and more scenes per call: the scenes
                               * as the matrix-core instruction's columns, csrc/decode_batched.hip) */
     int32_t decode_lanes;   /* ... and on how many decode lanes (sub-batches on their own streams, forked behind the TAR stacks and joined at the
                               * end of the frame; 0 when the batched layer did not run) */

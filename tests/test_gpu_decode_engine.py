@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 def make(cfg, sd, engine_on, max_batch=1, graphs=True):
     """engine_on: the XCD-resident engine for EVERY batch size (its systolic / rounds schedules included: the batched decode layer that
-    takes 32 and more scenes by default is switched off), else the five-launch layer."""
+    takes 24 and more scenes by default is switched off), else the five-launch layer."""
     old = {k: os.environ.get(k) for k in ("UMGEN_DECODE_ENGINE", "UMGEN_DECODE_BATCHED")}
     os.environ["UMGEN_DECODE_ENGINE"] = "1" if engine_on else "0"
     os.environ["UMGEN_DECODE_BATCHED"] = "0"
@@ -94,7 +94,7 @@ def test_engine_is_batch_invariant(setup, B, engine_on):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# the batched decode layer (csrc/decode_batched.hip): 32 and more scenes per call, the scenes as the MFMA's B-columns
+# the batched decode layer (csrc/decode_batched.hip): 24 and more scenes per call, the scenes as the MFMA's B-columns
 # ---------------------------------------------------------------------------------------------------------------------
 def make_batched(cfg, sd, threshold, max_batch=1, precision="bf16"):
     """UMGEN_DECODE_BATCHED=<threshold>: batches of at least that many scenes run the batched decode layer (1: every call does)."""
@@ -201,17 +201,17 @@ def test_decode_lanes_equal_the_single_stream_batched_layer(setup, precision):
 
 
 def test_default_path_selection_by_batch_size(setup):
-    """Up to 31 scenes per call the XCD-resident engine takes the decode step (its systolic schedule from 5 on), from 32 on the batched
-    layer (measured crossover, profiles/r04_bench_b{16,32}*.json; UMGEN_DECODE_BATCHED moves the threshold): umgen_timings says which ran."""
+    """Up to 23 scenes per call the XCD-resident engine takes the decode step (its systolic schedule from 5 on), from 24 on the batched
+    layer (measured crossover, profiles/r04_lanes_sweep.txt; UMGEN_DECODE_BATCHED moves the threshold): umgen_timings says which ran."""
     cfg, sd = setup
-    e = Engine(cfg, precision="bf16", max_batch=32, max_cond_frames=4)
+    e = Engine(cfg, precision="bf16", max_batch=24, max_cond_frames=4)
     e.load_state_dict(sd)
     e.finalize()
-    scenes = [synthetic_scene(40 + i, n_frames=2) for i in range(32)]
-    e.rollout({m: np.concatenate([s[m] for s in scenes[:31]]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(31)))
+    scenes = [synthetic_scene(40 + i, n_frames=2) for i in range(24)]
+    e.rollout({m: np.concatenate([s[m] for s in scenes[:23]]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(23)))
     t = e.timings()
     assert t["decode_engine"] == 1 and t["decode_batched"] == 0
-    e.rollout({m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(32)))
+    e.rollout({m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(24)))
     t = e.timings()
-    assert t["decode_engine"] == 0 and t["decode_batched"] == 1
+    assert t["decode_engine"] == 0 and t["decode_batched"] == 1 and t["decode_lanes"] == 2
     e.close()

@@ -152,7 +152,7 @@ def test_16bit_teacher_forced_frame_at_production_width_lies_inside_the_oracle_e
 
 
 def test_batched_decode_layer_lies_inside_the_oracle_ensemble_at_depth():
-    """The batched decode layer (32 and more scenes per call: csrc/decode_batched.hip, the scenes as the MFMA's columns) facing the
+    """The batched decode layer (24 and more scenes per call: csrc/decode_batched.hip, the scenes as the MFMA's columns) facing the
     ORACLE, not another engine path: the `deep` production-width frame (10 BlockOAR layers) teacher-forced through it
     (UMGEN_DECODE_BATCHED=1 sends a single scene down the same kernels; its results do not depend on the batch) must lie within
     2 x the spread of the rounding-aware oracle's accumulation-order ensemble, like the XCD-resident engine."""

@@ -1,4 +1,4 @@
-// Batched decode layer for MANY scenes per GPU (32 and more; UMGEN_DECODE_BATCHED): BlockOAR (module.py:378-428) for B scenes as five
+// Batched decode layer for MANY scenes per GPU (24 and more; UMGEN_DECODE_BATCHED): BlockOAR (module.py:378-428) for B scenes as five
 // launches per layer whose cost is what the roofline says a large batch should cost -- the layer's weights ONCE per step plus every
 // scene's K/V rows -- instead of the XCD-resident engine's one (scene, layer) item after the other (12.8 us per item whatever B is:
 // 0.24 of HBM peak at 32 scenes, profiles/r03_bench_b32.json).

@@ -146,7 +146,7 @@ struct umgen_engine {
     double gemm_flops_pending = 0, attn_flops_pending = 0;
     // Batched decode layer (decode_batched.hip) from `batched_min` scenes per launch on (UMGEN_DECODE_BATCHED=n; 0 = never): the weights
     // once per step for the whole batch, the scenes as the matrix-core instruction's B-columns
-    int batched_min = 32;
+    int batched_min = 24;               // measured crossover with the engine (profiles/r04_lanes_sweep.txt): 20 scenes 1546 (engine) vs 1674 us per step, 24: 1843 vs 1708, 28: 2104 vs 1775
     float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;   // fragment-major x / attention output [64 E], gelu(c_fc) [64 x 4E] of the batched layer
     bool use_batched(int B) const {      // (in_lanes: a lane's sub-batch of a batch that qualified)
         return tsz == 2 && (in_lanes || (batched_min > 0 && B >= batched_min)) && B <= kRowsMaxM && E % 32 == 0 && E <= 768;
@@ -175,7 +175,8 @@ struct umgen_engine {
         // measured (profiles/r04_lanes_sweep.txt): lanes of 16 scenes (one full column block of the matrix-core instruction) are best --
         // 32 scenes 2132 / 1829 / 2040 us per step on 1 / 2 / 4 lanes, 64 scenes 3284 / 2689 / 2532 on 1 / 2 / 4; the device runs four
         // streams' kernels at a time (8 lanes: two rounds, 3784 / 4063 us)
-        int n = lanes_env > 0 ? lanes_env : std::min(4, std::max(1, B / 16));
+        // ; from the threshold of 24 scenes on at least two lanes (24 scenes: 1978 us on one lane, 1708 on two)
+        int n = lanes_env > 0 ? lanes_env : std::min(4, std::max(B >= 24 ? 2 : 1, B / 16));
         return std::max(1, std::min(std::min(n, kMaxLanes), B));
     }
     hipError_t launch_status = hipSuccess;   // first refused kernel launch of the frame (hipGetLastError behind the GEMM launches): fails the frame
