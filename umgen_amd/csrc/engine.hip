@@ -176,7 +176,8 @@ struct umgen_engine {
         // 32 scenes 2132 / 1829 / 2040 us per step on 1 / 2 / 4 lanes, 64 scenes 3284 / 2689 / 2532 on 1 / 2 / 4; the device runs four
         // streams' kernels at a time (8 lanes: two rounds, 3784 / 4063 us)
         // ; from the threshold of 24 scenes on at least two lanes (24 scenes: 1978 us on one lane, 1708 on two)
-        int n = lanes_env > 0 ? lanes_env : std::min(4, std::max(B >= 24 ? 2 : 1, B / 16));
+        // ; lanes of at most 16 scenes: 40 scenes 2285 / 2020 / 2136 us on 2 / 3 / 4 lanes, 48: 2182 / 2231 on 3 / 4, 56: 2570 / 2369 on 3 / 4
+        int n = lanes_env > 0 ? lanes_env : std::min(4, std::max(B >= 24 ? 2 : 1, (B + 15) / 16));
         return std::max(1, std::min(std::min(n, kMaxLanes), B));
     }
     hipError_t launch_status = hipSuccess;   // first refused kernel launch of the frame (hipGetLastError behind the GEMM launches): fails the frame
