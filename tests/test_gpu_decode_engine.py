@@ -200,6 +200,42 @@ def test_decode_lanes_equal_the_single_stream_batched_layer(setup, precision):
             np.testing.assert_array_equal(outs[lanes][m], outs["1"][m], err_msg=f"{lanes} lanes, {m}")
 
 
+def test_decode_lanes_in_control_mode_with_a_growing_window(setup):
+    """The lanes address every per-scene array through their base offset -- the control mask, the previous frame's boxes, the decoded-box
+    buffer of the rule constraint, the seeds: a 25-scene control rollout (pose + one controlled slot per scene, window growing 2 -> 3 so that
+    the second frame reuses the slot caches) on 2 lanes equals the one-stream batched layer and the scenes' own one-scene rollouts."""
+    from umgen_amd.synth import synthetic_control
+    cfg, sd = setup
+    B = 25
+    scenes = [synthetic_scene(90 + i, n_frames=2) for i in range(B)]
+    inits = [synthetic_control(90 + i, n_frames=2, slot=2 + i % 5) for i in range(B)]
+    cat = lambda ds: {k: np.concatenate([d[k] for d in ds]) for k in ds[0]}
+    seeds = [700 + i for i in range(B)]
+    kw = dict(cond_frames=3, input_cond_frames=2, control_test=True)
+    outs = {}
+    for lanes in ("1", None):
+        old = os.environ.get("UMGEN_DECODE_LANES")
+        if lanes is not None:
+            os.environ["UMGEN_DECODE_LANES"] = lanes
+        try:
+            e = make_batched(cfg, sd, 1, max_batch=B)
+        finally:
+            if lanes is not None:
+                if old is None:
+                    del os.environ["UMGEN_DECODE_LANES"]
+                else:
+                    os.environ["UMGEN_DECODE_LANES"] = old
+        outs[lanes] = e.rollout(cat(scenes), 2, init_tokens=cat(inits), seeds=seeds, **kw)
+        assert e.timings()["decode_lanes"] == (1 if lanes else 2)
+        if lanes is None:
+            single = {i: e.rollout(scenes[i], 2, init_tokens=inits[i], seeds=[seeds[i]], **kw) for i in (0, 12, 13, 24)}
+        e.close()
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(outs[None][m], outs["1"][m], err_msg=m)
+        for i, ref in single.items():
+            np.testing.assert_array_equal(outs[None][m][i:i + 1], ref[m], err_msg=f"scene {i} {m}")
+
+
 def test_default_path_selection_by_batch_size(setup):
     """Up to 23 scenes per call the XCD-resident engine takes the decode step (its systolic schedule from 5 on), from 24 on the batched
     layer (measured crossover, profiles/r04_lanes_sweep.txt; UMGEN_DECODE_BATCHED moves the threshold): umgen_timings says which ran."""
