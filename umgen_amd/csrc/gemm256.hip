@@ -7,6 +7,7 @@
 //     128 x 128 form;
 //   * operands go HBM -> LDS with global_load_lds (no staging registers), into a RING of 8 half-tile slots (128 rows x 64 k = 16 KB
 //     each, XOR-swizzled on the source side so that ds_read_b128 fragment reads are conflict-free): 2 k-tiles x {P half 0/1, Q half 0/1};
+//   * (round 4: the four phases below run as TWO of 32 MFMAs -- UMGEN_G256_PH2 -- with the same refill / wait points pairwise merged)
 //   * a k-tile is 4 phases of 16 MFMAs (one quadrant of the wave's sub-tile x the whole k-tile).  Every phase issues ONE half-tile
 //     refill into the slot whose last reader retired a phase earlier: the P halves of k-tile kt+1 in phases 0 / 1, the Q halves of
 //     k-tile kt+2 in phases 2 / 3 -- every load has >= 3 phases (~1.5k cycles) to land, and the loads of an output tile's first
@@ -52,6 +53,12 @@ constexpr int EPI = UMGEN_G256_EPI;
 #define UMGEN_G256_FBALT 0
 #endif
 constexpr bool FBALT = UMGEN_G256_FBALT;
+#ifndef UMGEN_G256_PH2
+#define UMGEN_G256_PH2 1     // two phases of 32 MFMAs per k-tile -- 4 barriers instead of the 8 of the four-phase form (0): fragment reads 16 / 8 per
+                             // phase, both P refills in the first, both Q refills and the counted wait in the second.  Same products in the same
+                             // order (bit-identical outputs); 8 scenes' rows: q|k 936 -> 994, fc 1015 -> 1048, fc + GELU 833 -> 865, K = 3072
+                             // projection 957 -> 1019, V^T 855 -> 908, 4096^3 1283 -> 1402 TFLOP/s (profiles/r04_gemm_bench_ph2.txt)
+#endif
 #ifdef UMGEN_G256_STAMPS
 __device__ unsigned long long g256_stamps[16];
 #endif
@@ -175,6 +182,13 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *reinterpret_cast<const vec8*>(sP + swz(m * 16 + frow, kk * 4 + g));
+#if UMGEN_G256_PH2
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) FY[n][kk] = *reinterpret_cast<const vec8*>(sQ + swz((2 + n) * 16 + frow, kk * 4 + g));
+            if (do1) issue(par1 * 4 + 1, true, s1, 1, k1);
+#endif
             if (do1) issue(par1 * 4 + 0, true, s1, 0, k1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired BEFORE the barrier: the other wave group's next refill may target this slot
             __builtin_amdgcn_s_barrier();
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n) acc[m][n] = Mma16<TT>::mfma(fa[m][kk], FX[n][kk], acc[m][n]);
+#if !UMGEN_G256_PH2
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---------------- phase 1: quadrant (features 0..63, tokens 32..63) ----------------
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -212,6 +228,14 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) fa[m][kk] = *reinterpret_cast<const vec8*>(sP + swz((4 + m) * 16 + frow, kk * 4 + g));
             if (do2) issue(par * 4 + 2, false, s2, 0, k2);       // (the Q slots of this k-tile: their last reads were phase 1's)
+#if UMGEN_G256_PH2
+            if (do2) {
+                issue(par * 4 + 3, false, s2, 1, k2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#endif
             if (preload) {     // the Q halves of k-tile kt + 1 (requested a k-tile ago) have landed: everything but this k-tile's 4 + 2 requests
                 if (do2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -226,6 +250,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n) acc[4 + m][2 + n] = Mma16<TT>::mfma(fa[m][kk], FY[n][kk], acc[4 + m][2 + n]);
+#if !UMGEN_G256_PH2
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---------------- phase 3: quadrant (features 64..127, tokens 0..31); the k-tile's one counted wait ----------------
@@ -246,6 +271,7 @@ __global__ __launch_bounds__(512) void gemm16_256_kernel(GemmArgs a, int nI, int
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
