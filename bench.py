@@ -141,6 +141,10 @@ def main():
                          "two ranks on a device).  Exercises the launch contract, the partition, the gather, the max-over-ranks clock and "
                          "the JSON line -- NOT a scaling measurement (the line says so); use --config tiny: two XCD-resident decode "
                          "engines cannot share a GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="world size 1 only: still create the RCCL process group (backend nccl, device_id = this GPU) and run the path's "
+                         "barrier, device all-gather and max all-reduce on it -- the hardware execution of the N > 1 communication code a "
+                         "one-GPU box allows (the line carries rccl_exercised)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     args = ap.parse_args()
@@ -157,7 +161,14 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = args.force_dist and world == 1 and not args.share_gpu
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    dist_on = world > 1 or force_dist
+    if dist_on:
         if args.share_gpu:
             dist.init_process_group("gloo")
         else:
@@ -195,11 +206,11 @@ def main():
         return eng.rollout(toks, new_frames, cond_frames=T, input_cond_frames=T_in, seeds=seeds,
                            **control_of(scene_ids if scene_ids is not None else mine, new_frames))
 
-    gdev = "cpu" if (world == 1 or args.share_gpu) else "cuda"      # where the one all-gather of the path runs (RCCL: device buffers)
+    gdev = "cpu" if (not dist_on or args.share_gpu) else "cuda"      # where the one all-gather of the path runs (RCCL: device buffers)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -208,12 +219,13 @@ def main():
     sync()
     t0 = time.perf_counter()
     # the timed region: every rank's rollouts + the one exchange of the path (all-gather of the sampled tokens, north_star)
-    out = sharded_rollout(rollout_fn, scenes, base_seed=1000, batch=B, device=gdev, pass_ids=True, new_frames=args.steps)
+    out = sharded_rollout(rollout_fn, scenes, base_seed=1000, batch=B, device=gdev, pass_ids=True, force_collective=force_dist,
+                          new_frames=args.steps)
     assert out["map"].shape[0] == n_scenes
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=gdev if world > 1 else "cuda")
-    if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=gdev if dist_on else "cuda")
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     tm = eng.timings()
@@ -294,6 +306,9 @@ def main():
             "decode_engine": int(engine_on), "engine_fallback": int(tm["engine_fallback"]), "decode_batched": int(tm.get("decode_batched", 0)),
             "decode_lanes": lanes,
         }
+        if force_dist:
+            res["rccl_exercised"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective_device": gdev,
+                                     "calls": "init_process_group(nccl, device_id), barrier, all_reduce(MAX) x2, all_gather of the int32 token buffer -- inside the timed region"}
         if args.share_gpu:
             res["dry_run"] = f"{world} ranks SHARING cuda:0 over gloo: exercises the N > 1 code path only; value is not a scaling measurement"
         if tm["engine_fallback"]:
@@ -304,7 +319,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args.config, threads=min(32, os.cpu_count() or 1))
         print(json.dumps(res))
     eng.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -288,14 +288,18 @@ def test_sampler_topk_rows(V, k):
         for t in range(nthr):
             ii = np.arange(t * 7 + r, V, 256)
             L[r, ii] = 6.0 + rng.random(ii.size).astype(np.float32)
-    L[40, :70] = 9.0                                          # 70 equal maxima: the kept set overflows the sampler's 64 slots
+    L[40, :70] = 9.0                                          # 70 equal maxima: more ties than the kept-set buffer's 64 slots -> the exhaustive walk
+    L[41, :] = 0.0                                            # a zero-initialised head: every logit ties, the draw is uniform over V (UMGen.py:899-913 keeps every tie)
+    L[42, 5::3] = 7.5                                         # ~V / 3 ties at the top, strided over every thread
+    L[43, :70] = 9.0
     u = rng.random(n).astype(np.float32)
+    u[43] = np.float32(1.0 - 2.0 ** -24)                      # the largest uniform the generator emits: the walk ends on the last tie
     tok = np.zeros(n, np.int32)
     ovf = np.zeros(1, np.int32)
     import ctypes as C
     check(lib().umgen_dbg_sample_topk(fp(L), n, V, k, C.c_float(1.0), fp(u), tok.ctypes.data_as(C.POINTER(C.c_int32)),
                                       ovf.ctypes.data_as(C.POINTER(C.c_int32))))
-    assert ovf[0] == 1, "exactly the row with 70 tied maxima must report the kept-set overflow"
+    assert ovf[0] == 0, "no row is refused any more: ties beyond the 64-slot kept set are SAMPLED"
     for r in range(n):
-        if r != 40:
-            assert tok[r] == ref_sample_topk(L[r], k, 1.0, u[r]), (r, int(tok[r]))
+        assert tok[r] == ref_sample_topk(L[r], k, 1.0, u[r]), (r, int(tok[r]))
+    assert tok[40] < 70 and tok[43] < 70

@@ -17,7 +17,7 @@ LOGIT_POS = {"map": [0, 1, 511, 1023], "bbox3d": [0, 9, 10, 11, 330, 659], "imag
 COND_ROWS = [0, 1, 4, 5, 6, 500, 1030, 1031, 1032, 1042, 1692, 1693, 1694, 2000, 2206]
 
 
-@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy", "tiny_grow_boxctl_greedy", "tiny_mapgiven_greedy", "tiny_mapboxgiven_greedy"])
+@pytest.mark.parametrize("name", ["tiny_video_greedy", "tiny_control_greedy", "tiny_boxctl_greedy", "tiny_grow_boxctl_greedy", "tiny_grow_control_greedy", "tiny_mapgiven_greedy", "tiny_mapboxgiven_greedy"])
 def test_oracle_matches_reference_golden(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]

@@ -174,3 +174,29 @@ def test_bench_multi_rank_contract_dry_run_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 0 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["config"]["scenes_per_gpu"] == 2 and "dry_run" in d
     assert abs(d["value"] - 4 * 2207 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # 2 ranks x 2 scenes x 1 frame over the max-over-ranks time
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_runs_the_rccl_calls_on_one_gpu():
+    """SURVEY.md section 8e on hardware, as far as a one-GPU box allows: `bench.py --force-dist` creates the RCCL
+    process group (backend nccl, device_id = cuda:0, world size 1) and runs the N > 1 path's barrier, the DEVICE all-gather of the int32
+    token buffer and the max-over-ranks all-reduce of shard.py / bench.py inside the timed region."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "2", "--config", "tiny",
+           "--history", "3", "--force-dist", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_exercised"]["backend"] == "nccl" and d["rccl_exercised"]["collective_device"] == "cuda"
+    assert abs(d["value"] - 2 * 2207 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

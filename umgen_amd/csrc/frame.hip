@@ -337,8 +337,37 @@ __device__ int block_sample_topk(const float* __restrict__ logits, int V, int k,
         }
     }
     __syncthreads();
-    if (tid == 0 && sh.n_kept > kMaxKept && overflow) atomicAdd(overflow, 1);   // more ties than the buffer holds: the frame is failed on the host
-    if (wave == 0) {
+    (void)overflow;
+    if (sh.n_kept > kMaxKept) {
+        // More logits tie with the k-th largest one than the kept-set buffer holds (a degenerate head: e.g. zero-initialised weights give V
+        // equal logits).  The reference's topk keeps EVERY tie and samples among them (UMGen.py:899-913), so does this walk: one thread goes
+        // over the logits in index order -- maximum, sequential fp32 softmax denominator, inverse-CDF -- with exactly the arithmetic of the
+        // kept-set path below (and of the oracle).  Slow (three passes over V values by one lane) and never taken by a trained model.
+        if (tid == 0) {
+            float zmax = -INFINITY;
+            for (int idx = 0; idx < V; ++idx) {
+                const float l = idx != mask_idx ? logits[idx] : -INFINITY;
+                if (l >= kth && l > -INFINITY) zmax = fmaxf(zmax, l / temp);
+            }
+            float total = 0.f;
+            int last = 0;
+            for (int idx = 0; idx < V; ++idx) {
+                const float l = idx != mask_idx ? logits[idx] : -INFINITY;
+                if (l >= kth && l > -INFINITY) { total = __fadd_rn(total, exp_det(__fsub_rn(l / temp, zmax))); last = idx; }
+            }
+            const float target = __fmul_rn(u, total);
+            float c = 0.f;
+            int res = last;
+            for (int idx = 0; idx < V; ++idx) {
+                const float l = idx != mask_idx ? logits[idx] : -INFINITY;
+                if (l >= kth && l > -INFINITY) {
+                    c = __fadd_rn(c, exp_det(__fsub_rn(l / temp, zmax)));
+                    if (c > target) { res = idx; break; }
+                }
+            }
+            sh.result = res;
+        }
+    } else if (wave == 0) {
         const int n = min(sh.n_kept, kMaxKept);
         // sort the kept set by token index: rank by uniform readlane loop, scatter through LDS, read back sorted
         const int ki = lane < n ? sh.kept_i[lane] : 0x7fffffff;

@@ -585,7 +585,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
     const float* P = reinterpret_cast<const float*>(a.P) + (long)z * a.strideP;
     const float* Q = reinterpret_cast<const float*>(a.Q) + (long)z * a.strideQ;
     const int lr = tid >> 3, lk = (tid & 7) * 4;     // staging: rows lr + 32 it, k offset lk .. lk + 3
-    const bool k4 = (a.K % 4 == 0) && (a.ldp % 4 == 0) && (a.ldq % 4 == 0);
+    // 16-byte loads: rows, batch strides and both bases must keep every float4 aligned (the VALU kernel this one replaced had no such requirement)
+    const bool k4 = (a.K % 4 == 0) && (a.ldp % 4 == 0) && (a.ldq % 4 == 0) && (a.strideP % 4 == 0) && (a.strideQ % 4 == 0) &&
+                    (((uintptr_t)a.P | (uintptr_t)a.Q) % 16 == 0);
     float4 rp[4], rq[4];
     auto fetch = [&](int k0) {
 #pragma unroll

@@ -147,8 +147,9 @@ class Engine:
         elif init_tokens is not None and init_tokens.get("bbox3d") is not None:   # with or without pose tokens (UMGen.py:1458-1473)
             cb = _i64(init_tokens["bbox3d"])
             if cp is None:
-                if cb.ndim != 3 or cb.shape[0] != B or cb.shape[2] != CONTENT_LEN["bbox3d"]:
-                    raise UMGenError(f"init_tokens['bbox3d'] has shape {cb.shape}, expected ({B}, T_ctl, {CONTENT_LEN['bbox3d']})")
+                # (umgen_rollout takes ONE T_ctl for every control / given array: a given map and control boxes must cover the same frames)
+                if cb.ndim != 3 or cb.shape[0] != B or cb.shape[2] != CONTENT_LEN["bbox3d"] or (T_ctl and cb.shape[1] != T_ctl):
+                    raise UMGenError(f"init_tokens['bbox3d'] has shape {cb.shape}, expected ({B}, {T_ctl or 'T_ctl'}, {CONTENT_LEN['bbox3d']})")
                 T_ctl = cb.shape[1]
             elif cb.shape != (B, T_ctl, CONTENT_LEN["bbox3d"]):
                 raise UMGenError(f"init_tokens['bbox3d'] has shape {cb.shape}, expected {(B, T_ctl, CONTENT_LEN['bbox3d'])}")

@@ -38,11 +38,12 @@ def unpack_tokens(flat: np.ndarray) -> Dict[str, np.ndarray]:
 
 
 def gather_scene_tokens(local_out: Dict[str, np.ndarray], local_ids: Sequence[int], n_scenes: int,
-                        device: str = "cpu") -> Dict[str, np.ndarray]:
+                        device: str = "cpu", force_collective: bool = False) -> Dict[str, np.ndarray]:
     """All ranks receive mod -> int64 [n_scenes, T, S_mod] in scene-id order.  One all_gather of an int32 buffer
-    (ranks with fewer scenes pad to the largest per-rank count)."""
+    (ranks with fewer scenes pad to the largest per-rank count).  ``force_collective``: run the all_reduce / all_gather even in a
+    one-rank process group (bench.py --force-dist: the only way to execute the RCCL calls of this path on a one-GPU box)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return {m: np.asarray(local_out[m]).astype(np.int64) for m in MOD_ORDER}
     per_rank = (n_scenes + world - 1) // world
     flat = pack_tokens(local_out) if len(local_ids) else None
@@ -64,7 +65,8 @@ def gather_scene_tokens(local_out: Dict[str, np.ndarray], local_ids: Sequence[in
 
 
 def sharded_rollout(rollout_fn, scenes: Sequence[Dict[str, np.ndarray]], base_seed: int, batch: int = 1,
-                    device: str = "cpu", scene_ids: Optional[Sequence[int]] = None, pass_ids: bool = False, **kw) -> Dict[str, np.ndarray]:
+                    device: str = "cpu", scene_ids: Optional[Sequence[int]] = None, pass_ids: bool = False,
+                    force_collective: bool = False, **kw) -> Dict[str, np.ndarray]:
     """Runs ``rollout_fn(tokens[B,...], seeds=[...], **kw)`` on this rank's scenes in batches of ``batch`` and gathers all scenes.
 
     ``scene_ids``: global ids of the entries of ``scenes`` (default 0..n-1) -- the RNG seeds are keyed by them, so a filtered
@@ -82,4 +84,4 @@ def sharded_rollout(rollout_fn, scenes: Sequence[Dict[str, np.ndarray]], base_se
         extra = {"scene_ids": [gids[s] for s in chunk]} if pass_ids else {}
         outs.append(rollout_fn(toks, seeds=[scene_seed(base_seed, gids[s]) for s in chunk], **extra, **kw))
     local = {m: np.concatenate([o[m] for o in outs]) for m in MOD_ORDER} if outs else {m: np.zeros((0, 0, CONTENT_LEN[m]), np.int64) for m in MOD_ORDER}
-    return gather_scene_tokens(local, ids, len(scenes), device=device)
+    return gather_scene_tokens(local, ids, len(scenes), device=device, force_collective=force_collective)
