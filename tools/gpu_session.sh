@@ -24,7 +24,7 @@
 #   ab:<name>  bench.py --steps 3 with UMGEN_LIB_PATH=umgen_amd/libumgen_hip_<name>.so (tools/build_variant.sh) next to the shipped library
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
-R=r04
+R=r05
 line() {  # one-line summary of a bench JSON
 python - "$1" <<'PY'
 import json, sys
