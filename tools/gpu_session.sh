@@ -61,6 +61,17 @@ batched)
   b b64 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 64
   b b16_engine env UMGEN_DECODE_BATCHED=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 16
   b b32_engine env UMGEN_DECODE_BATCHED=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 32 ;;
+ms)   # the multi-scene decode engine (oar_engine_ms.hip) at MS_B scenes per GPU, with per-phase stamps of an item           -> r05_bench_ms_b<n>.json, r05_ms_stamps.txt
+  : > gpurun_out/${R}_ms_stamps.txt
+  for n in ${MS_B:-16 32 64}; do
+    b ms_b$n env UMGEN_DEBUG_TIMING=1 ${MS_ENV} python bench.py --steps ${MS_STEPS:-1} --warmup 1 --no-cpu-baseline --batch $n
+    echo "--- $n scenes ${MS_ENV}" >> gpurun_out/${R}_ms_stamps.txt; grep "multi-scene decode engine" gpurun_out/${R}_bench_ms_b$n.err | tail -1 >> gpurun_out/${R}_ms_stamps.txt
+  done; cat gpurun_out/${R}_ms_stamps.txt | cut -c1-400 ;;
+msab)  # the same batch on the multi-scene engine, the one-scene engine and the batched layer + lanes (round 4's path)
+  for n in ${MS_B:-16 32 64}; do
+    b ms_b$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch $n
+    b r4path_b$n env UMGEN_DECODE_MS=0 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch $n
+  done ;;
 lanes)   # decode lanes (sub-batches of the batched layer on their own streams): lane count sweep at 16 / 32 / 64 scenes
   for n in ${LANES_B32:-1 2 4 8}; do b b32_lanes$n env UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 32; done
   for n in ${LANES_B64:-2 4 8}; do b b64_lanes$n env UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 64; done

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # UMGEN_LIB_PATH selects an alternative build of the SAME library (kernel experiments with extra -D flags); never a fallback
 LIB_PATH = os.environ.get("UMGEN_LIB_PATH") or os.path.join(HERE, "libumgen_hip.so")
-SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "decode_batched.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "vqdec.hip", "debug_api.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "oar_engine_ms.hip", "decode_batched.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "vqdec.hip", "debug_api.hip"]
 EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen_rollout", "umgen_frame",
            "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",
            "umgen_tokenize_ego", "umgen_detokenize_ego", "umgen_tokenize_boxes", "umgen_detokenize_boxes",
@@ -77,7 +77,7 @@ def source_hash() -> str:
     """sha256 over every source the library is built from (and the compile flags): the staleness check of build_library."""
     import hashlib
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, x) for x in ("common.h", "kernels.h", "frame.h")] + \
+    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, x) for x in ("common.h", "kernels.h", "frame.h", "oar_common.h")] + \
         [os.path.join(os.path.dirname(HERE), "include", "umgen.h")]
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -105,7 +105,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     from concurrent.futures import ThreadPoolExecutor
     objdir = os.path.join(CSRC, ".obj")
     os.makedirs(objdir, exist_ok=True)
-    hdr = b"".join(open(os.path.join(CSRC, x), "rb").read() for x in ("common.h", "kernels.h", "frame.h")) + \
+    hdr = b"".join(open(os.path.join(CSRC, x), "rb").read() for x in ("common.h", "kernels.h", "frame.h", "oar_common.h")) + \
         open(os.path.join(os.path.dirname(HERE), "include", "umgen.h"), "rb").read()
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
 

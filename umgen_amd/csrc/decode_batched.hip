@@ -33,17 +33,13 @@ __device__ inline void split8(const float (&v)[8], typename Mma16<TT>::vec& hi, 
     }
 }
 
-constexpr int kRowsThreads = 512, kRowsWaves = 8, kRowsMaxNB = 4;
+constexpr int kRowsThreads = 512, kRowsWaves = 8;
 
-// FRAGMENT-MAJOR activations.  A wave's B operand of k-step s and column block nb is "lane l: the 8 values k = 32 s + 8 (l / 16) .. + 7
-// of scene 16 nb + l % 16".  Out of row-major [scene][K] rows that is 64 scattered 32-byte pieces per request, and the launches were
-// bound by exactly that gather (every workgroup re-reads all M x K activations: 1.4 TB/s out of the L2 at 64 scenes).  The batched
-// layer therefore keeps its activations in the order the matrix cores consume them: [k-step][4 column blocks][64 lanes][8] floats, so a
-// request is 2 KB contiguous.  Producers scatter single elements into it (their volume is tiny), consumers stream it.
-__host__ __device__ inline long frag_index(int m, int k) {
-    return ((((long)(k >> 5) * kRowsMaxNB + (m >> 4)) * 64 + ((k & 31) >> 3) * 16 + (m & 15)) << 3) + (k & 7);
-}
-
+// FRAGMENT-MAJOR activations (frag_index, kernels.h).  A wave's B operand of k-step s and column block nb is "lane l: the 8 values
+// k = 32 s + 8 (l / 16) .. + 7 of scene 16 nb + l % 16".  Out of row-major [scene][K] rows that is 64 scattered 32-byte pieces per
+// request, and the launches were bound by exactly that gather (every workgroup re-reads all M x K activations: 1.4 TB/s out of the L2
+// at 64 scenes).  The batched launches therefore keep their activations in the order the matrix cores consume them, so a request is
+// 2 KB contiguous.  Producers scatter single elements into it (their volume is tiny), consumers stream it.
 __global__ void rows_to_frag_kernel(const float* __restrict__ x, long ldx, int M, int K, float* __restrict__ xf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M * K) xf[frag_index(i / K, i % K)] = x[(long)(i / K) * ldx + i % K];

@@ -135,6 +135,13 @@ struct umgen_engine {
     std::vector<void*> eng_wf2;             // per BlockOAR: c_fc as matrix-core fragments (UMGEN_ENG_MFMA & 4)
     unsigned long long* eng_stamps = nullptr;   // UMGEN_DEBUG_TIMING: per-phase ticks of the engine (printed at destroy)
     size_t eng_gloc_bytes = 0;
+    // Multi-scene decode engine (oar_engine_ms.hip): from `ms_min` scenes per call on, a work item is (block of ceil(B / 8) scenes, layer) with the
+    // scenes as (hi, lo) column pairs of the matrix-core instruction (UMGEN_DECODE_MS=n moves the threshold; 0 = never)
+    unsigned long long* eng_gloc_ms = nullptr;
+    unsigned long long* eng_stamps_ms = nullptr;
+    size_t eng_gloc_ms_bytes = 0;
+    int ms_min = 16;
+    bool use_ms(int B) const { return eng_enabled && tsz == 2 && ms_min > 0 && B >= ms_min && B <= kEngMsMaxBatch && E == kEngE; }
     int fg_xcds = 8;
     unsigned eng_epoch = 16u;             // first hand-off tag of the next frame (see run_frame)
     int step_graph_NG = -1;
@@ -150,7 +157,7 @@ struct umgen_engine {
     int batched_min = 24;               // measured crossover with the engine (profiles/r04_lanes_sweep.txt): 20 scenes 1546 (engine) vs 1674 us per step, 24: 1843 vs 1708, 28: 2104 vs 1775
     float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;   // fragment-major x / attention output [64 E], gelu(c_fc) [64 x 4E] of the batched layer
     bool use_batched(int B) const {      // (in_lanes: a lane's sub-batch of a batch that qualified)
-        return tsz == 2 && (in_lanes || (batched_min > 0 && B >= batched_min)) && B <= kRowsMaxM && E % 32 == 0 && E <= 768;
+        return tsz == 2 && !use_ms(B) && (in_lanes || (batched_min > 0 && B >= batched_min)) && B <= kRowsMaxM && E % 32 == 0 && E <= 768;
     }
     // Decode LANES: the scenes of a batch are independent until the frame is complete (own K/V rows, own sampler state, own RNG
     // stream), and a batched layer launch for <= 16 scenes is latency-bound (5 dependent launches per layer, 48 - 96 workgroups each,
@@ -551,6 +558,22 @@ int oar_layers(umgen_engine* e, int B, int ns) {
             return 0;
         }
     }
+    if (const umgen_engine::EngStream* es = (sizeof(T) == 2 && e->use_ms(B)) ? e->eng_for(e->stream) : nullptr) {
+        OarMsArgs a{};
+        a.layers = e->d_layers; a.n_layers = (int)e->oar.size();
+        a.kvcache = reinterpret_cast<bf16_t*>(e->kvcache); a.kv_layer_stride = e->kv_layer_stride; a.kv_scene_stride = e->kv_scene_stride; a.Lmax = e->Lmax;
+        a.xdec = e->xdec; a.xfrag = e->xfrag; a.st = e->d_state; a.gx = e->eng_gx; a.gloc = e->eng_gloc_ms; a.ticket = e->eng_ticket; a.err = e->eng_err;
+        a.B = B; a.NG = es->NG;
+        a.ns = (B + 7) / 8;                      // at most 8 blocks: (35 + blocks) item slots per step
+        if (const char* fs = getenv("UMGEN_MS_SCENES")) a.ns = std::max(1, std::min(kEngMsScenes, atoi(fs)));   // measurement knob
+        a.nb = (B + a.ns - 1) / a.ns;
+        if ((unsigned)(a.nb * 64 * 8) > kEpochPerStep) return e->fail(UMGEN_E_UNSUPPORTED, "decode engine: %d blocks need more hand-off tags than one step has", a.nb);
+        memcpy(a.xcc_group, es->map, 16);
+        a.stamps = e->eng_stamps_ms;
+        a.fp16 = std::is_same<T, f16_t>::value ? 1 : 0;
+        HIPCHK(e, launch_oar_engine_ms(e->stream, a));
+        return 0;
+    }
     if (const umgen_engine::EngStream* es = sizeof(T) == 2 ? e->eng_for(e->stream) : nullptr) {
         OarEngineArgs a{};
         a.layers = e->d_layers; a.n_layers = (int)e->oar.size();
@@ -748,7 +771,7 @@ int enqueue_step(umgen_engine* e, int B, int mod, int ns, const umgen_trace* tr,
         const int V = mod == 1 ? e->cfg.map_vocab : (mod == 2 ? e->cfg.bbox3d_vocab : e->cfg.img_vocab);
         bool head_done = false;
         if constexpr (sizeof(T) == 2) {
-            if (e->use_batched(B)) {
+            if (e->use_batched(B) || (e->use_ms(B) && e->eng_for(e->stream))) {
                 RowsArgs r{};
                 r.x = e->xfrag; r.M = B; r.ln_w = e->ln_oar; r.W = head; r.N = V; r.K = E; r.mode = ROWS_F32; r.out = e->logits; r.ldo = sa.ld_logits; r.E = E;   // (xfrag: the last layer's copy of x)
                 launch_rows_mfma<T>(e->stream, r);
@@ -935,6 +958,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         HIPCHK(e, hipDeviceSynchronize());
         HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
         HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
+        HIPCHK(e, hipMemset(e->eng_gloc_ms, 0, e->eng_gloc_ms_bytes));
         e->eng_epoch = 16u;
     }
     OarState s0{j_begin, io.frame_idx, forced ? 1 : 0, io.control_slot ? 1 : 0, 0, e->eng_epoch, sp};
@@ -1174,7 +1198,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     }
     hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->tm.total_ms += ms;
     e->tm.frames += 1;
-    e->tm.decode_engine = eng ? 1 : 0;
+    e->tm.decode_engine = eng ? (e->use_ms(B) ? 2 : 1) : 0;      // 2: the multi-scene engine (oar_engine_ms.hip)
     e->tm.decode_batched = batched ? 1 : 0;
     e->tm.decode_lanes = batched ? n_lanes : 0;
     e->tm.engine_fallback = e->eng_fallback ? 1 : 0;
@@ -1390,6 +1414,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         // falls back to the five-launch decode layer WITH the overlapped TAR pass, and says so.
         HIPCHK(e, hipStreamCreate(&e->stream));
         HIPCHK(e, oar_engine_prepare());
+        HIPCHK(e, oar_engine_ms_prepare());
         unsigned* d_cnt = nullptr;
         HIPCHK(e, hipMalloc(&d_cnt, 64));
         umgen_engine::EngStream& es = e->eng_fg;
@@ -1684,6 +1709,18 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         HIPCHK(e, hipMemset(e->eng_gx, 0, Bm * kEngE * 8));
         HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
         HIPCHK(e, hipMemset(e->eng_err, 0, 16));
+        if (const char* mm = getenv("UMGEN_DECODE_MS")) e->ms_min = atoi(mm);
+        if (e->tsz == 2 && Bm >= 1 && e->ms_min > 0 && (int)Bm >= std::min(e->ms_min, kEngMsMaxBatch)) {
+            e->eng_gloc_ms_bytes = (size_t)16 * kEngMsLocStride * 8;
+            if (int rc = dev_alloc(e, reinterpret_cast<void**>(&e->eng_gloc_ms), e->eng_gloc_ms_bytes)) return rc;
+            HIPCHK(e, hipMemset(e->eng_gloc_ms, 0, e->eng_gloc_ms_bytes));
+            if (getenv("UMGEN_DEBUG_TIMING")) {
+                if (int rc = dalloc(e, &e->eng_stamps_ms, (size_t)16)) return rc;
+                HIPCHK(e, hipMemset(e->eng_stamps_ms, 0, 128));
+            }
+        } else {
+            e->ms_min = 0;
+        }
         if (getenv("UMGEN_DEBUG_TIMING")) fprintf(stderr, "[umgen] decode engine: on (8 XCD groups)\n");
     }
     return UMGEN_OK;
@@ -2004,6 +2041,7 @@ int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in,
         HIPCHK(e, hipDeviceSynchronize());
         HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
         HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
+        HIPCHK(e, hipMemset(e->eng_gloc_ms, 0, e->eng_gloc_ms_bytes));
         e->eng_epoch = 16u;
     }
     const unsigned epoch = e->eng_epoch;   // tags never repeat across calls
@@ -2014,11 +2052,19 @@ int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in,
     HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->xdec, x_in, (size_t)B * e->E * 4, hipMemcpyHostToDevice, st));
     const bool en = e->eng_enabled;
+    const int ms_keep = e->ms_min;
     e->eng_enabled = en && use_engine;
+    if (use_engine == 2) {      // the multi-scene engine whatever B is
+        if (!e->eng_gloc_ms) return e->fail(UMGEN_E_UNSUPPORTED, "multi-scene decode engine not available on this engine");
+        e->ms_min = 1;
+    } else {
+        e->ms_min = 0;
+    }
     e->stream = st;
     const int lrc = e->cfg.precision == UMGEN_PREC_FP16 ? oar_layers<f16_t>(e, B, attn_nsplit(L + 1)) : oar_layers<bf16_t>(e, B, attn_nsplit(L + 1));
     e->stream = keep;
     e->eng_enabled = en;
+    e->ms_min = ms_keep;
     if (lrc) return lrc;
     HIPCHK(e, hipMemcpyAsync(x_out, e->xdec, (size_t)B * e->E * 4, hipMemcpyDeviceToHost, st));
     unsigned eng_err = 0;
@@ -2035,6 +2081,16 @@ int umgen_destroy(umgen_engine* e) {
     if (!e) return UMGEN_OK;
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();   // every stream of this engine (decode, background, side, unmasked) is idle before anything is freed
+    if (e->eng_stamps_ms) {
+        unsigned long long st[16];
+        if (hipMemcpy(st, e->eng_stamps_ms, 128, hipMemcpyDeviceToHost) == hipSuccess && st[15]) {
+            const char* nm[11] = {"wait x", "LN + qkv rows", "wait qkv", "attention", "wait att", "c_proj", "wait x'", "LN + c_fc + GELU", "mlp partial sums", "wait partial sums", "add partials"};
+            fprintf(stderr, "[umgen] multi-scene decode engine, group 0 rank 0, us per item over %llu items:", st[15]);
+            double tot = 0;
+            for (int p = 0; p < 11; ++p) { fprintf(stderr, " %s %.2f", nm[p], (double)st[p] / 100.0 / (double)st[15]); tot += (double)st[p] / 100.0 / (double)st[15]; }
+            fprintf(stderr, " | total %.2f\n", tot);
+        }
+    }
     if (e->eng_stamps) {
         unsigned long long st[16];
         if (hipMemcpy(st, e->eng_stamps, 128, hipMemcpyDeviceToHost) == hipSuccess && st[10]) {

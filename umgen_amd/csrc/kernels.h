@@ -118,6 +118,12 @@ enum RowsMode {
     ROWS_RESID = 3   // out[m*ldo + n] += v
 };
 constexpr int kRowsMaxM = 64;      // scenes per rows_mfma launch (4 column blocks of 16)
+constexpr int kRowsMaxNB = 4;
+// FRAGMENT-MAJOR activations of the batched launches: [k-step][4 column blocks][64 lanes][8] floats -- the order the matrix cores consume
+// them in (a wave's B operand of k-step s and column block nb is 2 KB contiguous); decode_batched.hip
+__host__ __device__ inline long frag_index(int m, int k) {
+    return ((((long)(k >> 5) * kRowsMaxNB + (m >> 4)) * 64 + ((k & 31) >> 3) * 16 + (m & 15)) << 3) + (k & 7);
+}
 struct RowsArgs {
     const float* x; int M;             // fp32 activations of the M <= kRowsMaxM scenes, FRAGMENT-MAJOR (decode_batched.hip: frag_index; 64 K floats)
     const float* ln_w;                 // ROWS_QKV / _GELU / _F32: LayerNorm (weight only) of every scene's K values first (K <= 768)
@@ -171,6 +177,32 @@ struct OarEngineArgs {
     int fp16;                                  // 0: weights and K/V cache hold bfloat16 bits, 1: IEEE half (UMGEN_PREC_FP16)
     int systolic;                              // 1: layer-resident groups, the scenes flow through all NG groups (R, D unused); B * 64 * 8 tags
 };
+// ------------------------------------------------------------------------------------------------
+// multi-scene XCD-resident decode engine (oar_engine_ms.hip): work item = (block of <= 8 scenes, layer), the scenes as (hi, lo) column
+// pairs of the matrix-core instruction; same groups / tickets / epoch tags as the one-scene engine
+// ------------------------------------------------------------------------------------------------
+constexpr int kEngMsScenes = 8;                // scenes per work item (16 MFMA columns)
+constexpr int kEngMsMaxBatch = 64;             // 8 blocks of 8 scenes
+constexpr int kEngMsLocStride = kEngMsScenes * (3 * kEngE + kEngE + kEngE) + kEngGroup * kEngMsScenes * kEngE;   // granules per group: q|k|v, attention out, x' [8][..], mlp partial sums [32][8][768]
+struct OarMsArgs {
+    const OarLayerDev* layers; int n_layers;
+    bf16_t* kvcache; long kv_layer_stride, kv_scene_stride; int Lmax;   // [layer][scene][2][H][Lmax][48]
+    float* xdec;                               // [B][E]: in = input of layer 0, out = output of the last layer
+    float* xfrag;                              // nullable: the last layer's x once more, fragment-major (frag_index) for the head launch
+    const OarState* st;
+    unsigned long long* gx;                    // [max_batch][E] cross-group x granules (shared with the one-scene engine)
+    unsigned long long* gloc;                  // [NG][kEngMsLocStride] group-private granules
+    unsigned int* ticket;
+    unsigned int* err;
+    int B, NG, ns, nb;                         // scenes; groups; scenes per block; blocks (ns * nb >= B, nb <= 32: tag budget)
+    unsigned char xcc_group[16];
+    unsigned long long* stamps;                // optional [16]
+    int fp16;
+};
+size_t oar_engine_ms_lds_bytes();
+hipError_t oar_engine_ms_prepare();
+hipError_t launch_oar_engine_ms(hipStream_t s, const OarMsArgs& a);
+
 size_t oar_engine_lds_bytes();
 hipError_t oar_engine_prepare();                // per device, before the first launch / census (dynamic-LDS attribute)
 hipError_t launch_oar_engine(hipStream_t s, const OarEngineArgs& a);

@@ -55,6 +55,24 @@ static_assert(M_TOTAL * 4 <= 160 * 1024, "LDS budget");
 // slot; while something is missing a lane asks for ONE of its missing granules per round with a short sleep in between (the gathers
 // of this engine are up to 12 granules per thread and 32 CUs: polling all of them would put 1.5 MB per round on the L2 / the fabric
 // while a group waits for its predecessor), then requests all its missing slots again.
+// Granule i of a WAVE-UNIFORM base as `saddr + 32-bit byte offset`: one VGPR of address per request in flight (a gather of this engine keeps
+// 12 requests per lane in flight; as 64-bit flat pointers -- what the compiler makes of an agent-scope atomic load -- their addresses alone
+// were 24 VGPRs and pushed 12 of the resident c_fc fragments out to scratch memory).  Written as inline assembly, so the requests are
+// invisible to the compiler's wait-count bookkeeping: poll_wait() is the explicit s_waitcnt every consumer goes through (a wave's loads
+// return in order: vmcnt(0) is exactly what waiting for the youngest request means).
+__device__ inline void poll_issue(u64& v, const u64* g, u32 i) {
+    asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(v) : "v"(i << 3), "s"(g) : "memory");
+}
+template <int PER>
+__device__ inline void poll_wait(u64 (&v)[PER]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < PER; ++k) asm volatile("" : "+v"(v[k]));     // (the values are defined behind the wait, not behind the request)
+}
+// slot k of thread tid (bit k of need) waits for granule idx(k) with `tag` and hands its value to sink(k, value).  Round 1 requests every
+// slot; while something is missing a lane asks for ONE of its missing granules per round with a short sleep in between (the gathers
+// of this engine are up to 12 granules per thread and 32 CUs: polling all of them would put 1.5 MB per round on the L2 / the fabric
+// while a group waits for its predecessor), then requests all its missing slots again.
 template <int PER, typename IDX, typename SINK>
 __device__ inline void poll_ms(Ctx& c, int tid, const u64* g, u32 need, IDX idx, u32 tag, SINK sink) {
     if (c.failed || !__any(need != 0u)) return;
@@ -62,20 +80,21 @@ __device__ inline void poll_ms(Ctx& c, int tid, const u64* g, u32 need, IDX idx,
     for (u32 spins = 0;;) {
         u64 v[PER];
 #pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if (((need & ~got) >> k) & 1u) v[k] = get(g, idx(k));
+        for (int k = 0; k < PER; ++k) poll_issue(v[k], g, idx(k));      // (unconditional: slots that are not needed re-read a valid index)
+        poll_wait<PER>(v);
 #pragma unroll
         for (int k = 0; k < PER; ++k)
             if ((((need & ~got) >> k) & 1u) && (u32)(v[k] >> 32) == tag) { sink(k, __uint_as_float((u32)v[k])); got |= 1u << k; }
         if (!__any(got != need)) break;
-        // one missing granule per lane until it is there (lanes that have everything idle)
+        // one missing granule per lane until it is there (lanes that have everything re-read a slot of theirs)
         const u32 miss = need & ~got;
-        const int k1 = miss ? __ffs((int)miss) - 1 : 0;
-        const u32 i1 = idx(k1);
+        const u32 i1 = idx(miss ? __ffs((int)miss) - 1 : 0);
         for (;;) {
             __builtin_amdgcn_s_sleep(2);
-            const u64 v1 = miss ? get(g, i1) : ((u64)tag << 32);
-            if (!__any((u32)(v1 >> 32) != tag)) break;
+            u64 v1[1];
+            poll_issue(v1[0], g, i1);
+            poll_wait<1>(v1);
+            if (!__any(miss != 0u && (u32)(v1[0] >> 32) != tag)) break;
             if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, tag | 0x80000000u); c.failed = true; break; }
             if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
         }
@@ -177,7 +196,13 @@ __device__ inline void att_fold_swap(AttState& a) {      // with the neighbourin
     sw(a.m, x.m, y.m);
     sw(a.l, x.l, y.l);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { sw(a.o[j].x, x.o[j].x, y.o[j].x); sw(a.o[j].y, x.o[j].y, y.o[j].y); }
+    for (int j = 0; j < 6; ++j) {
+        float x0, y0, x1, y1;
+        sw(a.o[j].x, x0, y0);
+        sw(a.o[j].y, x1, y1);
+        x.o[j] = f32x2_t{x0, x1};
+        y.o[j] = f32x2_t{y0, y1};
+    }
     att_merge(x, y.m, y.l, y.o);
     a = x;
 }
@@ -229,7 +254,6 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
         }
     }
     const int n_items = n_full * nb + (ts1 - ts0);
-    WFrags<2> fo;            // c_proj: this CU's 24 rows as 2 tiles x this wave's 3 k-steps          (resident over the blocks of a layer)
     WFrags<6> ff;            // c_fc: this CU's 96 rows as 6 tiles                                      (resident)
     WFrags<5> fq;            // q|k|v: this CU's 72 rows as 5 tiles                                     (requested by every item: out of the L2 after the layer's first block)
     float xres2 = 0.f;       // x' of (scene tid / 24, row 24 w + tid % 24): the mlp projection's residual
@@ -268,11 +292,6 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
 #pragma unroll
         for (int it = 0; it < 2; ++it) { const int o = tid + it * NT; bq[it] = o < 72 * ns ? ldg(lw.bqkv + 72 * w + o % 72) : 0.f; }
         if (tid < 24 * ns) bo = ldg(lw.bo + 24 * w + tid % 24);
-        float x_first[12];
-        if (l == 0) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) { const int f = tid + k * NT; x_first[k] = f < ns * E ? ldg(a.xdec + (long)s0 * E + f) : 0.f; }
-        }
         if (load_w) {
             // layer switch (once per layer and step): the parked mlp fragments through 6 staging registers at a time, in front of everything else
 #pragma unroll
@@ -285,19 +304,16 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
             }
         }
         req_frags<5, true>(fq, lw.Wqkv, 72 * w, 72, wave, lane);
-        if (load_w) {
-            req_frags<2, false>(fo, lw.Wo, 24 * w, 24, wave, lane);
-            req_frags_packed<6, false>(ff, lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8, lane);
-        }
+        if (load_w) req_frags_packed<6, false>(ff, lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8, lane);
         stamp(-1);
         // ================= P1: x -> LN -> q | k | v of the block's scenes =================
         if (load_w) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) lds[M_LN + tid + k * NT] = lnr[k];
         }
-        if (l == 0) {
+        if (l == 0) {      // (the sampler's / the first-input kernel's rows: plain loads, once per block and step)
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int f = tid + k * NT; if (f < ns * E) lds[M_XS + (f / E) * XST + f % E] = x_first[k]; }
+            for (int k = 0; k < 12; ++k) { const int f = tid + k * NT; if (f < ns * E) lds[M_XS + (f / E) * XST + f % E] = ldg(a.xdec + (long)s0 * E + f); }
         } else {
             u32 need = 0;
 #pragma unroll
@@ -485,7 +501,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
             wg_barrier();
         }
         stamp(4);   // waited for the attention outputs
-        u32x4_t wpl[6];                          // fragments 12..17 of the mlp c_proj slice (requested now: the attention has freed its registers)
+        // c_proj: this CU's 24 rows as 2 tiles x this wave's 3 k-steps, and fragments 12..17 of the mlp c_proj slice: requested by every item
+        // once the attention has freed its registers (1.2 MB each per item and group, out of the L2 / the Infinity Cache after the layer's
+        // first block; resident they cost 48 VGPRs through the key loop -- the register file holds ff and the LDS the other 12 fragments)
+        WFrags<2> fo;
+        req_frags<2, true>(fo, lw.Wo, 24 * w, 24, wave, lane);
+        u32x4_t wpl[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) wpl[j] = ldwk(wp2 + (long)(12 + j) * NT * 8, (u32)tid * 8u);
         {
