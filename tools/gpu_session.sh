@@ -67,6 +67,11 @@ ms)   # the multi-scene decode engine (oar_engine_ms.hip) at MS_B scenes per GPU
     b ms_b$n env UMGEN_DEBUG_TIMING=1 ${MS_ENV} python bench.py --steps ${MS_STEPS:-1} --warmup 1 --no-cpu-baseline --batch $n
     echo "--- $n scenes ${MS_ENV}" >> gpurun_out/${R}_ms_stamps.txt; grep "multi-scene decode engine" gpurun_out/${R}_bench_ms_b$n.err | tail -1 >> gpurun_out/${R}_ms_stamps.txt
   done; cat gpurun_out/${R}_ms_stamps.txt | cut -c1-400 ;;
+msvar)  # measurement builds of the multi-scene engine (MS_VARIANTS="nb2 ..." -> umgen_amd/libumgen_hip_<v>.so) at MS_B scenes, stamps of an item
+  for v in ${MS_VARIANTS}; do for n in ${MS_B:-64}; do
+    b msvar_${v}_b$n env UMGEN_DEBUG_TIMING=1 UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_$v.so ${MS_ENV} python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch $n
+    grep "multi-scene decode engine" gpurun_out/${R}_bench_msvar_${v}_b$n.err | tail -1 | cut -c1-400
+  done; done ;;
 msab)  # the same batch on the multi-scene engine, the one-scene engine and the batched layer + lanes (round 4's path)
   for n in ${MS_B:-16 32 64}; do
     b ms_b$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch $n

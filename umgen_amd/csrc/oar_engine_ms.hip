@@ -27,7 +27,14 @@ namespace umgen {
 namespace {
 
 #ifndef UMGEN_MS_NB
-#define UMGEN_MS_NB 4            // 16-key passes of a wave in flight (12 VGPRs each for K, 12 for V)
+#define UMGEN_MS_NB 2            // 16-key passes of a wave in flight (12 VGPRs each for K, 12 for V).  The key loop is bound by the XCD's memory link (0.67 TB/s
+                                 // with 2, 3, 4 or 6 passes in flight, profiles/r05_ms_experiments.txt); 4 spill 32 VGPRs, 2 none
+#endif
+#ifndef UMGEN_MS_POLL_ALL_X
+#define UMGEN_MS_POLL_ALL_X false      // re-request every missing x granule every round while the group waits for its predecessor (cross-XCD)
+#endif
+#ifndef UMGEN_MS_POLL_ALL_ATT
+#define UMGEN_MS_POLL_ALL_ATT false    // ... every missing attention output while other CUs of the group still stream K/V through the same L2
 #endif
 constexpr int MS = kEngMsScenes;  // scenes per work item (16 matrix-core columns = 8 x (hi, lo))
 constexpr int XST = E + 4;        // scene stride (dwords) of the activation buffer: 772 = 4 mod 32 banks, the 32 (scene, k-group) chunks of a B-fragment read spread over all banks
@@ -73,7 +80,9 @@ __device__ inline void poll_wait(u64 (&v)[PER]) {
 // slot; while something is missing a lane asks for ONE of its missing granules per round with a short sleep in between (the gathers
 // of this engine are up to 12 granules per thread and 32 CUs: polling all of them would put 1.5 MB per round on the L2 / the fabric
 // while a group waits for its predecessor), then requests all its missing slots again.
-template <int PER, typename IDX, typename SINK>
+// ALL: every round requests every slot again (one round trip behind the producers; for the hand-offs at which the whole group
+// is waiting anyway -- nobody's K/V stream shares the L2 with the polls).
+template <int PER, bool ALL = false, typename IDX, typename SINK>
 __device__ inline void poll_ms(Ctx& c, int tid, const u64* g, u32 need, IDX idx, u32 tag, SINK sink) {
     if (c.failed || !__any(need != 0u)) return;
     u32 got = 0;
@@ -86,6 +95,11 @@ __device__ inline void poll_ms(Ctx& c, int tid, const u64* g, u32 need, IDX idx,
         for (int k = 0; k < PER; ++k)
             if ((((need & ~got) >> k) & 1u) && (u32)(v[k] >> 32) == tag) { sink(k, __uint_as_float((u32)v[k])); got |= 1u << k; }
         if (!__any(got != need)) break;
+        if (ALL) {
+            if (++spins > kSpinLimit / 8) { if ((tid & 63) == 0) atomicExch(c.err, tag | 0x80000000u); c.failed = true; break; }
+            if ((spins & 63u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
+            continue;
+        }
         // one missing granule per lane until it is there (lanes that have everything re-read a slot of theirs)
         const u32 miss = need & ~got;
         const u32 i1 = idx(miss ? __ffs((int)miss) - 1 : 0);
@@ -254,14 +268,20 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
         }
     }
     const int n_items = n_full * nb + (ts1 - ts0);
-    WFrags<6> ff;            // c_fc: this CU's 96 rows as 6 tiles                                      (resident)
+    WFrags<4> ff;            // c_fc: tiles 0..3 of this CU's 96 rows (6 tiles)                         (resident over the blocks of a layer; tiles 4, 5 per item)
     WFrags<5> fq;            // q|k|v: this CU's 72 rows as 5 tiles                                     (requested by every item: out of the L2 after the layer's first block)
     float xres2 = 0.f;       // x' of (scene tid / 24, row 24 w + tid % 24): the mlp projection's residual
-    for (int item = 0; item < n_items; ++item) {
+    // (block, layer) of this group's item number `item`
+    auto sched = [&](int item, int& blk, int& l, bool& load_w) {
         const bool tail = item >= n_full * nb;
-        const int blk = tail ? ts0 + item - n_full * nb : item % nb;
-        const int l = tail ? tail_l : q + D * (item / nb);
-        const bool load_w = blk == (tail ? ts0 : 0);          // this item requests the layer's resident weights
+        blk = tail ? ts0 + item - n_full * nb : item % nb;
+        l = tail ? tail_l : q + D * (item / nb);
+        load_w = blk == (tail ? ts0 : 0);          // this item requests the layer's resident weights
+    };
+    for (int item = 0; item < n_items; ++item) {
+        int blk, l;
+        bool load_w;
+        sched(item, blk, l, load_w);
         const int s0 = blk * a.ns;
         const int ns = min(a.ns, a.B - s0);
         if (ns <= 0) continue;
@@ -304,7 +324,8 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
             }
         }
         req_frags<5, true>(fq, lw.Wqkv, 72 * w, 72, wave, lane);
-        if (load_w) req_frags_packed<6, false>(ff, lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8, lane);
+        const bf16_t* pf = lw.Wf2 + (long)(w * NW + wave) * 18 * 64 * 8;
+        if (load_w) req_frags_packed<4, false>(ff, pf, lane);
         stamp(-1);
         // ================= P1: x -> LN -> q | k | v of the block's scenes =================
         if (load_w) {
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
             u32 need = 0;
 #pragma unroll
             for (int k = 0; k < 12; ++k) if (tid + k * NT < ns * E) need |= 1u << k;
-            poll_ms<12>(c, tid, a.gx + (long)s0 * E, need, [&](int k) { return (u32)min(tid + k * NT, ns * E - 1); }, tg + 0,
+            poll_ms<12, UMGEN_MS_POLL_ALL_X>(c, tid, a.gx + (long)s0 * E, need, [&](int k) { return (u32)min(tid + k * NT, ns * E - 1); }, tg + 0,
                         [&](int k, float v) { const int f = tid + k * NT; lds[M_XS + (f / E) * XST + f % E] = v; });
         }
         wg_barrier();
@@ -371,7 +392,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
                     const int pi = f / 144, e = f - 144 * pi, p = w + 32 * pi;
                     return (u32)((p >> 4) * 3 * E + (e / kHeadDim) * E + (p & 15) * kHeadDim + e % kHeadDim);
                 };
-                poll_ms<2>(c, tid, gqkv, need, src, tg + 1, [&](int k, float v) { const int f = tid + k * NT; qs[(f / 144) * QST + f % 144] = v; });
+                poll_ms<2, true>(c, tid, gqkv, need, src, tg + 1, [&](int k, float v) { const int f = tid + k * NT; qs[(f / 144) * QST + f % 144] = v; });
                 wg_barrier();
             }
             stamp(2);   // waited for the pairs' q_h | k_h | v_h
@@ -384,27 +405,51 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
             const bf16_t* kv_layer = a.kvcache + (long)l * a.kv_layer_stride + (long)s0 * a.kv_scene_stride;
             constexpr int NB = UMGEN_MS_NB;
             KVPiece kc[NB], vc[NB];
-            // chunk c of the flat (pair, 16-key pass) sequence
+            // Chunk c of the flat (pair, 16-key pass) sequence.  The K/V requests are INLINE ASSEMBLY with hand-counted waits: written as
+            // compiler-visible loads under `if (chunk exists)` the wait-count pass has to assume the shortest path and emitted
+            // s_waitcnt vmcnt(3..0) in front of every chunk -- every pass waited for ALL the requests in flight, the key loop ran at one
+            // memory latency per 16 keys whatever UMGEN_MS_NB was (profiles/r05_ms_nb_sweep.txt: 10.6 us per pair for NB = 2, 3, 4, 6).
+            // Here every slot of the ring ALWAYS issues its four requests (slots past the end of the sequence re-request the last
+            // chunk: cache hits), so exactly 4 (NB - 1) requests are younger than the oldest buffer's and `s_waitcnt vmcnt(4 (NB - 1))`
+            // is exact (a wave's loads return in order; the one granule store wave 0 has in flight can only make the wait longer).
             int rq_pi = 0, rq_ci = 0;
-            auto kv_req = [&](int buf) {
+            auto kv_req = [&](KVPiece& kq, KVPiece& vq) {
                 const int p = w + 32 * rq_pi;
                 const bf16_t* kbase = kv_layer + (long)(p >> 4) * a.kv_scene_stride + (long)(p & 15) * a.Lmax * kHeadDim;
                 const bf16_t* vbase = kbase + (long)H * a.Lmax * kHeadDim;
-                const u32 off = (u32)min(k_lo + KPW * rq_ci + kg, a.Lmax - 1) * (u32)kHeadDim;
-                kc[buf].a = ldwu(kbase, off + (u32)piece * 8u);
-                kc[buf].b = ldwu2(kbase, off + 32u + (u32)piece * 4u);
-                vc[buf].a = ldwu(vbase, off + (u32)piece * 8u);
-                vc[buf].b = ldwu2(vbase, off + 32u + (u32)piece * 4u);
-                if (++rq_ci == nch) { rq_ci = 0; ++rq_pi; }
+                const u32 off = ((u32)min(k_lo + KPW * rq_ci + kg, a.Lmax - 1) * (u32)kHeadDim + (u32)piece * 8u) * 2u;      // bytes
+                const u32 off2 = ((u32)min(k_lo + KPW * rq_ci + kg, a.Lmax - 1) * (u32)kHeadDim + 32u + (u32)piece * 4u) * 2u;
+#ifdef UMGEN_MS_EXP_NOLOAD      // measurement builds only (tools/build_variant.sh): the key loop without its K/V requests / without its arithmetic
+                kq.a = u32x4_t{off, off2, off, off2}; kq.b = u32x2_t{off, off2}; vq.a = kq.a; vq.b = kq.b;
+                if (rq_pi * nch + rq_ci + 1 < total) { if (++rq_ci == nch) { rq_ci = 0; ++rq_pi; } }
+                return;
+#endif
+                asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(kq.a) : "v"(off), "s"(kbase));
+                asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(kq.b) : "v"(off2), "s"(kbase));
+                asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(vq.a) : "v"(off), "s"(vbase));
+                asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(vq.b) : "v"(off2), "s"(vbase));
+                if (rq_pi * nch + rq_ci + 1 < total) { if (++rq_ci == nch) { rq_ci = 0; ++rq_pi; } }     // (stays on the last chunk behind the end)
             };
+            auto kv_wait = [&](KVPiece& kq, KVPiece& vq) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 1)));
+                asm volatile("" : "+v"(kq.a), "+v"(kq.b), "+v"(vq.a), "+v"(vq.b));     // (defined behind the wait, not behind the request)
+            };
+            if (total > 0) {
 #pragma unroll
-            for (int bfr = 0; bfr < NB; ++bfr)
-                if (bfr < total) kv_req(bfr);
+                for (int bfr = 0; bfr < NB; ++bfr) kv_req(kc[bfr], vc[bfr]);
+            }
             int pi = 0, ci = 0;
             AttState st;
             f32x2_t q2[6];
             auto chunk = [&](const KVPiece& kcb, const KVPiece& vcb) {
                 const float* qp = qs + pi * QST;
+#ifdef UMGEN_MS_EXP_NOMATH
+                if (ci == 0) { st.m = 0.f; st.l = 1.f;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { st.o[j] = f32x2_t{0.f, 0.f}; q2[j] = st.o[j]; } }
+                st.o[0].x += __uint_as_float((kcb.a.x ^ kcb.a.y ^ kcb.a.z ^ kcb.a.w ^ kcb.b.x ^ kcb.b.y ^ vcb.a.x ^ vcb.a.y ^ vcb.a.z ^ vcb.a.w ^ vcb.b.x ^ vcb.b.y) & 0x3f800000u);
+                return;
+#endif
                 if (ci == 0) {
                     st.m = -INFINITY; st.l = 0.f;
 #pragma unroll
@@ -451,8 +496,9 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
 #pragma unroll
                 for (int bfr = 0; bfr < NB; ++bfr) {
                     if (c0 + bfr < total) {
+                        kv_wait(kc[bfr], vc[bfr]);
                         chunk(kc[bfr], vc[bfr]);
-                        if (c0 + bfr + NB < total) kv_req(bfr);
+                        kv_req(kc[bfr], vc[bfr]);
                         if (++ci == nch) {
                             // the pair is complete: the wave's 16 lane groups fold to one (same dimensions: lanes l, l + 4, l + 8, l + 12 of a
                             // 16-lane row, then the four rows), the 8 waves' partials meet in LDS and 48 threads merge them in wave order
@@ -488,27 +534,34 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
                     }
                 }
             }
+            if (total > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the ring's last, unused requests: their registers are free again)
             wg_barrier();     // (the activation buffer is rewritten by P3's gather: the last pair's merge must be through with its scratch)
         }
         stamp(3);   // attention of this CU's pairs
-        // ================= P3: attention outputs -> c_proj -> x' =================
-        {
-            u32 need = 0;
-#pragma unroll
-            for (int k = 0; k < 12; ++k) if (tid + k * NT < ns * E) need |= 1u << k;
-            poll_ms<12>(c, tid, gatt, need, [&](int k) { return (u32)min(tid + k * NT, ns * E - 1); }, tg + 2,
-                        [&](int k, float v) { const int f = tid + k * NT; ldsu[M_XS + (f / E) * XST + f % E] = pack16<TT>(v); });
-            wg_barrier();
-        }
-        stamp(4);   // waited for the attention outputs
-        // c_proj: this CU's 24 rows as 2 tiles x this wave's 3 k-steps, and fragments 12..17 of the mlp c_proj slice: requested by every item
-        // once the attention has freed its registers (1.2 MB each per item and group, out of the L2 / the Infinity Cache after the layer's
-        // first block; resident they cost 48 VGPRs through the key loop -- the register file holds ff and the LDS the other 12 fragments)
+        // c_proj: this CU's 24 rows as 2 tiles x this wave's 3 k-steps, fragments 12..17 of the mlp c_proj slice and c_fc tiles 4, 5: requested by
+        // every item as soon as the key loop has freed its registers -- they fly while the group waits for the attention outputs (1.2 +
+        // 1.2 + 1.6 MB per item and group, out of the L2 / the Infinity Cache after the layer's first block; resident they would cost
+        // 72 VGPRs through the key loop, and the compiler parked 12 c_fc fragments in scratch memory instead)
         WFrags<2> fo;
         req_frags<2, true>(fo, lw.Wo, 24 * w, 24, wave, lane);
         u32x4_t wpl[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) wpl[j] = ldwk(wp2 + (long)(12 + j) * NT * 8, (u32)tid * 8u);
+        WFrags<2> ffi;           // c_fc tiles 4, 5 (the register file holds four of the six tiles through the key loop)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ffi.f[t][j] = ldwk(pf, (u32)((3 * (4 + t) + j) * 64 + lane) * 8u);
+        // ================= P3: attention outputs -> c_proj -> x' =================
+        {
+            u32 need = 0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) if (tid + k * NT < ns * E) need |= 1u << k;
+            poll_ms<12, UMGEN_MS_POLL_ALL_ATT>(c, tid, gatt, need, [&](int k) { return (u32)min(tid + k * NT, ns * E - 1); }, tg + 2,
+                        [&](int k, float v) { const int f = tid + k * NT; ldsu[M_XS + (f / E) * XST + f % E] = pack16<TT>(v); });
+            wg_barrier();
+        }
+        stamp(4);   // waited for the attention outputs
         {
             typename Mma16<TT>::vec bx[3];
             typedef typename Mma16<TT>::vec vec;
@@ -536,7 +589,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
             u32 need = 0;
 #pragma unroll
             for (int k = 0; k < 12; ++k) if (tid + k * NT < ns * E) need |= 1u << k;
-            poll_ms<12>(c, tid, gxb, need, [&](int k) { return (u32)min(tid + k * NT, ns * E - 1); }, tg + 3,
+            poll_ms<12, true>(c, tid, gxb, need, [&](int k) { return (u32)min(tid + k * NT, ns * E - 1); }, tg + 3,
                         [&](int k, float v) { const int f = tid + k * NT; lds[M_XS + (f / E) * XST + f % E] = v; });
             wg_barrier();
         }
@@ -553,7 +606,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) a3[t] = Mma16<TT>::mfma(__builtin_bit_cast(vec, ff.f[3 * hf + t][j]), bx[j], a3[t]);
+                    for (int t = 0; t < 3; ++t) {
+                        const int tt = 3 * hf + t;
+                        a3[t] = Mma16<TT>::mfma(__builtin_bit_cast(vec, tt < 4 ? ff.f[tt < 4 ? tt : 0][j] : ffi.f[tt < 4 ? 0 : tt - 4][j]), bx[j], a3[t]);
+                    }
 #pragma unroll
                 for (int t = 0; t < 3; ++t) store_tile(lds + M_ST + wave * MS * RS, ns, lane, 3 * hf + t, a3[t]);
             }
@@ -604,7 +660,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_ms_kernel(OarMsArgs a)
             u32 need = 0;
 #pragma unroll
             for (int k = 0; k < 12; ++k) if (((tid + k * NT) / 24) % MS < ns) need |= 1u << k;
-            poll_ms<12>(c, tid, gpy + 24 * w, need,
+            poll_ms<12, true>(c, tid, gpy + 24 * w, need,
                         [&](int k) { const u32 f = (u32)(tid + k * NT); return (f / 192u) * (u32)(MS * E) + ((f / 24u) % (u32)MS) * (u32)E + f % 24u; }, tg + 4,
                         [&](int k, float v) { part[tid + k * NT] = v; });
             wg_barrier();
