@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from umgen_amd.config import MOD_ORDER, SEQ_LEN, large_config, tiny_config, wide2x_config  # noqa: E402
-from umgen_amd.synth import synthetic_control, synthetic_scene  # noqa: E402
+from umgen_amd.synth import synthetic_control, synthetic_given_map, synthetic_scene  # noqa: E402
 from umgen_amd.weights import expected_keys, synth_tensor  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -131,8 +131,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="bf16: BASELINE.json configs[1]; fp16: the same kernels with IEEE-half operands (the reference's autocast dtype)")
     ap.add_argument("--history", type=int, default=20, help="history frames T (configs[4]: 40 = doubled context)")
-    ap.add_argument("--task", default="video", choices=["video", "control"],
-                    help="control: ego pose + one agent slot of every new frame given (configs[2] with --batch 4); the bench line is video")
+    ap.add_argument("--task", default="video", choices=["video", "control", "mapgiven"],
+                    help="control: ego pose + one agent slot of every new frame given (configs[2] with --batch 4); mapgiven: the map of every new "
+                         "frame given (infer_oar_net's predefined-token prefix, UMGen.py:1184-1201); the bench line is video")
     ap.add_argument("--input-history", type=int, default=0,
                     help="history frames the rollout STARTS with (0 = the reference's setting: --history for video, 13 for control, "
                          "infer_fun.py:64-71 -- the control window then grows 13 -> 20 before it slides)")
@@ -197,6 +198,8 @@ def main():
     seeds = [scene_seed(1000, i) for i in mine]
 
     def control_of(ids, new_frames):
+        if args.task == "mapgiven":
+            return {"init_tokens": {"map": np.concatenate([synthetic_given_map(i, n_frames=new_frames)["map"] for i in ids])}}
         if args.task != "control":
             return {}
         ctl = [synthetic_control(i, n_frames=new_frames) for i in ids]

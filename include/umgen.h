@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define UMGEN_ABI_VERSION 2   /* 2: umgen_rollout takes given_map / given_bbox3d; umgen_timings::decode_batched */
+#define UMGEN_ABI_VERSION 3   /* 2: umgen_rollout takes given_map / given_bbox3d; umgen_timings::decode_batched.  3: umgen_timings::prefix_passes; decode_engine == 2 */
 
 enum {
     UMGEN_OK = 0,
@@ -104,13 +104,16 @@ typedef struct umgen_timings {
     double layers_ms;       /* sum over launches of the decode step's layer kernel(s): the decode engine's one launch per step, or the
                              * 5 x n_oar_layer launches of the five-launch form (when profiling enabled; HIP events on the decode stream) */
     int64_t layers_launches; /* decode steps timed that way */
-    int32_t decode_engine;  /* 1 when the last frame's decode steps ran on the XCD-resident decode engine */
+    int32_t decode_engine;  /* 1 when the last frame's decode steps ran on the XCD-resident decode engine, 2: on its multi-scene form
+                             * (csrc/oar_engine_ms.hip; UMGEN_DECODE_MS=n) */
     int32_t engine_fallback; /* 1 when this configuration would use the decode engine (16-bit mode, n_embd 768) but its census failed at
                               * umgen_create: the five-launch decode layer runs instead (a warning is printed at create) */
     int32_t decode_batched; /* 1 when the last frame's decode steps ran on the batched decode layer (24 and more scenes per call: the scenes
                               * as the matrix-core instruction's columns, csrc/decode_batched.hip) */
     int32_t decode_lanes;   /* ... and on how many decode lanes (sub-batches on their own streams, forked behind the TAR stacks and joined at the
                               * end of the frame; 0 when the batched layer did not run) */
+    int64_t prefix_passes;  /* frames whose GIVEN map / bbox3d positions went through the BlockOAR layers as one forward pass (UMGen.py:1184-1201)
+                             * instead of one decode step per position */
 } umgen_timings;
 
 /* UMGen(config)  -- UMGen.py:53 */

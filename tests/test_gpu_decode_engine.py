@@ -240,20 +240,34 @@ def test_decode_lanes_in_control_mode_with_a_growing_window(setup):
 
 
 def test_default_path_selection_by_batch_size(setup):
-    """Up to 15 scenes per call the one-scene XCD-resident engine takes the decode step (its systolic schedule from 5 on), 16 .. 64 scenes
-    the multi-scene engine (UMGEN_DECODE_MS moves the threshold); the batched layer only when asked for (UMGEN_DECODE_BATCHED with the
-    multi-scene engine off): umgen_timings says which ran."""
+    """Up to 23 scenes per call the XCD-resident engine takes the decode step (its systolic schedule from 5 on), from 24 on the batched
+    layer (measured crossover, profiles/r04_lanes_sweep.txt; UMGEN_DECODE_BATCHED moves the threshold); the multi-scene engine only when
+    asked for (UMGEN_DECODE_MS=n: measured behind both at 16 / 32 / 64 scenes, profiles/r05_ms_experiments.txt): umgen_timings says which ran."""
     cfg, sd = setup
-    e = Engine(cfg, precision="bf16", max_batch=16, max_cond_frames=4)
+    e = Engine(cfg, precision="bf16", max_batch=24, max_cond_frames=4)
     e.load_state_dict(sd)
     e.finalize()
-    scenes = [synthetic_scene(40 + i, n_frames=2) for i in range(16)]
-    e.rollout({m: np.concatenate([s[m] for s in scenes[:15]]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(15)))
+    scenes = [synthetic_scene(40 + i, n_frames=2) for i in range(24)]
+    e.rollout({m: np.concatenate([s[m] for s in scenes[:23]]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(23)))
     t = e.timings()
     assert t["decode_engine"] == 1 and t["decode_batched"] == 0
-    e.rollout({m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(16)))
+    e.rollout({m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(24)))
     t = e.timings()
-    assert t["decode_engine"] == 2 and t["decode_batched"] == 0
+    assert t["decode_engine"] == 0 and t["decode_batched"] == 1 and t["decode_lanes"] == 2
+    e.close()
+    old = os.environ.get("UMGEN_DECODE_MS")
+    os.environ["UMGEN_DECODE_MS"] = "16"
+    try:
+        e = Engine(cfg, precision="bf16", max_batch=16, max_cond_frames=4)
+    finally:
+        if old is None:
+            del os.environ["UMGEN_DECODE_MS"]
+        else:
+            os.environ["UMGEN_DECODE_MS"] = old
+    e.load_state_dict(sd)
+    e.finalize()
+    e.rollout({m: np.concatenate([s[m] for s in scenes[:16]]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(16)))
+    assert e.timings()["decode_engine"] == 2 and e.timings()["decode_batched"] == 0
     e.close()
 
 

@@ -199,6 +199,40 @@ def test_multi_scene_engine_lies_inside_the_oracle_ensemble_at_depth():
             assert d <= bar["logits"], (precision, m, d)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_given_map_prefix_pass_at_production_width_batch_and_engine(precision):
+    """The given-map prefix as one pass at production width (E = 768: the 256-tile GEMM, the matrix-core attention with the causal mask, the
+    decode engine behind it) for 3 scenes at once: equals the three one-scene rollouts token for token (the pass is row-wise / per (scene,
+    head)), and agrees with the step-by-step replay of the given positions (UMGEN_PREFIX_PASS=0: fp32 activations in the decode step
+    instead of the GEMM's 16-bit operands) on all but near-tie tokens."""
+    from umgen_amd.synth import synthetic_given_map
+    cfg = width_config("full_width")
+    B = 3
+    scenes = [synthetic_scene(60 + i, n_frames=2) for i in range(B)]
+    inits = [synthetic_given_map(60 + i, n_frames=2) for i in range(B)]
+    cat = lambda ds: {k: np.concatenate([d[k] for d in ds]) for k in ds[0]}
+    sd = synthetic_state_dict(cfg, seed=WEIGHT_SEED)
+    outs = {}
+    for passes in (True, False):
+        with env(**({} if passes else {"UMGEN_PREFIX_PASS": "0"})):
+            e = Engine(cfg, precision=precision, max_batch=B, max_cond_frames=4)
+            e.load_state_dict(sd)
+            e.finalize()
+            outs[passes] = e.rollout(cat(scenes), 2, cond_frames=3, input_cond_frames=2, init_tokens=cat(inits), seeds=[7, 8, 9])
+            t = e.timings()
+            assert t["prefix_passes"] == (2 if passes else 0) and t["decode_engine"] == 1, t
+            if passes:
+                single = [e.rollout(scenes[i], 2, cond_frames=3, input_cond_frames=2, init_tokens=inits[i], seeds=[7 + i]) for i in range(B)]
+            e.close()
+    for m in MOD_ORDER:
+        for i in range(B):
+            np.testing.assert_array_equal(outs[True][m][i:i + 1], single[i][m], err_msg=f"scene {i} {m}")
+        np.testing.assert_array_equal(outs[True]["map"][:, 2:], cat(inits)["map"])
+    agree = np.mean([np.mean(outs[True][m][:, 2:] == outs[False][m][:, 2:]) for m in ("bbox3d", "image")])
+    print(f"full_width {precision}: token agreement of the prefix pass with the step-by-step replay {agree:.4f}")
+    assert agree > (0.90 if precision == "bf16" else 0.97), agree
+
+
 def test_bf16_teacher_forced_logits_at_2x_width_vs_rounding_aware_oracle_golden():
     """Config #5's doubled width (E=1536, H=32; five-launch decode layer) in bf16 against one run of the rounding-aware oracle
     (no ensemble at this width: one oracle frame takes ~10 CPU minutes): 1.5e-2 absolute / 4e-3 relative rms on logits, every

@@ -51,6 +51,38 @@ def test_fp32_greedy_rollout_is_token_exact_vs_reference_golden(name):
     e.close()
 
 
+@pytest.mark.parametrize("name", ["tiny_mapgiven_greedy", "tiny_mapboxgiven_greedy"])
+def test_given_token_prefix_as_one_pass_is_token_exact(name, monkeypatch):
+    """The predefined-token prefix of infer_oar_net (UMGen.py:1184-1201, 1234-1237: the reference pushes the given map -- or map and boxes --
+    through the 36 layers in ONE forward pass) as one pass here too (engine.hip run_prefix_prefill: the given positions as the rows of the
+    stacks' GEMMs + S x S attention with the causal mask, every layer's k | v rows into the decode cache; the step loop starts at the last given
+    position): the rollouts recorded from the reference bit for bit in fp32 mode, on EVERY new frame (UMGEN_OVERLAP=0: no background TAR pass in
+    the stacks' buffers), equal to the step-by-step replay of rounds 1-4 (UMGEN_PREFIX_PASS=0); in bf16 the two forms agree up to near-ties."""
+    monkeypatch.setenv("UMGEN_OVERLAP", "0")
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
+    cfg = tiny_config().greedy()
+    scene = synthetic_scene(sid, n_frames=icf)
+    init = golden_init_tokens(sid, nf, ctl)
+    outs = {}
+    for precision in ("fp32", "bf16"):
+        for passes in (True, False):
+            if passes:
+                monkeypatch.delenv("UMGEN_PREFIX_PASS", raising=False)
+            else:
+                monkeypatch.setenv("UMGEN_PREFIX_PASS", "0")
+            e = make_engine(cfg, ws, precision)
+            outs[precision, passes] = e.rollout(scene, nf, cond_frames=cf, input_cond_frames=icf, init_tokens=init, seeds=[0])
+            assert e.timings()["prefix_passes"] == (nf if passes else 0)
+            e.close()
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(outs["fp32", True][m], g[f"out_{m}"].astype(np.int64), err_msg=m)
+        np.testing.assert_array_equal(outs["fp32", False][m], g[f"out_{m}"].astype(np.int64), err_msg=m)
+    agree = np.mean([np.mean(outs["bf16", True][m][:, icf:] == outs["bf16", False][m][:, icf:]) for m in ("bbox3d", "image")])
+    print(f"{name}: bf16 greedy token agreement of the prefix pass with the step-by-step replay {agree:.4f}")
+    assert agree > 0.97, agree
+
+
 @pytest.mark.parametrize("name", ["tiny_control_greedy", "tiny_boxctl_greedy", "tiny_grow_control_greedy", "tiny_grow_boxctl_greedy"])
 @pytest.mark.parametrize("precision", ["fp32"])
 def test_growing_window_slot_reuse_in_the_foreground_is_token_exact(name, precision, monkeypatch):

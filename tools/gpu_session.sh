@@ -84,6 +84,9 @@ lanes)   # decode lanes (sub-batches of the batched layer on their own streams):
 wide)
   b wide2x python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x
   b wide2x_h40 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x --history 40 ;;
+mapgiven)  # a given-map rollout (the predefined-token prefix): one pass over the given positions vs the step-by-step replay of rounds 1-4
+  b mapgiven python bench.py --steps 3 --warmup 1 --no-cpu-baseline --task mapgiven
+  b mapgiven_replay env UMGEN_PREFIX_PASS=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --task mapgiven ;;
 control)
   b control_b4 python bench.py --steps 30 --warmup 0 --no-cpu-baseline --batch 4 --task control
   b control_b4_nogrow env UMGEN_GROW_CACHE=0 python bench.py --steps 30 --warmup 0 --no-cpu-baseline --batch 4 --task control ;;

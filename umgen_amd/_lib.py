@@ -63,7 +63,7 @@ class Timings(C.Structure):
                 ("attn_ms", C.c_double), ("attn_launches", C.c_int64), ("attn_flops", C.c_double),
                 ("bg_ms", C.c_double), ("overlapped_frames", C.c_int64),
                 ("layers_ms", C.c_double), ("layers_launches", C.c_int64), ("decode_engine", C.c_int32), ("engine_fallback", C.c_int32),
-                ("decode_batched", C.c_int32), ("decode_lanes", C.c_int32)]
+                ("decode_batched", C.c_int32), ("decode_lanes", C.c_int32), ("prefix_passes", C.c_int64)]
 
 
 def hipcc_path() -> str:

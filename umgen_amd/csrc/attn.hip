@@ -32,7 +32,10 @@ constexpr int kKStride = 128;
 constexpr int kVStride = 128;
 constexpr int kTileBytes = 64 * kKStride + 48 * kVStride;   // 14336
 
-template <int QT, typename TT>
+// CAUSAL (the OAR prefix pass, engine.hip run_prefix_prefill; module.py:402-416 with flash-attn's causal mask at q_len == k_len): query i sees
+// keys 0 .. i.  The key loop stops behind the workgroup's last query; inside it keys past a query are masked (the first tile always holds
+// key 0, so a query's running maximum is finite before the first fully masked tile: exp2(-inf - m) = 0, alpha = 1).
+template <int QT, typename TT, bool CAUSAL = false>
 __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const TT* __restrict__ qk, const TT* __restrict__ vt,
                                                                 TT* __restrict__ y, int S, int S_pad, int H, int nq, int npairs) {
     typedef typename Mma16<TT>::vec vec8;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const TT* __rest
         for (int d = 0; d < 3; ++d) o[t][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     const float c = kScale * kLog2e;
-    const int ntile = (S + 63) / 64;
+    const int ntile = CAUSAL ? min((S + 63) / 64, ((qb * 4 + 4) * (QT * 16) + 63) / 64) : (S + 63) / 64;
     gload(0);
     __syncthreads();   // zero halves in place before the first real halves land next to them
     lstore(0);
@@ -147,6 +150,15 @@ __global__ __launch_bounds__(256) void attn_spatial_mfma_kernel(const TT* __rest
 #pragma unroll
                         for (int t = 0; t < QT; ++t) st[t][kt][r] = -INFINITY;
                     }
+        }
+        if (CAUSAL && k0 + 63 > q0) {   // (wave-uniform: tiles that reach past this wave's first query)
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + kt * 16 + 4 * g + r > q0 + t * 16 + c16) st[t][kt][r] = -INFINITY;
         }
         vec8 pb[QT][2];
 #pragma unroll
@@ -593,13 +605,22 @@ void launch_attn_spatial_mfma(hipStream_t s, const TT* qk, const TT* vt, TT* y, 
 }
 template void launch_attn_spatial_mfma<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int);
 template void launch_attn_spatial_mfma<f16_t>(hipStream_t, const f16_t*, const f16_t*, f16_t*, int, int, int, int);
+template <typename TT>
+void launch_attn_causal_mfma(hipStream_t s, const TT* qk, const TT* vt, TT* y, int F, int S, int S_pad, int H) {
+    constexpr int QT = UMGEN_ATTN_QT;
+    const int nq = (S + 4 * QT * 16 - 1) / (4 * QT * 16);
+    const int pairs = ((F * H + 7) / 8) * 8;
+    hipLaunchKernelGGL((attn_spatial_mfma_kernel<QT, TT, true>), dim3(pairs * nq), dim3(256), 0, s, qk, vt, y, S, S_pad, H, nq, F * H);
+}
+template void launch_attn_causal_mfma<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int);
+template void launch_attn_causal_mfma<f16_t>(hipStream_t, const f16_t*, const f16_t*, f16_t*, int, int, int, int);
 
 // ---------------------------------------------------------------------------------------------------------
 // spatial, generic VALU (parity mode): one thread per query, keys streamed through LDS in tiles of 32
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(128) void attn_spatial_valu_kernel(const T* __restrict__ qk, const T* __restrict__ vt, T* __restrict__ y,
-                                                                int S, int S_pad, int H) {
+                                                                int S, int S_pad, int H, int causal = 0) {
     __shared__ float sk[32][kHeadDim + 1];
     __shared__ float sv[32][kHeadDim + 1];
     const int E = H * kHeadDim;
@@ -617,7 +638,8 @@ __global__ __launch_bounds__(128) void attn_spatial_valu_kernel(const T* __restr
         o[d] = 0.f;
     }
     float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < S; k0 += 32) {
+    const int k_end = causal ? min(S, (int)blockIdx.x * 128 + 128) : S;     // (causal: the keys up to the workgroup's last query)
+    for (int k0 = 0; k0 < k_end; k0 += 32) {
         __syncthreads();
         for (int e = threadIdx.x; e < 32 * kHeadDim; e += 128) {
             const int kk = e / kHeadDim, d = e % kHeadDim;
@@ -634,7 +656,7 @@ __global__ __launch_bounds__(128) void attn_spatial_valu_kernel(const T* __restr
             float a = 0.f;
 #pragma unroll
             for (int d = 0; d < kHeadDim; ++d) a = fmaf(q[d], sk[kk][d], a);
-            a = (k0 + kk < S) ? a * kScale : -INFINITY;
+            a = (k0 + kk < S && !(causal && k0 + kk > qi)) ? a * kScale : -INFINITY;
             sc[kk] = a;
             mx = fmaxf(mx, a);
         }
@@ -673,7 +695,7 @@ __global__ __launch_bounds__(128) void attn_spatial_valu_kernel(const T* __restr
 //         half-used 32-row tile
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_spatial_f32_mfma_kernel(const float* __restrict__ qk, const float* __restrict__ vt, float* __restrict__ y,
-                                                                    int S, int S_pad, int H) {
+                                                                    int S, int S_pad, int H, int causal = 0) {
     __shared__ float sK[kHeadDim][33];
     __shared__ float sV[kHeadDim][33];
     const int E = H * kHeadDim;
@@ -720,10 +742,11 @@ __global__ __launch_bounds__(256) void attn_spatial_f32_mfma_kernel(const float*
         }
     };
     fetch(0);
-    for (int k0 = 0; k0 < S; k0 += 32) {
+    const int k_end = causal ? min(S, (int)blockIdx.x * 128 + 128) : S;     // (causal: the keys up to the workgroup's last query)
+    for (int k0 = 0; k0 < k_end; k0 += 32) {
         stash();
         __syncthreads();
-        if (k0 + 32 < S) fetch(k0 + 32);
+        if (k0 + 32 < k_end) fetch(k0 + 32);
         f32x16_t sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f;
@@ -735,7 +758,7 @@ __global__ __launch_bounds__(256) void attn_spatial_f32_mfma_kernel(const float*
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
-            sc[r] = key < S ? sc[r] * kScale : -INFINITY;
+            sc[r] = (key < S && !(causal && key > qi)) ? sc[r] * kScale : -INFINITY;
             mx = fmaxf(mx, sc[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -790,6 +813,13 @@ void launch_attn_spatial_f32_mfma(hipStream_t s, const float* qk, const float* v
     if (off) { launch_attn_spatial_valu<float>(s, qk, vt, y, F, S, S_pad, H); return; }
     dim3 grid((S + 127) / 128, H, F);
     hipLaunchKernelGGL(attn_spatial_f32_mfma_kernel, grid, dim3(256), 0, s, qk, vt, y, S, S_pad, H);
+}
+// causal S x S attention in fp32 (parity mode) / generic VALU: the OAR prefix pass
+void launch_attn_causal_f32(hipStream_t s, const float* qk, const float* vt, float* y, int F, int S, int S_pad, int H) {
+    static const bool off = getenv("UMGEN_FP32_MFMA") && getenv("UMGEN_FP32_MFMA")[0] == '0';
+    dim3 grid((S + 127) / 128, H, F);
+    if (off) hipLaunchKernelGGL(attn_spatial_valu_kernel<float>, grid, dim3(128), 0, s, qk, vt, y, S, S_pad, H, 1);
+    else hipLaunchKernelGGL(attn_spatial_f32_mfma_kernel, grid, dim3(256), 0, s, qk, vt, y, S, S_pad, H, 1);
 }
 template void launch_attn_spatial_valu<float>(hipStream_t, const float*, const float*, float*, int, int, int, int);
 template void launch_attn_spatial_valu<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int);

@@ -136,11 +136,11 @@ struct umgen_engine {
     unsigned long long* eng_stamps = nullptr;   // UMGEN_DEBUG_TIMING: per-phase ticks of the engine (printed at destroy)
     size_t eng_gloc_bytes = 0;
     // Multi-scene decode engine (oar_engine_ms.hip): from `ms_min` scenes per call on, a work item is (block of ceil(B / 8) scenes, layer) with the
-    // scenes as (hi, lo) column pairs of the matrix-core instruction (UMGEN_DECODE_MS=n moves the threshold; 0 = never)
+    // scenes as (hi, lo) column pairs of the matrix-core instruction (UMGEN_DECODE_MS=n: from n scenes on; default 0 = never)
     unsigned long long* eng_gloc_ms = nullptr;
     unsigned long long* eng_stamps_ms = nullptr;
     size_t eng_gloc_ms_bytes = 0;
-    int ms_min = 16;
+    int ms_min = 0;                       // off by default: measured behind the one-scene engine (<= 23 scenes) and the batched layer + lanes (24 .. 64) at 16 / 32 / 64 scenes
     bool use_ms(int B) const { return eng_enabled && tsz == 2 && ms_min > 0 && B >= ms_min && B <= kEngMsMaxBatch && E == kEngE; }
     int fg_xcds = 8;
     unsigned eng_epoch = 16u;             // first hand-off tag of the next frame (see run_frame)
@@ -320,12 +320,18 @@ template <> struct Path<float> {
     static void attn_spatial(hipStream_t s, const float* qk, const float* vt, float* y, int F, int S, int Sp, int H) {
         launch_attn_spatial_f32_mfma(s, qk, vt, y, F, S, Sp, H);
     }
+    static void attn_causal(hipStream_t s, const float* qk, const float* vt, float* y, int F, int S, int Sp, int H) {
+        launch_attn_causal_f32(s, qk, vt, y, F, S, Sp, H);
+    }
     static void gemm_w_f32act(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<float, float>(s, a); }
 };
 template <typename TT> struct Path16 {   // bf16_t / f16_t: the same matrix-core kernels with the other operand type
     static void gemm(hipStream_t s, const GemmArgs& a) { launch_gemm_mfma<TT>(s, a); }
     static void attn_spatial(hipStream_t s, const TT* qk, const TT* vt, TT* y, int F, int S, int Sp, int H) {
         launch_attn_spatial_mfma<TT>(s, qk, vt, y, F, S, Sp, H);
+    }
+    static void attn_causal(hipStream_t s, const TT* qk, const TT* vt, TT* y, int F, int S, int Sp, int H) {
+        launch_attn_causal_mfma<TT>(s, qk, vt, y, F, S, Sp, H);
     }
     static void gemm_w_f32act(hipStream_t s, const GemmArgs& a) { launch_gemm_valu<TT, float>(s, a); }
 };
@@ -620,6 +626,46 @@ int oar_layers(umgen_engine* e, int B, int ns) {
         }
         gemv<T>(e, e->xdec, E, w.ln_b, w.mlp.Wfc, nullptr, 4 * E, E, B, GEMV_OUT_GELU, e->hdec, 4L * E);
         gemv_resid<T>(e, e->hdec, 4L * E, nullptr, w.mlp.Wproj, nullptr, E, 4 * E, B, e->xdec, E);
+    }
+    return 0;
+}
+
+// The GIVEN-token prefix of a frame as ONE forward pass (infer_oar_net's first iteration pushes the whole predefined prefix through the 36
+// layers, UMGen.py:1184-1201, 1234-1237; rounds 1-4 replayed it as up to 1693 single decode steps, ~0.46 s per frame for a given map).
+// Positions 0 .. P - 2 of every scene are the rows of the TAR stacks' own kernels -- LayerNorm, q|k and V^T GEMMs, S x S attention with the
+// causal mask, projection + MLP with the residual epilogues -- in the stacks' workspaces (idle while the decode runs); every layer leaves its
+// k | v rows in the decode cache.  Position P - 1 stays a decode step: its input goes to xdec and the step loop starts there.
+// Arithmetic: the stacks' contract (16-bit GEMM operands in the 16-bit modes, exact fp32 chains in fp32 mode) instead of the decode
+// step's fp32 activations -- the reference computes the prefix in one fp16-autocast pass as well.
+template <typename T>
+int run_prefix_prefill(umgen_engine* e, int B, int P) {
+    const int E = e->E, H = e->H, S = P - 1;
+    if (S < 1 || S > e->S_pad) return e->fail(UMGEN_E_INVALID, "prefix pass over %d positions", S);
+    hipStream_t st = e->stream;
+    const long R = (long)B * S;
+    T* A = reinterpret_cast<T*>(e->A);
+    T* QKV = reinterpret_cast<T*>(e->QKV);
+    T* Hb = reinterpret_cast<T*>(e->Hb);
+    T* vt = reinterpret_cast<T*>(e->VT);
+    launch_prefix_rows(st, e->tb, e->tb.tske + (long)e->cfg.task_id * E, e->cond, e->d_tokens, B, P, e->X, e->xdec);
+    const size_t wrow = (size_t)E * sizeof(T);
+    for (size_t li = 0; li < e->oar.size(); ++li) {
+        const SubW& w = e->oar[li];
+        const char* Wqkv = reinterpret_cast<const char*>(w.attn.Wqkv);
+        launch_layernorm<T>(st, e->X, E, R, E, w.ln_a, A);
+        linear_store<T>(e, Wqkv, w.attn.bqkv, 2 * E, E, A, R, QKV, 2L * E, 0);           // q | k rows
+        GemmArgs g{};                                                                     // V^T per (scene, head): [B][H][48][S_pad]
+        g.P = A; g.Q = Wqkv + (size_t)2 * E * wrow;
+        g.Mi = S; g.Nj = E; g.K = E; g.ldp = E; g.ldq = E; g.strideP = (long)S * E; g.strideQ = 0; g.batch = B;
+        g.mode = GEMM_VT; g.bias = w.attn.bqkv + 2 * E; g.out = vt; g.ldo = e->S_pad; g.H = H;
+        gemm_timed<T>(e, g);
+        launch_prefix_kv_to_cache<T>(st, QKV, vt, B, S, e->S_pad, H, e->Lmax, reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride,
+                                     e->kv_scene_stride);
+        Path<T>::attn_causal(st, QKV, vt, A, B, S, e->S_pad, H);
+        linear_resid<T>(e, w.attn.Wo, w.attn.bo, E, E, A, R, e->X);
+        launch_layernorm<T>(st, e->X, E, R, E, w.ln_b, A);
+        linear_store<T>(e, w.mlp.Wfc, nullptr, 4 * E, E, A, R, Hb, 4L * E, 1);
+        linear_resid<T>(e, w.mlp.Wproj, nullptr, E, 4 * E, Hb, R, e->X);
     }
     return 0;
 }
@@ -1035,6 +1081,19 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         if (getenv("UMGEN_DEBUG_TIMING"))
             fprintf(stderr, "[umgen] host time to enqueue the background pass: %.1f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+    }
+    // given map (/ boxes): positions 0 .. given_end - 2 as one pass, the step loop starts at given_end - 1 (UMGEN_PREFIX_PASS=0: replay every
+    // given position as a decode step, rounds 1-4).  Not beside a background TAR pass: it works in the stacks' buffers.
+    const char* ppe = getenv("UMGEN_PREFIX_PASS");      // (read per frame: the tests compare both forms in one process)
+    const bool prefix_pass_off = ppe && ppe[0] == '0';
+    if (given_end > kPoseEos + 1 && !prefix_pass_off && !(ov_active && io.next_follows) && !e->bg_pending && j_begin == 0 && !tr) {
+        if (int rc = run_prefix_prefill<T>(e, B, given_end)) return rc;
+        j_begin = given_end - 1;
+        OarState s1 = s0;
+        s1.step = j_begin;
+        HIPCHK(e, hipMemcpyAsync(e->d_state, &s1, sizeof(s1), hipMemcpyHostToDevice, st));
+        for (int l = 0; l < n_lanes && n_lanes > 1; ++l) HIPCHK(e, hipMemcpyAsync(e->lane[l].st, &s1, sizeof(s1), hipMemcpyHostToDevice, st));
+        e->tm.prefix_passes += 1;
     }
     const bool graphs = e->cfg.use_graphs && !tr && !e->profiling;   // profiled frames time every decode step's layer kernel(s) with events
     const bool batched = sizeof(T) == 2 && e->use_batched(B);       // the batched decode layer takes the step (oar_layers)

@@ -88,6 +88,11 @@ void launch_cond_rows(hipStream_t s, int stack, int B, int T, int E, const float
 // x[b] = row (+ cond[b][pos])
 void launch_first_input(hipStream_t s, int B, int E, const float* tske_row, const float* cond, float* x);
 void launch_fixed_token(hipStream_t s, const SampleArgs& a, int B);             // bos/eos/pose prefix steps
+// given-token prefix as one pass (engine.hip run_prefix_prefill): decode inputs of positions 0 .. P - 1, and a pass's k | V^T rows -> the decode cache
+void launch_prefix_rows(hipStream_t s, const EmbedTables& tb, const float* tske_row, const float* cond, const int* tokens, int B, int P, float* X,
+                        float* x_last);
+template <typename T>
+void launch_prefix_kv_to_cache(hipStream_t s, const T* qk, const T* vt, int B, int S, int S_pad, int H, int Lmax, T* cache, long scene_stride);
 void launch_sample_token(hipStream_t s, const SampleArgs& a, int B);            // sampled steps
 // ego head: sample 3 pose tokens per scene from logits [B*3][vocab]
 void launch_sample_rows(hipStream_t s, const float* logits, int V, int k, float temp, const float* u, int* out, int* overflow, int n);   // test hook

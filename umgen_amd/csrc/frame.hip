@@ -584,6 +584,56 @@ __global__ __launch_bounds__(256) void fixed_token_kernel(SampleArgs a) {
 }
 void launch_fixed_token(hipStream_t s, const SampleArgs& a, int B) { hipLaunchKernelGGL(fixed_token_kernel, dim3(B), dim3(256), 0, s, a); }
 
+// The decode inputs of the GIVEN positions 0 .. P - 1 of every scene at once (infer_oar_net's predefined-token prefix, UMGen.py:1184-1201): row j is
+// what the step loop would have fed into step j -- the task row + cond[0] for j = 0 (first_input_kernel), the embedding of the token at
+// position j - 1 + cond[j] behind it (fixed_token_kernel) -- none of which depends on a layer output.  Rows 0 .. P - 2 go to X (the prefix
+// pass pushes them through the BlockOAR layers as the rows of GEMMs), row P - 1 to x_last (the input of the first step the loop still runs).
+__global__ __launch_bounds__(256) void prefix_rows_kernel(EmbedTables tb, const float* __restrict__ tske_row, const float* __restrict__ cond,
+                                                          const int* __restrict__ tokens, int P, float* __restrict__ X, float* __restrict__ x_last) {
+    const int b = blockIdx.x / P, j = blockIdx.x % P, E = tb.E;
+    const float* cr = cond + ((long)b * kSeq + j) * E;
+    float* xo = j + 1 < P ? X + ((long)b * (P - 1) + j) * E : x_last + (long)b * E;
+    const int* toks = tokens + (long)b * kTokPerFrame;
+    const float* ef = nullptr;
+    const bf16_t* eb = nullptr;
+    if (j == 0) ef = tske_row;
+    else {
+        const int jp = j - 1, aux = fixed_aux_id(jp);      // the token at position j - 1
+        if (aux >= 0) ef = tb.axe + (long)aux * E;
+        else if (jp < kPoseEos) eb = tb.fouier_pe + (long)toks[jp - 1] * E;
+        else if (jp < kMapEos) ef = tb.gmap + (long)toks[kOffMap + (jp - kMapC0)] * E;
+        else ef = tb.be + (long)toks[kOffBox + (jp - kBoxC0)] * E;
+    }
+    for (int c = threadIdx.x; c < E; c += blockDim.x) xo[c] = (ef ? ef[c] : bf16_to_f32(eb[c])) + cr[c];
+}
+void launch_prefix_rows(hipStream_t s, const EmbedTables& tb, const float* tske_row, const float* cond, const int* tokens, int B, int P, float* X,
+                        float* x_last) {
+    hipLaunchKernelGGL(prefix_rows_kernel, dim3(B * P), dim3(256), 0, s, tb, tske_row, cond, tokens, P, X, x_last);
+}
+
+// k rows (row-major [B S][2E]: q | k) and V^T ([B][H][48][S_pad]) of a prefix pass -> rows 0 .. S - 1 of one layer's decode cache
+// ([scene][2][H][Lmax][48], the type the pass computed in)
+template <typename T>
+__global__ __launch_bounds__(256) void prefix_kv_to_cache_kernel(const T* __restrict__ qk, const T* __restrict__ vt, int S, int S_pad, int H, int Lmax,
+                                                                  T* __restrict__ cache, long scene_stride) {
+    const int E = H * kHeadDim;
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // (key, head, dim)
+    if (i >= (long)S * E) return;
+    const int j = (int)(i / E), hd = (int)(i % E), h = hd / kHeadDim, d = hd % kHeadDim;
+    T* c = cache + (long)b * scene_stride;
+    c[((long)h * Lmax + j) * kHeadDim + d] = qk[((long)b * S + j) * 2 * E + E + hd];
+    c[((long)(H + h) * Lmax + j) * kHeadDim + d] = vt[(((long)b * H + h) * kHeadDim + d) * S_pad + j];
+}
+template <typename T>
+void launch_prefix_kv_to_cache(hipStream_t s, const T* qk, const T* vt, int B, int S, int S_pad, int H, int Lmax, T* cache, long scene_stride) {
+    const long n = (long)S * H * kHeadDim;
+    hipLaunchKernelGGL(prefix_kv_to_cache_kernel<T>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, qk, vt, S, S_pad, H, Lmax, cache, scene_stride);
+}
+template void launch_prefix_kv_to_cache<float>(hipStream_t, const float*, const float*, int, int, int, int, int, float*, long);
+template void launch_prefix_kv_to_cache<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, int, int, int, int, int, bf16_t*, long);
+template void launch_prefix_kv_to_cache<f16_t>(hipStream_t, const f16_t*, const f16_t*, int, int, int, int, int, f16_t*, long);
+
 __global__ __launch_bounds__(256) void sample_token_kernel(SampleArgs a) {
     __shared__ SamplerLds sh;
     __shared__ float cor[64][8];

@@ -53,6 +53,9 @@ template <typename TT> void launch_attn_spatial_mfma(hipStream_t s, const TT* qk
 template <typename T> void launch_attn_spatial_valu(hipStream_t s, const T* qk, const T* vt, T* y, int F, int S, int S_pad, int H);
 // fp32 parity mode on v_mfma_f32_32x32x2_f32 (UMGEN_FP32_MFMA=0: the VALU kernel above)
 void launch_attn_spatial_f32_mfma(hipStream_t s, const float* qk, const float* vt, float* y, int F, int S, int S_pad, int H);
+// the same layouts with flash-attn's causal mask at q_len == k_len (query i sees keys 0 .. i): the OAR prefix pass over the given tokens
+template <typename TT> void launch_attn_causal_mfma(hipStream_t s, const TT* qk, const TT* vt, TT* y, int F, int S, int S_pad, int H);
+void launch_attn_causal_f32(hipStream_t s, const float* qk, const float* vt, float* y, int F, int S, int S_pad, int H);
 // temporal causal attention over T frames per spatial position: qkv [B*T*S][3E] row-major, y [B*T*S][E]
 // Temporal attention over history slots [t0, t0 + Tn) held in the qkv rows; k | v of slots [0, t0) are read from `cache`
 // ([B][Tcap][S][2E], dtype T) and, when write != 0, the k | v rows of the new slots are appended to it (attn.hip).

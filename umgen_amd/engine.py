@@ -34,7 +34,7 @@ class Engine:
         self.precision = precision
         self.max_batch = max_batch
         c = _lib.Config(
-            abi_version=2, n_embd=cfg.n_embd, n_head=cfg.n_head, n_ego_tar_layer=cfg.n_ego_tar_layer,
+            abi_version=3, n_embd=cfg.n_embd, n_head=cfg.n_head, n_ego_tar_layer=cfg.n_ego_tar_layer,
             n_ego_ca_layer=cfg.n_ego_ca_layer, n_map_tar_layer=cfg.n_map_tar_layer, n_box_tar_layer=cfg.n_box_tar_layer,
             n_tar_layer=cfg.n_tar_layer, n_oar_layer=cfg.n_oar_layer, pose_vocab=cfg.pose_vocab_size,
             map_vocab=cfg.map_vocab_size, bbox3d_vocab=cfg.bbox3d_vocab_size, img_vocab=cfg.img_vocab_size,
