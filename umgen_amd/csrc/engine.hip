@@ -1717,6 +1717,8 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     e->kv_scene_stride = (long)e->Lmax * 2 * E;
     e->kv_layer_stride = (long)Bm * e->kv_scene_stride;
     if (int rc = dev_alloc(e, &e->kvcache, (size_t)cfg->n_oar_layer * e->kv_layer_stride * e->tsz)) return rc;
+    // (the engines' key loops request whole 16-key passes and mask the keys past the step: p = 0 times whatever bits lie there must be 0, not NaN)
+    HIPCHK(e, hipMemset(e->kvcache, 0, (size_t)cfg->n_oar_layer * e->kv_layer_stride * e->tsz));
     if ((UMGEN_ENG_MFMA & 16) && e->tsz == 2) {
         // the matrix-core attention multiplies whole 32-key tiles, masked keys included: no NaN bit patterns may sit behind the mask
         HIPCHK(e, hipMemset(e->kvcache, 0, (size_t)cfg->n_oar_layer * e->kv_layer_stride * e->tsz));

@@ -62,60 +62,6 @@ static_assert(M_TOTAL * 4 <= 160 * 1024, "LDS budget");
 // slot; while something is missing a lane asks for ONE of its missing granules per round with a short sleep in between (the gathers
 // of this engine are up to 12 granules per thread and 32 CUs: polling all of them would put 1.5 MB per round on the L2 / the fabric
 // while a group waits for its predecessor), then requests all its missing slots again.
-// Granule i of a WAVE-UNIFORM base as `saddr + 32-bit byte offset`: one VGPR of address per request in flight (a gather of this engine keeps
-// 12 requests per lane in flight; as 64-bit flat pointers -- what the compiler makes of an agent-scope atomic load -- their addresses alone
-// were 24 VGPRs and pushed 12 of the resident c_fc fragments out to scratch memory).  Written as inline assembly, so the requests are
-// invisible to the compiler's wait-count bookkeeping: poll_wait() is the explicit s_waitcnt every consumer goes through (a wave's loads
-// return in order: vmcnt(0) is exactly what waiting for the youngest request means).
-__device__ inline void poll_issue(u64& v, const u64* g, u32 i) {
-    asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(v) : "v"(i << 3), "s"(g) : "memory");
-}
-template <int PER>
-__device__ inline void poll_wait(u64 (&v)[PER]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < PER; ++k) asm volatile("" : "+v"(v[k]));     // (the values are defined behind the wait, not behind the request)
-}
-// slot k of thread tid (bit k of need) waits for granule idx(k) with `tag` and hands its value to sink(k, value).  Round 1 requests every
-// slot; while something is missing a lane asks for ONE of its missing granules per round with a short sleep in between (the gathers
-// of this engine are up to 12 granules per thread and 32 CUs: polling all of them would put 1.5 MB per round on the L2 / the fabric
-// while a group waits for its predecessor), then requests all its missing slots again.
-// ALL: every round requests every slot again (one round trip behind the producers; for the hand-offs at which the whole group
-// is waiting anyway -- nobody's K/V stream shares the L2 with the polls).
-template <int PER, bool ALL = false, typename IDX, typename SINK>
-__device__ inline void poll_ms(Ctx& c, int tid, const u64* g, u32 need, IDX idx, u32 tag, SINK sink) {
-    if (c.failed || !__any(need != 0u)) return;
-    u32 got = 0;
-    for (u32 spins = 0;;) {
-        u64 v[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) poll_issue(v[k], g, idx(k));      // (unconditional: slots that are not needed re-read a valid index)
-        poll_wait<PER>(v);
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if ((((need & ~got) >> k) & 1u) && (u32)(v[k] >> 32) == tag) { sink(k, __uint_as_float((u32)v[k])); got |= 1u << k; }
-        if (!__any(got != need)) break;
-        if (ALL) {
-            if (++spins > kSpinLimit / 8) { if ((tid & 63) == 0) atomicExch(c.err, tag | 0x80000000u); c.failed = true; break; }
-            if ((spins & 63u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
-            continue;
-        }
-        // one missing granule per lane until it is there (lanes that have everything re-read a slot of theirs)
-        const u32 miss = need & ~got;
-        const u32 i1 = idx(miss ? __ffs((int)miss) - 1 : 0);
-        for (;;) {
-            __builtin_amdgcn_s_sleep(2);
-            u64 v1[1];
-            poll_issue(v1[0], g, i1);
-            poll_wait<1>(v1);
-            if (!__any(miss != 0u && (u32)(v1[0] >> 32) != tag)) break;
-            if (++spins > kSpinLimit) { if ((tid & 63) == 0) atomicExch(c.err, tag | 0x80000000u); c.failed = true; break; }
-            if ((spins & 255u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
-        }
-        if (c.failed) break;
-    }
-}
-
 // value -> hi | lo << 16 in the operand type
 template <typename TT>
 __device__ inline u32 pack16(float v) {
