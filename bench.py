@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak
 
 
-PMC_FILES = ["r04_pmc_fetch_size_engine.csv", "r03_pmc_fetch_size_engine.csv"]   # newest first
+PMC_FILES = ["r05_pmc_fetch_size_engine.csv", "r04_pmc_fetch_size_engine.csv", "r03_pmc_fetch_size_engine.csv"]   # newest first
 
 
 def pmc_traffic_per_launch(engine_on: bool):
@@ -58,7 +58,7 @@ def pmc_traffic_per_launch(engine_on: bool):
 def closed_loop_record(precision: str):
     """Greedy closed-loop token agreement of the timed precision with the fp32 engine (frames 0 / 2 / 8), from the newest committed
     tools/closed_loop.py run -- a 30-frame fp32 rollout does not fit a bench run; `source` names the file."""
-    for fn in ("r04_closed_loop.json", "r03_closed_loop.json"):
+    for fn in ("r05_closed_loop.json", "r04_closed_loop.json", "r03_closed_loop.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if os.path.exists(path):
             try:

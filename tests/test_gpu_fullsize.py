@@ -251,6 +251,52 @@ def test_bf16_teacher_forced_logits_at_2x_width_vs_rounding_aware_oracle_golden(
     assert n_flip <= 0.015 * 2196, rep
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_wide_engine_matches_the_five_launch_path_at_2x_width(precision):
+    """The chip-wide decode engine of the wide layers (csrc/oar_engine_wide.hip: n_embd 1536, 256 workgroups of 6 compute + 2 poll waves, hand-offs
+    across the fabric; the default decode path of configs[4] at up to 4 scenes per call) against the five-launch layer it replaces
+    (UMGEN_DECODE_WIDE=0): same rounding points, another fp32 summation order -- teacher-forced logits within the north-star's 1e-3, at most a
+    handful of sampled tokens on the other side of a near-tie; its graph-replayed steps equal its eager launches token for token; a batch of three
+    scenes equals the three one-scene rollouts (one engine launch per scene and step on shared hand-off buffers)."""
+    cfg = width_config("wide2x")
+    sd = synthetic_state_dict(cfg, seed=WEIGHT_SEED)
+    scene = synthetic_scene(SCENE_ID, n_frames=2)
+    window = {m: scene[m][0] for m in MOD_ORDER}
+    with env(UMGEN_DECODE_WIDE=0):
+        ref = Engine(cfg, precision=precision, max_cond_frames=4)
+    ref.load_state_dict(sd)
+    ref.finalize()
+    toks_ref, tr_ref = ref.frame(window, frame_idx=0, seed=3, trace=True)
+    assert ref.timings()["decode_engine"] == 0
+    ref.close()
+    e = Engine(cfg, precision=precision, max_batch=3, max_cond_frames=4)
+    e.load_state_dict(sd)
+    e.finalize()
+    toks, tr = e.frame(window, frame_idx=0, seed=3, trace=True, forced=toks_ref)
+    assert e.timings()["decode_engine"] == 3
+    worst = 0.0
+    for m in ("map", "bbox3d", "image"):
+        worst = max(worst, float(np.abs(tr[f"logits_{m}"] - tr_ref[f"logits_{m}"]).max()))
+        np.testing.assert_allclose(tr[f"logits_{m}"], tr_ref[f"logits_{m}"], atol=1e-3, rtol=0, err_msg=m)
+    print(f"chip-wide engine vs launches at 2x width ({precision}): max |dlogit| = {worst:.2e}, sampled != forced: {tr['counters']['sampled_ne_forced']}")
+    assert tr["counters"]["sampled_ne_forced"] <= 4, tr["counters"]
+    scenes = [synthetic_scene(80 + i, n_frames=2) for i in range(3)]
+    single = [e.rollout(scenes[i], 1, cond_frames=3, input_cond_frames=2, seeds=[21 + i]) for i in range(3)]
+    both = e.rollout(cat(scenes), 1, cond_frames=3, input_cond_frames=2, seeds=[21, 22, 23])
+    assert e.timings()["decode_engine"] == 3
+    e.close()
+    for i in range(3):
+        for m in MOD_ORDER:
+            np.testing.assert_array_equal(both[m][i:i + 1], single[i][m], err_msg=f"scene {i} {m}")
+    eager = Engine(cfg, precision=precision, max_batch=1, max_cond_frames=4, use_graphs=False)
+    eager.load_state_dict(sd)
+    eager.finalize()
+    out = eager.rollout(scenes[0], 1, cond_frames=3, input_cond_frames=2, seeds=[21])
+    eager.close()
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(out[m], single[0][m], err_msg=m)
+
+
 def test_wide2x_doubled_context_rollout_properties():
     """BASELINE.json config #5 (2x width, doubled context): 39 history frames -> the window grows to 40 slots (the 64-slot temporal
     attention form).  The oracle cannot run this in test time, so: two scenes in one batch == the two one-scene rollouts, the

@@ -140,6 +140,13 @@ struct umgen_engine {
     unsigned long long* eng_gloc_ms = nullptr;
     unsigned long long* eng_stamps_ms = nullptr;
     size_t eng_gloc_ms_bytes = 0;
+    // Chip-wide decode engine for wide layers (oar_engine_wide.hip; n_embd 1536, up to 4 scenes per call, one launch each; UMGEN_DECODE_WIDE=0: five launches per layer)
+    bool wide_enabled = false;
+    OarLayerDev* d_layers_wide = nullptr;
+    std::vector<void*> wide_wp2;            // per BlockOAR: mlp c_proj repacked [256 ranks][E rows][24 hidden units of the rank]
+    unsigned long long* wide_gran = nullptr;
+    unsigned int *wide_ticket = nullptr, *wide_err = nullptr;
+    bool use_wide(int B) const { return wide_enabled && tsz == 2 && B <= 4; }
     int ms_min = 0;                       // off by default: measured behind the one-scene engine (<= 23 scenes) and the batched layer + lanes (24 .. 64) at 16 / 32 / 64 scenes
     bool use_ms(int B) const { return eng_enabled && tsz == 2 && ms_min > 0 && B >= ms_min && B <= kEngMsMaxBatch && E == kEngE; }
     int fg_xcds = 8;
@@ -563,6 +570,18 @@ int oar_layers(umgen_engine* e, int B, int ns) {
             }
             return 0;
         }
+    }
+    if (sizeof(T) == 2 && e->use_wide(B)) {
+        OarWideArgs a{};
+        a.layers = e->d_layers_wide; a.n_layers = (int)e->oar.size();
+        a.kvcache = reinterpret_cast<bf16_t*>(e->kvcache); a.kv_layer_stride = e->kv_layer_stride; a.kv_scene_stride = e->kv_scene_stride; a.Lmax = e->Lmax;
+        a.xdec = e->xdec; a.st = e->d_state; a.gran = e->wide_gran; a.ticket = e->wide_ticket; a.err = e->wide_err;
+        a.fp16 = std::is_same<T, f16_t>::value ? 1 : 0;
+        for (int b = 0; b < B; ++b) {
+            a.scene = b;
+            HIPCHK(e, launch_oar_engine_wide(e->stream, a));
+        }
+        return 0;
     }
     if (const umgen_engine::EngStream* es = (sizeof(T) == 2 && e->use_ms(B)) ? e->eng_for(e->stream) : nullptr) {
         OarMsArgs a{};
@@ -1000,6 +1019,11 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     // Hand-off tags of the decode engine never repeat while a copy of an old granule can survive anywhere (a group's L2 keeps its
     // plain-stored granules across launches): the epoch runs on monotonically over the engine's lifetime.  Before the 32-bit
     // counter would wrap (~100 frames at 16384 tags per step) everything is drained and the granule buffers are cleared.
+    if (e->wide_enabled && e->eng_epoch > 0xE0000000u) {
+        HIPCHK(e, hipDeviceSynchronize());
+        HIPCHK(e, hipMemset(e->wide_gran, 0, oar_engine_wide_granules() * 8));
+        e->eng_epoch = 16u;
+    }
     if (e->eng_enabled && e->eng_epoch > 0xE0000000u) {
         HIPCHK(e, hipDeviceSynchronize());
         HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
@@ -1097,8 +1121,10 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     }
     const bool graphs = e->cfg.use_graphs && !tr && !e->profiling;   // profiled frames time every decode step's layer kernel(s) with events
     const bool batched = sizeof(T) == 2 && e->use_batched(B);       // the batched decode layer takes the step (oar_layers)
-    const umgen_engine::EngStream* eng = (sizeof(T) == 2 && !batched) ? e->eng_for(st) : nullptr;
-    const int eng_ng = eng ? eng->NG : (batched ? -2 : 0);     // the engine's grid depends on the stream's XCDs: graphs are per (B, NG)
+    const bool wide = sizeof(T) == 2 && e->use_wide(B);           // the chip-wide engine of the wide layers: one launch per scene and step
+    static const umgen_engine::EngStream wide_stream{true, 8, {}};
+    const umgen_engine::EngStream* eng = wide ? &wide_stream : ((sizeof(T) == 2 && !batched) ? e->eng_for(st) : nullptr);
+    const int eng_ng = wide ? -3 : (eng ? eng->NG : (batched ? -2 : 0));     // the engine's grid depends on the stream's XCDs: graphs are per (B, NG)
     if (graphs && (e->step_graph_B != B || e->step_graph_NG != eng_ng)) {
         for (auto& row : e->step_graph)
             for (auto& g : row)
@@ -1220,12 +1246,12 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                 HIPCHK(e, hipGraphDestroy(g));
             }
             HIPCHK(e, hipGraphLaunch(ge, st));
-            e->tm.oar_kernels += (int64_t)(run - 1) * ((eng ? 1 : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
+            e->tm.oar_kernels += (int64_t)(run - 1) * ((eng ? (wide ? B : 1) : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
             j += run - 1;
         } else if (int rc = enqueue_step<T>(e, B, mod, ns, tr, j)) {
             return rc;
         }
-        e->tm.oar_kernels += (eng ? 1 : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
+        e->tm.oar_kernels += (eng ? (wide ? B : 1) : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
     }
     e->tm.oar_steps += kImgEos;
     HIPCHK(e, hipEventRecord(e->ev[3], st));
@@ -1233,7 +1259,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     int counters[8] = {};
     HIPCHK(e, hipMemcpyAsync(counters, e->d_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     unsigned eng_err = 0;
-    if (eng) HIPCHK(e, hipMemcpyAsync(&eng_err, e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    if (eng) HIPCHK(e, hipMemcpyAsync(&eng_err, wide ? e->wide_err : e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
     {
         const hipError_t le = e->launch_status != hipSuccess ? e->launch_status : hipGetLastError();
@@ -1241,7 +1267,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         if (le != hipSuccess) return e->fail(UMGEN_E_HIP, "a kernel launch of this frame was refused: %s", hipGetErrorString(le));
     }
     if (eng_err) {   // a hand-off of the decode engine timed out (e.g. two engines sharing one GPU): never return tokens from such a frame
-        (void)hipMemset(e->eng_err, 0, sizeof(unsigned));
+        (void)hipMemset(wide ? e->wide_err : e->eng_err, 0, sizeof(unsigned));
         return e->fail(UMGEN_E_HIP, "decode engine gave up waiting for hand-off tag 0x%08x (is another persistent kernel using this GPU?)", eng_err);
     }
     if (tr && tr->counters) memcpy(tr->counters, counters, sizeof(counters));
@@ -1257,7 +1283,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     }
     hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->tm.total_ms += ms;
     e->tm.frames += 1;
-    e->tm.decode_engine = eng ? (e->use_ms(B) ? 2 : 1) : 0;      // 2: the multi-scene engine (oar_engine_ms.hip)
+    e->tm.decode_engine = eng ? (wide ? 3 : (e->use_ms(B) ? 2 : 1)) : 0;      // 2: the multi-scene engine (oar_engine_ms.hip), 3: the chip-wide engine of the wide layers
     e->tm.decode_batched = batched ? 1 : 0;
     e->tm.decode_lanes = batched ? n_lanes : 0;
     e->tm.engine_fallback = e->eng_fallback ? 1 : 0;
@@ -1417,6 +1443,32 @@ int repack_mlp_proj(umgen_engine* e) {
     return 0;
 }
 
+// Layer table of the chip-wide engine (oar_engine_wide.hip) + its mlp c_proj slices: rank r multiplies its 24 hidden units h[24 r ..] into ALL E
+// output rows, so its slice is W[row][24 r .. 24 r + 23] for every row: [256 ranks][E rows][24], 48 contiguous bytes per (rank, row).
+int repack_wide(umgen_engine* e) {
+    const int E = e->E, F4 = 4 * E, RF = F4 / kWideGroups;
+    std::vector<bf16_t> src((size_t)E * F4), dst((size_t)E * F4);
+    std::vector<OarLayerDev> hl(e->oar.size());
+    if (e->wide_wp2.size() != e->oar.size()) {
+        e->wide_wp2.assign(e->oar.size(), nullptr);
+        for (auto& p : e->wide_wp2)
+            if (int rc = dev_alloc(e, &p, dst.size() * sizeof(bf16_t))) return rc;
+    }
+    for (size_t li = 0; li < e->oar.size(); ++li) {
+        const SubW& w = e->oar[li];
+        HIPCHK(e, hipMemcpy(src.data(), w.mlp.Wproj, src.size() * sizeof(bf16_t), hipMemcpyDeviceToHost));
+        for (int r = 0; r < kWideGroups; ++r)
+            for (int row = 0; row < E; ++row)
+                memcpy(&dst[((size_t)r * E + row) * RF], &src[(size_t)row * F4 + (size_t)RF * r], RF * sizeof(bf16_t));
+        HIPCHK(e, hipMemcpy(e->wide_wp2[li], dst.data(), dst.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+        hl[li] = OarLayerDev{reinterpret_cast<const bf16_t*>(w.attn.Wqkv), reinterpret_cast<const bf16_t*>(w.attn.Wo),
+                             reinterpret_cast<const bf16_t*>(w.mlp.Wfc), reinterpret_cast<const bf16_t*>(w.mlp.Wproj),
+                             reinterpret_cast<const bf16_t*>(e->wide_wp2[li]), w.attn.bqkv, w.attn.bo, w.ln_a, w.ln_b, nullptr};
+    }
+    HIPCHK(e, hipMemcpy(e->d_layers_wide, hl.data(), hl.size() * sizeof(OarLayerDev), hipMemcpyHostToDevice));
+    return 0;
+}
+
 }  // namespace
 
 // =============================================================================================================
@@ -1512,7 +1564,41 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
             e->stream = nullptr;
         }
     }
-    e->overlap = cfg->max_cond_frames >= 2 && !e->eng_enabled;
+    // Wide layers (n_embd 1536): the chip-wide engine needs all 256 CUs of the decode stream at once (one persistent workgroup per CU: the same
+    // census as the XCD-resident engine's, 32 workgroups on each of 8 XCDs, twice) and, like it, gives up the CU-masked background TAR pass.
+    const char* dw_env = getenv("UMGEN_DECODE_WIDE");
+    if (cfg->precision != UMGEN_PREC_FP32 && cfg->n_embd == kWideE && cfg->n_head == kWideE / kHeadDim && cfg->n_oar_layer <= 64 &&
+        !(dw_env && dw_env[0] == '0') && !(ov_env && ov_env[0] != '0')) {
+        HIPCHK(e, hipStreamCreate(&e->stream));
+        HIPCHK(e, oar_engine_wide_prepare());
+        unsigned* d_cnt = nullptr;
+        HIPCHK(e, hipMalloc(&d_cnt, 64));
+        bool ok = true;
+        for (int rep2 = 0; rep2 < 2 && ok; ++rep2) {
+            unsigned cnt[16] = {};
+            if (hipMemsetAsync(d_cnt, 0, 64, e->stream) != hipSuccess || launch_oar_engine_wide_census(e->stream, d_cnt) != hipSuccess ||
+                hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) {
+                (void)hipGetLastError();
+                ok = false;
+                break;
+            }
+            int groups = 0;
+            for (int x = 0; x < 16; ++x) {
+                if (cnt[x] == (unsigned)kEngGroup) ++groups;
+                else if (cnt[x] != 0) ok = false;
+            }
+            if (groups != 8) ok = false;
+        }
+        (void)hipFree(d_cnt);
+        e->wide_enabled = ok;
+        if (!ok) {
+            fprintf(stderr, "[umgen] WARNING: the chip-wide decode engine cannot be used on device %d (its census did not find one workgroup on each of 256 "
+                            "CUs); decode steps run as five launches per layer\n", cfg->device);
+            HIPCHK(e, hipStreamDestroy(e->stream));
+            e->stream = nullptr;
+        }
+    }
+    e->overlap = cfg->max_cond_frames >= 2 && !e->eng_enabled && !e->wide_enabled;
     if (ov_env) { e->overlap_mode = ov_env[0] - '0'; e->overlap = cfg->max_cond_frames >= 2 && ov_env[0] != '0'; }
     int bg_cus = 64;   // mask bits are striped over the 8 XCDs: 64 = 8 CUs of each XCD for the background stream
     if (const char* bc = getenv("UMGEN_BG_CUS")) bg_cus = std::max(32, std::min(128, atoi(bc)));
@@ -1784,6 +1870,15 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         }
         if (getenv("UMGEN_DEBUG_TIMING")) fprintf(stderr, "[umgen] decode engine: on (8 XCD groups)\n");
     }
+    if (e->wide_enabled) {
+        if (int rc = dalloc(e, &e->d_layers_wide, (size_t)cfg->n_oar_layer)) return rc;
+        if (int rc = dalloc(e, &e->wide_gran, oar_engine_wide_granules())) return rc;
+        if (int rc = dalloc(e, &e->wide_ticket, (size_t)4)) return rc;
+        if (int rc = dalloc(e, &e->wide_err, (size_t)4)) return rc;
+        HIPCHK(e, hipMemset(e->wide_gran, 0, oar_engine_wide_granules() * 8));
+        HIPCHK(e, hipMemset(e->wide_ticket, 0, 16));
+        HIPCHK(e, hipMemset(e->wide_err, 0, 16));
+    }
     return UMGEN_OK;
 }
 
@@ -1885,6 +1980,7 @@ int umgen_finalize_weights(umgen_engine* e) {
                  : e->cfg.precision == UMGEN_PREC_FP16 ? build_tables<f16_t>(e) : build_tables<float>(e);
     if (rc) return rc;
     if (e->eng_enabled) { if (int rc2 = repack_mlp_proj(e)) return rc2; }
+    if (e->wide_enabled) { if (int rc2 = repack_wide(e)) return rc2; }
     e->px.valid = false;   // slot caches filled with other weights are not a prefix of anything
     e->finalized = true;
     return UMGEN_OK;
@@ -2097,7 +2193,7 @@ int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in,
     if (!e->finalized) return e->fail(UMGEN_E_STATE, "umgen_finalize_weights has not been called");
     if (e->cfg.precision == UMGEN_PREC_FP32) return e->fail(UMGEN_E_UNSUPPORTED, "16-bit engines only");
     if (B < 1 || B > e->cfg.max_batch || L < 0 || L >= e->Lmax) return e->fail(UMGEN_E_INVALID, "B=%d L=%d", B, L);
-    if (use_engine && !e->eng_enabled) return e->fail(UMGEN_E_UNSUPPORTED, "decode engine not available on this engine");
+    if (use_engine && use_engine != 3 && !e->eng_enabled) return e->fail(UMGEN_E_UNSUPPORTED, "decode engine not available on this engine");
     if (e->eng_enabled && e->eng_epoch > 0xE0000000u) {   // same wrap rule as run_frame
         HIPCHK(e, hipDeviceSynchronize());
         HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
@@ -2112,9 +2208,11 @@ int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in,
     OarState s0{L, 0, 0, 0, 0, epoch, SamplerParams{}};
     HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->xdec, x_in, (size_t)B * e->E * 4, hipMemcpyHostToDevice, st));
-    const bool en = e->eng_enabled;
+    const bool en = e->eng_enabled, wide_keep = e->wide_enabled;
     const int ms_keep = e->ms_min;
-    e->eng_enabled = en && use_engine;
+    if (use_engine == 3 && !e->wide_enabled) return e->fail(UMGEN_E_UNSUPPORTED, "chip-wide decode engine not available on this engine");
+    e->wide_enabled = wide_keep && use_engine == 3;
+    e->eng_enabled = en && use_engine && use_engine != 3;
     if (use_engine == 2) {      // the multi-scene engine whatever B is
         if (!e->eng_gloc_ms) return e->fail(UMGEN_E_UNSUPPORTED, "multi-scene decode engine not available on this engine");
         e->ms_min = 1;
@@ -2125,11 +2223,12 @@ int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in,
     const int lrc = e->cfg.precision == UMGEN_PREC_FP16 ? oar_layers<f16_t>(e, B, attn_nsplit(L + 1)) : oar_layers<bf16_t>(e, B, attn_nsplit(L + 1));
     e->stream = keep;
     e->eng_enabled = en;
+    e->wide_enabled = wide_keep;
     e->ms_min = ms_keep;
     if (lrc) return lrc;
     HIPCHK(e, hipMemcpyAsync(x_out, e->xdec, (size_t)B * e->E * 4, hipMemcpyDeviceToHost, st));
     unsigned eng_err = 0;
-    if (use_engine) HIPCHK(e, hipMemcpyAsync(&eng_err, e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    if (use_engine) HIPCHK(e, hipMemcpyAsync(&eng_err, use_engine == 3 ? e->wide_err : e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
     if (eng_err) {
         (void)hipMemset(e->eng_err, 0, sizeof(unsigned));

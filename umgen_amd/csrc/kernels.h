@@ -206,6 +206,30 @@ size_t oar_engine_ms_lds_bytes();
 hipError_t oar_engine_ms_prepare();
 hipError_t launch_oar_engine_ms(hipStream_t s, const OarMsArgs& a);
 
+// ------------------------------------------------------------------------------------------------
+// chip-wide decode engine for wide layers (oar_engine_wide.hip): n_embd 1536, one scene per launch, 256 workgroups (6 compute + 2 poll waves),
+// hand-offs across the fabric
+// ------------------------------------------------------------------------------------------------
+constexpr int kWideE = 1536;                   // the width this engine is built for (configs[4]: 2x UMGen_Large)
+constexpr int kWideGroups = 256;               // workgroups = ranks (one per CU)
+constexpr int kWideSplits = 4;                 // key quarters per head in the attention phase (32 heads x 4 = 128 ranks)
+struct OarWideArgs {
+    const OarLayerDev* layers; int n_layers;   // Wp2: mlp c_proj repacked [256 ranks][1536 rows][24 hidden units of the rank] (engine.hip repack_wide)
+    bf16_t* kvcache; long kv_layer_stride, kv_scene_stride; int Lmax;   // [layer][scene][2][H][Lmax][48]
+    float* xdec;                               // [B][E]: in = input of layer 0, out = output of the last layer
+    int scene;                                 // the scene of this launch (a call's scenes: one launch each, one behind the other)
+    const OarState* st;
+    unsigned long long* gran;                  // oar_engine_wide_granules() hand-off granules
+    unsigned int* ticket;                      // monotonic arrival counter (rank = ticket % 256)
+    unsigned int* err;
+    int fp16;
+};
+size_t oar_engine_wide_lds_bytes();
+size_t oar_engine_wide_granules();
+hipError_t oar_engine_wide_prepare();
+hipError_t launch_oar_engine_wide(hipStream_t s, const OarWideArgs& a);
+hipError_t launch_oar_engine_wide_census(hipStream_t s, unsigned int* d_counts16);
+
 size_t oar_engine_lds_bytes();
 hipError_t oar_engine_prepare();                // per device, before the first launch / census (dynamic-LDS attribute)
 hipError_t launch_oar_engine(hipStream_t s, const OarEngineArgs& a);

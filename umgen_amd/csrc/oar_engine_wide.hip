@@ -1,0 +1,453 @@
+// Chip-wide decode engine for WIDE BlockOAR layers (configs[4]: n_embd 1536, 32 heads): the n_oar_layer layers of one decode step (module.py:378-428)
+// of ONE scene in one persistent launch of 256 workgroups (one per CU).
+//
+// At 2x width a layer is 57 MB: through ONE XCD's memory link (the XCD-resident engine, oar_engine.hip) that is 45-85 us per layer, as five launches
+// (gemv.hip) 33.5 us of which 11 us are the weight stream and the rest kernel boundaries.  Here all 256 CUs work on every layer -- rank r (a ticket)
+// owns q|k|v rows 18 r .., c_proj rows 6 r .., the hidden units 24 r .. of c_fc and the matching 24 columns of the mlp c_proj (hidden-unit split: what is
+// exchanged are the ranks' partial sums of the 1536 outputs) -- and a layer's hand-offs are {tag, value} granules across the fabric.
+//
+// ROLES.  The first form of this engine (round 5, profiles/r05_wide2x_engine.txt) ran at the five launches' 33 us per layer: a wave's loads return in
+// order, so a hand-off poll's s_waitcnt also waited for the weight requests in front of it and every phase paid first-byte latency + its 11-19 MB
+// weight stream + a fabric round trip one behind the other.  Wait counters are PER WAVE: here waves 6, 7 of a workgroup are POLL waves that issue
+// nothing but granule polls (and the layer's LayerNorm weights) and hand the gathered vectors over through LDS + the workgroup barrier (which
+// does not drain vmcnt, oar_common.h wg_barrier); waves 0..5 are COMPUTE waves that never poll: their weight requests (one to two phases ahead, into
+// registers) stream in the shadow of the hand-offs, and their K/V requests of the attention phase are only behind weights requested a whole phase earlier.
+//   per layer: x -> [P1 LN + 18 q|k|v rows] -> q|k|v -> [attention: head r / 4, key quarter r % 4, ranks 0..127] -> 4 partials per head ->
+//              [owner rank merges] -> attention output -> [P3 c_proj + residual] -> x' -> [P4 LN + 24 hidden units + GELU + partial sums] -> [P5 adds 256 partials]
+//   six fabric hops and eight workgroup barriers per layer.
+// Arithmetic (fixed, independent of the placement): fp32 activations, 16-bit weights and K/V cache, fp32 accumulation; row dot products as in gemv.hip
+// (lane l owns k = 512 c + 8 l .. + 7, packed fp32 FMAs, wave sum); weight-only LayerNorm (eps 1e-5) with gemv.hip's statistics; exact erf-GELU; the
+// attention's new key / value out of the q|k|v exchange rounded to 16 bits.  Against the five-launch form only fp32 summation orders differ.
+#include "oar_common.h"
+
+namespace umgen {
+
+namespace {
+
+constexpr int WE = kWideE, WH = kWideE / kHeadDim, WF = 4 * kWideE;
+constexpr int NWG = kWideGroups;                 // 256 workgroups = ranks
+constexpr int WT = kEngThreads;                  // 512 threads
+constexpr int CW = 6, PW = 2;                    // compute waves, poll waves
+constexpr int CT = CW * 64, PT = PW * 64;        // 384 compute threads, 128 poll threads
+constexpr int KC = WE / 512;                     // 16-byte weight chunks per lane and row (3)
+constexpr int WRQ = 3 * WE / NWG;                // 18 q|k|v rows per rank: 3 per compute wave
+constexpr int WRO = WE / NWG;                    // 6 c_proj rows: 1 per compute wave
+constexpr int WRF = WF / NWG;                    // 24 hidden units: 4 per compute wave
+constexpr int NSP = kWideSplits;                 // key splits per head (H x NSP attention ranks)
+constexpr int PREC = 52;                         // floats per attention partial record: o[48] | m | l | pad
+static_assert(WE == 1536 && WRQ == 3 * CW && WRO == CW && WRF == 4 * CW && WE == 4 * CT && WH * NSP <= NWG && NSP == 4, "wide engine geometry");
+static_assert(WE == 12 * PT, "gathers of 1536 granules: 12 per poll lane");
+
+// LDS carve (floats)
+constexpr int W_XS = 0;                       // x of the layer [1536]
+constexpr int W_XB = W_XS + WE;               // x' [1536]
+constexpr int W_AS = W_XB + WE;               // attention output [1536]
+constexpr int W_LN = W_AS + WE;               // ln_1 | ln_2 weights of the layer [2][1536]
+constexpr int W_PT = W_LN + 2 * WE;           // gathered mlp partial sums [256][6]
+constexpr int W_SB = W_PT + NWG * WRO;        // the four key quarters' partials of this owner's head [4][52]
+constexpr int W_QS = W_SB + NSP * PREC;       // q_h | k_h | v_h [144 -> 160]
+constexpr int W_WP = W_QS + 160;              // the compute waves' attention partials [6][52]
+constexpr int W_HS = W_WP + CW * PREC;        // gelu(c_fc) of this rank's 24 hidden units [24 -> 32]
+constexpr int W_MISC = W_HS + 32;
+constexpr int W_TOTAL = W_MISC + 16;
+
+struct WRow { u32x4_t c[KC]; };
+__device__ inline void req_row(WRow& w, const bf16_t* W, long row, int lane) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) w.c[c] = ldwu(W + row * WE, (u32)(512 * c + 8 * lane));
+}
+struct XRegs { f32x2_t v[KC][4]; };
+// lane l's values k = 512 c + 8 l .. + 7 of a 1536-vector
+__device__ inline void load_x(const float* xs, int lane, XRegs& x) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) load8p(xs + 512 * c + 8 * lane, x.v[c]);
+}
+// weight-only LayerNorm (module.py:26-37) of the whole row held by the wave (every wave computes the statistics itself), gemv.hip's form
+__device__ inline void ln_regs(XRegs& x, const float* lnw, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += x.v[c][e].x + x.v[c][e].y;
+    const float mean = wave_sum_all(s) / (float)WE;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d0 = x.v[c][e].x - mean, d1 = x.v[c][e].y - mean; q += d0 * d0 + d1 * d1; }
+    const float rstd = 1.0f / sqrtf(wave_sum_all(q) / (float)WE + 1e-5f);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        f32x2_t lw[4];
+        load8p(lnw + 512 * c + 8 * lane, lw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x.v[c][e] = f32x2_t{(x.v[c][e].x - mean) * rstd * lw[e].x, (x.v[c][e].y - mean) * rstd * lw[e].y};
+    }
+}
+template <typename TT>
+__device__ inline float row_dot(const WRow& w, const XRegs& x) {
+    f32x2_t acc = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KC; ++c) acc = dot8<TT>(w.c[c], x.v[c], acc);
+    return wave_sum_all(acc.x + acc.y);
+}
+
+// online-softmax state of a lane (its 12 of the head's 48 dimensions) and its folds (the multi-scene engine's, oar_engine_ms.hip)
+struct WAtt { float m, l; f32x2_t o[6]; };
+__device__ inline void watt_merge(WAtt& a, float mb, float lb, const f32x2_t (&ob)[6]) {
+    const float M = fmaxf(a.m, mb);
+    const float ea = (M > -INFINITY) ? __expf(a.m - M) : 0.f, eb = (M > -INFINITY) ? __expf(mb - M) : 0.f;
+    a.l = fmaf(eb, lb, ea * a.l);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) a.o[j] = f32x2_t{fmaf(eb, ob[j].x, ea * a.o[j].x), fmaf(eb, ob[j].y, ea * a.o[j].y)};
+    a.m = M;
+}
+template <int CTRL>
+__device__ inline void watt_fold_dpp(WAtt& a) {
+    f32x2_t ob[6];
+    const float mb = dpp_mov<CTRL>(a.m), lb = dpp_mov<CTRL>(a.l);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) ob[j] = f32x2_t{dpp_mov<CTRL>(a.o[j].x), dpp_mov<CTRL>(a.o[j].y)};
+    watt_merge(a, mb, lb, ob);
+}
+template <bool ROW32>
+__device__ inline void watt_fold_swap(WAtt& a) {
+    auto sw = [](float v, float& x, float& y) {
+        if (ROW32) { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); x = __uint_as_float(r[0]); y = __uint_as_float(r[1]); }
+        else { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); x = __uint_as_float(r[0]); y = __uint_as_float(r[1]); }
+    };
+    WAtt x, y;
+    sw(a.m, x.m, y.m);
+    sw(a.l, x.l, y.l);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float x0, y0, x1, y1;
+        sw(a.o[j].x, x0, y0);
+        sw(a.o[j].y, x1, y1);
+        x.o[j] = f32x2_t{x0, x1};
+        y.o[j] = f32x2_t{y0, y1};
+    }
+    watt_merge(x, y.m, y.l, y.o);
+    a = x;
+}
+
+}  // namespace
+
+template <typename TT>
+__global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    u32* ldsu = reinterpret_cast<u32*>(lds);
+    const int tid0 = threadIdx.x;
+    if (tid0 == 0) ldsu[W_MISC] = atomicAdd(a.ticket, 1u) & (u32)(NWG - 1);
+    wg_barrier();
+    const int r0 = __builtin_amdgcn_readfirstlane((int)ldsu[W_MISC]);     // this workgroup's rank
+    const bool poller = tid0 >= CT;
+    Ctx c{a.err, false};
+    const int Lk = a.st->step;
+    const u32 ep = a.st->epoch;
+    float* xs = lds + W_XS;
+    float* xb = lds + W_XB;
+    float* as = lds + W_AS;
+    float* hs = lds + W_HS;
+    float* qs = lds + W_QS;
+    // granule buffers (shared by a call's scenes, one launch behind the other): x | q|k|v | key-quarter partials | attention output | x' | mlp partial sums [256][1536]
+    u64* gx = a.gran;
+    u64* gqkv = gx + WE;
+    u64* gpart = gqkv + 3 * WE;
+    u64* gatt = gpart + WH * NSP * PREC;
+    u64* gxb = gatt + WE;
+    u64* gpy = gxb + WE;
+    const long kv_scene = (long)a.scene * a.kv_scene_stride;
+    // compute waves: the weights of the phases ahead
+    WRow wq[3], wo, wf[4];
+    u32x4_t wp[4][3];
+    int tid = tid0, r = r0;
+    int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto req_q = [&](const OarLayerDev& lw) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) req_row(wq[i], lw.Wqkv, (long)WRQ * r + wave + CW * i, lane);
+    };
+    auto req_f = [&](const OarLayerDev& lw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) req_row(wf[i], lw.Wfc, (long)WRF * r + wave + CW * i, lane);
+    };
+    auto req_p = [&](const OarLayerDev& lw) {      // mlp c_proj slice of this rank, repacked [256 ranks][1536 rows][24]: rows tid, tid + 384, ...
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wp[i][j] = ldwu(lw.Wp2 + ((long)r * WE + tid + CT * i) * WRF, (u32)(8 * j));
+    };
+    if (!poller) req_q(a.layers[0]);
+    for (int l = 0; l < a.n_layers; ++l) {
+        // (everything of a layer is derived from these INSIDE the layer: laundered, so that no loop-invariant row / granule address is hoisted into
+        //  registers -- 64-bit addresses in VGPRs were what the register allocator spilled)
+        tid = tid0; r = r0;
+        asm volatile("" : "+v"(tid));
+        asm volatile("" : "+s"(r));
+        lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int pt = tid - CT;                                              // poll thread 0 .. 127
+        const bool att_rank = r < WH * NSP, owner = att_rank && (r % NSP) == 0;
+        const int hh = r / NSP, sp = r % NSP;                                 // (attention ranks)
+        const OarLayerDev lw = a.layers[l];
+        const u32 tg = ep + (u32)((a.scene * 64 + l) * 8);
+        float bq[3], bo = 0.f;
+        // ---------------- hand-off 1: x ----------------
+        if (poller) {
+            float lnv[24];      // ln_1 | ln_2 weights of the layer -> LDS (3072 floats over 128 lanes)
+#pragma unroll
+            for (int k = 0; k < 24; ++k) lnv[k] = ldg((pt + k * PT < WE ? lw.ln_a : lw.ln_b - WE) + pt + k * PT);
+            if (l == 0) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) xs[pt + k * PT] = ldg(a.xdec + (long)a.scene * WE + pt + k * PT);
+            } else {
+                poll_ms<12>(c, tid, gx, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 0, [&](int k, float v) { xs[pt + k * PT] = v; });
+            }
+#pragma unroll
+            for (int k = 0; k < 24; ++k) lds[W_LN + pt + k * PT] = lnv[k];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) bq[i] = ldg(lw.bqkv + WRQ * r + wave + CW * i);
+            bo = ldg(lw.bo + WRO * r + wave);
+            req_row(wo, lw.Wo, (long)WRO * r + wave, lane);
+        }
+        wg_barrier();      // B1
+        // ---------------- P1: LN + this rank's 18 q|k|v rows | hand-off 2: q_h | k_h | v_h of the attention ranks ----------------
+        if (!poller) {
+            XRegs x;
+            load_x(xs, lane, x);
+            ln_regs(x, lds + W_LN, lane);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float v = row_dot<TT>(wq[i], x) + bq[i];
+                const int n = WRQ * r + wave + CW * i;
+                if (lane == 0) {
+                    put_far(gqkv, (u32)n, tg + 1, v);
+                    if (n >= WE) {   // K / V rows of the new token: 16 bits into the cache (head-major [2][H][Lmax][48])
+                        const int cc = n - WE, kvsel = cc / WE, hc = cc % WE;
+                        (a.kvcache + (long)l * a.kv_layer_stride + kv_scene)[(u32)(((kvsel * WH + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim)] = bits16<TT>(v);
+                    }
+                }
+            }
+        } else if (att_rank) {
+            // lanes 0 .. 127: values 0 .. 127 of q_h | k_h | v_h, lanes 0 .. 15 also 128 .. 143
+            auto src = [&](int k) { const int e = min(pt + k * PT, 3 * kHeadDim - 1); return (u32)((e / kHeadDim) * WE + hh * kHeadDim + e % kHeadDim); };
+            poll_ms<2>(c, tid, gqkv, pt < 16 ? 3u : 1u, src, tg + 1, [&](int k, float v) { qs[pt + k * PT] = v; });
+        }
+        wg_barrier();      // B2
+        // ---------------- P2: attention of (head hh, key quarter sp): the compute waves split the quarter's keys ----------------
+        if (!poller && att_rank) {
+            const int nk = Lk + 1;
+            const int spn = ((((nk + NSP - 1) / NSP) + KPW - 1) / KPW) * KPW;        // keys per quarter
+            const int span = ((((spn + CW - 1) / CW) + KPW - 1) / KPW) * KPW;        // keys per wave
+            const int nch = span / KPW;
+            const int k_lo = sp * spn + wave * span, k_hi = min(min(nk, (sp + 1) * spn), k_lo + span);
+            const int piece = lane & (LPK - 1), kg = lane / LPK;
+            auto dim_of = [&](int j) { return j < 4 ? piece * 8 + 2 * j : 32 + piece * 4 + 2 * (j - 4); };
+            const bf16_t* kbase = a.kvcache + (long)l * a.kv_layer_stride + kv_scene + (long)hh * a.Lmax * kHeadDim;
+            const bf16_t* vbase = kbase + (long)WH * a.Lmax * kHeadDim;
+            KVPiece kc[2], vc[2];      // two 16-key passes: one in the registers being used, one in flight (plain loads: the compiler counts them)
+            auto kv_req = [&](int buf, int ci) {
+                const u32 off = (u32)min(k_lo + KPW * min(ci, nch - 1) + kg, a.Lmax - 1) * (u32)kHeadDim;
+                kc[buf].a = ldwu(kbase, off + (u32)piece * 8u);
+                kc[buf].b = ldwu2(kbase, off + 32u + (u32)piece * 4u);
+                vc[buf].a = ldwu(vbase, off + (u32)piece * 8u);
+                vc[buf].b = ldwu2(vbase, off + 32u + (u32)piece * 4u);
+            };
+            kv_req(0, 0);
+            WAtt st;
+            st.m = -INFINITY; st.l = 0.f;
+            f32x2_t q2[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { st.o[j] = f32x2_t{0.f, 0.f}; q2[j] = f32x2_t{qs[dim_of(j)], qs[dim_of(j) + 1]}; }
+            auto chunk = [&](const KVPiece& kcb, const KVPiece& vcb, int ci) {
+                const int k = k_lo + KPW * ci + kg;
+                const u32 kw[6] = {kcb.a.x, kcb.a.y, kcb.a.z, kcb.a.w, kcb.b.x, kcb.b.y};
+                f32x2_t acc = {0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc = mac2<TT>(kw[j], q2[j], acc);
+                if (k == Lk) {   // the new token's own key is not in the cache yet: from the q | k | v exchange, as the cache will hold it
+                    acc = f32x2_t{0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+                        acc = __builtin_elementwise_fma(f32x2_t{round16<TT>(qs[kHeadDim + dim_of(j)]), round16<TT>(qs[kHeadDim + dim_of(j) + 1])}, q2[j], acc);
+                }
+                float d = acc.x + acc.y;
+                d += dpp_xor1(d);
+                d += dpp_xor2(d);
+                d = (k < k_hi) ? d * kScaleQK : -INFINITY;
+                const float m_new = fmaxf(st.m, d);
+                if (m_new > -INFINITY) {
+                    const float scale = __expf(st.m - m_new);
+                    const f32x2_t scale2 = {scale, scale};
+                    st.l *= scale;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) st.o[j] *= scale2;
+                    const u32 vw[6] = {vcb.a.x, vcb.a.y, vcb.a.z, vcb.a.w, vcb.b.x, vcb.b.y};
+                    const float p = (k < k_hi) ? __expf(d - m_new) : 0.f;
+                    const f32x2_t p2 = {p, p};
+                    st.l += p;
+                    if (k == Lk) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j)
+                            st.o[j] = __builtin_elementwise_fma(p2, f32x2_t{round16<TT>(qs[2 * kHeadDim + dim_of(j)]), round16<TT>(qs[2 * kHeadDim + dim_of(j) + 1])}, st.o[j]);
+                    } else if (k < k_hi) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) st.o[j] = mac2<TT>(vw[j], p2, st.o[j]);
+                    }
+                    st.m = m_new;
+                }
+            };
+            for (int ci = 0; ci < nch; ci += 2) {
+                kv_req(1, ci + 1);
+                chunk(kc[0], vc[0], ci);
+                kv_req(0, ci + 2);
+                if (ci + 1 < nch) chunk(kc[1], vc[1], ci + 1);
+            }
+            watt_fold_dpp<0x124>(st);
+            watt_fold_dpp<0x128>(st);
+            watt_fold_swap<false>(st);
+            watt_fold_swap<true>(st);
+            float* wpz = lds + W_WP + wave * PREC;
+            if (lane < LPK) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2_t*>(wpz + dim_of(j)) = st.o[j];
+                if (lane == 0) { wpz[48] = st.m; wpz[49] = st.l; }
+            }
+        }
+        if (!poller) { req_f(lw); req_p(lw); }      // (behind the key loop: they stream under the next three hand-offs)
+        wg_barrier();      // B3
+        // ---------------- the compute waves' partials merged in wave order -> this quarter's partial (unnormalised o, m, l) | hand-off 3: the owner's four quarters ----------------
+        if (!poller && att_rank && tid < kHeadDim + 2) {
+            const float* wz = lds + W_WP;
+            float M = wz[48];
+#pragma unroll
+            for (int ww = 1; ww < CW; ++ww) M = fmaxf(M, wz[ww * PREC + 48]);
+            float Ls = 0.f, o = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < CW; ++ww) {
+                const float e = (M > -INFINITY) ? __expf(wz[ww * PREC + 48] - M) : 0.f;
+                Ls = fmaf(e, wz[ww * PREC + 49], Ls);
+                if (tid < kHeadDim) o = fmaf(e, wz[ww * PREC + tid], o);
+            }
+            put_far(gpart + (long)r * PREC, (u32)tid, tg + 2, tid < kHeadDim ? o : (tid == kHeadDim ? M : Ls));
+        }
+        if (poller && owner) {
+            // 4 records x 50 values = 200 granules over 128 lanes
+            auto src = [&](int k) { const int f = min(pt + k * PT, NSP * (kHeadDim + 2) - 1); return (u32)((f / (kHeadDim + 2)) * PREC + f % (kHeadDim + 2)); };
+            poll_ms<2>(c, tid, gpart + (long)r * PREC, pt + PT < NSP * (kHeadDim + 2) ? 3u : 1u, src, tg + 2,
+                       [&](int k, float v) { const int f = pt + k * PT; lds[W_SB + (f / (kHeadDim + 2)) * PREC + f % (kHeadDim + 2)] = v; });
+        }
+        wg_barrier();      // B4
+        // ---------------- the owner merges its head's four quarters -> attention output | hand-off 4: the 1536 attention outputs ----------------
+        if (!poller && owner && tid < kHeadDim) {
+            const float* p0 = lds + W_SB;
+            float M = p0[48];
+#pragma unroll
+            for (int s2 = 1; s2 < NSP; ++s2) M = fmaxf(M, p0[s2 * PREC + 48]);
+            float Ls = 0.f, o = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < NSP; ++s2) {
+                const float e = (p0[s2 * PREC + 48] > -INFINITY) ? __expf(p0[s2 * PREC + 48] - M) : 0.f;
+                Ls = fmaf(e, p0[s2 * PREC + 49], Ls);
+                o = fmaf(e, p0[s2 * PREC + tid], o);
+            }
+            put_far(gatt, (u32)(hh * kHeadDim + tid), tg + 3, o / Ls);
+        }
+        if (poller) poll_ms<12>(c, tid, gatt, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 3, [&](int k, float v) { as[pt + k * PT] = v; });
+        wg_barrier();      // B5
+        // ---------------- P3: c_proj row 6 r + wave + residual -> x' | hand-off 5: x' ----------------
+        if (!poller) {
+            XRegs x;
+            load_x(as, lane, x);
+            const int n = WRO * r + wave;
+            const float v = row_dot<TT>(wo, x) + bo;
+            if (lane == 0) put_far(gxb, (u32)n, tg + 4, xs[n] + v);
+            if (l + 1 < a.n_layers) req_q(a.layers[l + 1]);
+        } else {
+            poll_ms<12>(c, tid, gxb, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 4, [&](int k, float v) { xb[pt + k * PT] = v; });
+        }
+        wg_barrier();      // B6
+        // ---------------- P4: LN + this rank's 24 hidden units + GELU ----------------
+        if (!poller) {
+            XRegs x;
+            load_x(xb, lane, x);
+            ln_regs(x, lds + W_LN + WE, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = row_dot<TT>(wf[i], x);
+                if (lane == 0) hs[wave + CW * i] = gelu_erf(v);
+            }
+        }
+        wg_barrier();      // B7
+        // ---------------- this rank's partial sums of the 1536 mlp c_proj outputs | hand-off 6: the 256 partials of this rank's 6 rows ----------------
+        if (!poller) {
+            f32x2_t hq[3][4];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) load8p(hs + 8 * j, hq[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x2_t acc = {0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc = dot8<TT>(wp[i][j], hq[j], acc);
+                put_far(gpy + (long)r * WE, (u32)(tid + CT * i), tg + 5, acc.x + acc.y);
+            }
+        } else {
+            // slot f = producer p x 6 + row i (1536 granules, 12 per poll lane)
+            poll_ms<12>(c, tid, gpy + WRO * r, 0xfffu, [&](int k) { const u32 f = (u32)(pt + k * PT); return (f / (u32)WRO) * (u32)WE + f % (u32)WRO; }, tg + 5,
+                        [&](int k, float v) { lds[W_PT + pt + k * PT] = v; });
+        }
+        wg_barrier();      // B8
+        // ---------------- P5: x'' = x' + the 256 partial sums (four lanes add 64 producers each, ascending; then the quad in a fixed order) ----------------
+        if (tid < 4 * WRO) {
+            const int i = tid >> 2, g4 = tid & 3;
+            float s = 0.f;
+            for (int p = 0; p < NWG / 4; ++p) s += lds[W_PT + (g4 * (NWG / 4) + p) * WRO + i];
+            s += dpp_xor1(s);
+            s += dpp_xor2(s);
+            const int n = WRO * r + i;
+            const float xn = xb[n] + s;
+            if (g4 == 0) {
+                if (l + 1 == a.n_layers) a.xdec[(long)a.scene * WE + n] = xn;
+                else put_far(gx, (u32)n, tg + 8, xn);
+            }
+        }
+        // (no barrier: the next layer's gathers cannot complete before every rank -- this one included -- has published its x'' rows, and
+        //  W_PT / xb are next written behind B6 / B8 of the next layer)
+    }
+}
+
+size_t oar_engine_wide_lds_bytes() {
+    const size_t need = (size_t)W_TOTAL * sizeof(float);
+    return need > (size_t)(96 << 10) ? need : (size_t)(96 << 10);      // > 80 KB: never two workgroups on one CU
+}
+size_t oar_engine_wide_granules() { return (size_t)WE + 3 * WE + (size_t)WH * NSP * PREC + WE + WE + (size_t)NWG * WE; }
+
+__global__ __launch_bounds__(kEngThreads) void oar_engine_wide_census_kernel(unsigned int* count) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (threadIdx.x == 0) {
+        lds[0] = 0.f;
+        atomicAdd(count + xcc_id(), 1u);
+    }
+}
+hipError_t launch_oar_engine_wide_census(hipStream_t s, unsigned int* d_counts16) {
+    hipLaunchKernelGGL(oar_engine_wide_census_kernel, dim3(NWG), dim3(kEngThreads), oar_engine_wide_lds_bytes(), s, d_counts16);
+    return hipGetLastError();
+}
+
+hipError_t oar_engine_wide_prepare() {
+    for (const void* f : {reinterpret_cast<const void*>(oar_engine_wide_kernel<bf16_t>), reinterpret_cast<const void*>(oar_engine_wide_kernel<f16_t>),
+                          reinterpret_cast<const void*>(oar_engine_wide_census_kernel)}) {
+        hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oar_engine_wide_lds_bytes());
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_oar_engine_wide(hipStream_t s, const OarWideArgs& a) {
+    const dim3 grid(NWG), block(kEngThreads);
+    if (a.fp16) hipLaunchKernelGGL((oar_engine_wide_kernel<f16_t>), grid, block, oar_engine_wide_lds_bytes(), s, a);
+    else hipLaunchKernelGGL((oar_engine_wide_kernel<bf16_t>), grid, block, oar_engine_wide_lds_bytes(), s, a);
+    return hipGetLastError();
+}
+
+}  // namespace umgen
