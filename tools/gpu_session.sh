@@ -84,6 +84,20 @@ lanes)   # decode lanes (sub-batches of the batched layer on their own streams):
 wide)
   b wide2x python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x
   b wide2x_h40 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --config wide2x --history 40 ;;
+widevar)  # the chip-wide 2x-width engine: shipped library + measurement builds WIDE_VARIANTS="..." (tools/build_variant.sh), per-phase stamps of rank 0
+  for v in shipped ${WIDE_VARIANTS}; do
+    lib=$PWD/umgen_amd/libumgen_hip_$v.so; [ $v = shipped ] && lib=$PWD/umgen_amd/libumgen_hip.so
+    b widevar_$v env UMGEN_DEBUG_TIMING=1 UMGEN_LIB_PATH=$lib ${WIDE_ENV} python bench.py --steps 1 --warmup 1 --no-cpu-baseline --config wide2x
+    grep "chip-wide decode engine, rank 0" gpurun_out/${R}_bench_widevar_$v.err | tail -1 | cut -c1-600
+  done ;;
+widestep)  # tools/wide_step_time.py with the shipped library and the measurement builds WIDE_VARIANTS="..." -> r05_wide_step_time.txt
+  : > gpurun_out/${R}_wide_step_time.txt
+  for v in shipped ${WIDE_VARIANTS}; do
+    lib=$PWD/umgen_amd/libumgen_hip_$v.so; [ $v = shipped ] && lib=$PWD/umgen_amd/libumgen_hip.so
+    echo "--- $v" >> gpurun_out/${R}_wide_step_time.txt
+    if [ $v = shipped ]; then env ${WIDE_ENV} UMGEN_LIB_PATH=$lib python tools/wide_step_time.py >> gpurun_out/${R}_wide_step_time.txt 2>&1
+    else env ${WIDE_ENV} ENGINE_ONLY=1 UMGEN_LIB_PATH=$lib python tools/wide_step_time.py >> gpurun_out/${R}_wide_step_time.txt 2>&1; fi
+  done; cat gpurun_out/${R}_wide_step_time.txt ;;
 mapgiven)  # a given-map rollout (the predefined-token prefix): one pass over the given positions vs the step-by-step replay of rounds 1-4
   b mapgiven python bench.py --steps 3 --warmup 1 --no-cpu-baseline --task mapgiven
   b mapgiven_replay env UMGEN_PREFIX_PASS=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --task mapgiven ;;

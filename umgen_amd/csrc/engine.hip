@@ -146,6 +146,7 @@ struct umgen_engine {
     std::vector<void*> wide_wp2;            // per BlockOAR: mlp c_proj repacked [256 ranks][E rows][24 hidden units of the rank]
     unsigned long long* wide_gran = nullptr;
     unsigned int *wide_ticket = nullptr, *wide_err = nullptr;
+    unsigned long long* wide_stamps = nullptr;
     bool use_wide(int B) const { return wide_enabled && tsz == 2 && B <= 4; }
     int ms_min = 0;                       // off by default: measured behind the one-scene engine (<= 23 scenes) and the batched layer + lanes (24 .. 64) at 16 / 32 / 64 scenes
     bool use_ms(int B) const { return eng_enabled && tsz == 2 && ms_min > 0 && B >= ms_min && B <= kEngMsMaxBatch && E == kEngE; }
@@ -577,6 +578,7 @@ int oar_layers(umgen_engine* e, int B, int ns) {
         a.kvcache = reinterpret_cast<bf16_t*>(e->kvcache); a.kv_layer_stride = e->kv_layer_stride; a.kv_scene_stride = e->kv_scene_stride; a.Lmax = e->Lmax;
         a.xdec = e->xdec; a.st = e->d_state; a.gran = e->wide_gran; a.ticket = e->wide_ticket; a.err = e->wide_err;
         a.fp16 = std::is_same<T, f16_t>::value ? 1 : 0;
+        a.stamps = e->wide_stamps;
         for (int b = 0; b < B; ++b) {
             a.scene = b;
             HIPCHK(e, launch_oar_engine_wide(e->stream, a));
@@ -1873,11 +1875,15 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     if (e->wide_enabled) {
         if (int rc = dalloc(e, &e->d_layers_wide, (size_t)cfg->n_oar_layer)) return rc;
         if (int rc = dalloc(e, &e->wide_gran, oar_engine_wide_granules())) return rc;
-        if (int rc = dalloc(e, &e->wide_ticket, (size_t)4)) return rc;
+        if (int rc = dalloc(e, &e->wide_ticket, (size_t)16)) return rc;      // one arrival counter per XCD
         if (int rc = dalloc(e, &e->wide_err, (size_t)4)) return rc;
         HIPCHK(e, hipMemset(e->wide_gran, 0, oar_engine_wide_granules() * 8));
-        HIPCHK(e, hipMemset(e->wide_ticket, 0, 16));
+        HIPCHK(e, hipMemset(e->wide_ticket, 0, 64));
         HIPCHK(e, hipMemset(e->wide_err, 0, 16));
+        if (getenv("UMGEN_DEBUG_TIMING")) {
+            if (int rc = dalloc(e, &e->wide_stamps, (size_t)16)) return rc;
+            HIPCHK(e, hipMemset(e->wide_stamps, 0, 128));
+        }
     }
     return UMGEN_OK;
 }
@@ -2248,6 +2254,17 @@ int umgen_destroy(umgen_engine* e) {
             fprintf(stderr, "[umgen] multi-scene decode engine, group 0 rank 0, us per item over %llu items:", st[15]);
             double tot = 0;
             for (int p = 0; p < 11; ++p) { fprintf(stderr, " %s %.2f", nm[p], (double)st[p] / 100.0 / (double)st[15]); tot += (double)st[p] / 100.0 / (double)st[15]; }
+            fprintf(stderr, " | total %.2f\n", tot);
+        }
+    }
+    if (e->wide_stamps) {
+        unsigned long long st[16];
+        if (hipMemcpy(st, e->wide_stamps, 128, hipMemcpyDeviceToHost) == hipSuccess && st[15]) {
+            const char* nm[14] = {"wait x", "LN + qkv rows", "wait qkv", "attention", "wait waves", "quarter out + wait quarters", "merge + wait att", "c_proj", "wait x'",
+                                  "LN + c_fc + GELU", "wait waves", "mlp partial sums", "wait partial sums", "add partials"};
+            fprintf(stderr, "[umgen] chip-wide decode engine, rank 0 wave 0, us per layer over %llu layers:", st[15]);
+            double tot = 0;
+            for (int p = 0; p < 14; ++p) { fprintf(stderr, " %s %.2f", nm[p], (double)st[p] / 100.0 / (double)st[15]); tot += (double)st[p] / 100.0 / (double)st[15]; }
             fprintf(stderr, " | total %.2f\n", tot);
         }
     }

@@ -220,9 +220,10 @@ struct OarWideArgs {
     int scene;                                 // the scene of this launch (a call's scenes: one launch each, one behind the other)
     const OarState* st;
     unsigned long long* gran;                  // oar_engine_wide_granules() hand-off granules
-    unsigned int* ticket;                      // monotonic arrival counter (rank = ticket % 256)
+    unsigned int* ticket;                      // [8] monotonic arrival counters, one per XCD (rank = 32 x XCD + ticket % 32)
     unsigned int* err;
     int fp16;
+    unsigned long long* stamps;                // optional [16]: 100 MHz ticks per phase + layer count, rank 0 / scene 0
 };
 size_t oar_engine_wide_lds_bytes();
 size_t oar_engine_wide_granules();

@@ -34,6 +34,9 @@ constexpr int WRQ = 3 * WE / NWG;                // 18 q|k|v rows per rank: 3 pe
 constexpr int WRO = WE / NWG;                    // 6 c_proj rows: 1 per compute wave
 constexpr int WRF = WF / NWG;                    // 24 hidden units: 4 per compute wave
 constexpr int NSP = kWideSplits;                 // key splits per head (H x NSP attention ranks)
+constexpr int NXCD = 8, RPX = NWG / NXCD;        // XCDs, ranks per XCD
+constexpr int HPX = WH / NXCD;                   // heads per XCD (4): RPX / 2 attention ranks per XCD
+constexpr int KG = 5;                            // 16-key passes of a wave in flight at once
 constexpr int PREC = 52;                         // floats per attention partial record: o[48] | m | l | pad
 static_assert(WE == 1536 && WRQ == 3 * CW && WRO == CW && WRF == 4 * CW && WE == 4 * CT && WH * NSP <= NWG && NSP == 4, "wide engine geometry");
 static_assert(WE == 12 * PT, "gathers of 1536 granules: 12 per poll lane");
@@ -51,10 +54,30 @@ constexpr int W_HS = W_WP + CW * PREC;        // gelu(c_fc) of this rank's 24 hi
 constexpr int W_MISC = W_HS + 32;
 constexpr int W_TOTAL = W_MISC + 16;
 
+// Hand-off polls of the poll waves: 0 = request everything once, then one missing granule per lane until it is there, then everything missing again
+// (two fabric round trips behind the producers); 1 = every round requests every slot again (one round trip behind)
+#ifndef UMGEN_WIDE_POLL
+#define UMGEN_WIDE_POLL 1
+#endif
+constexpr bool kPollAll = UMGEN_WIDE_POLL != 0;
+// Measurement builds (tools/build_variant.sh; results are garbage, only the step time means something):
+//   UMGEN_WIDE_EXP_NOPOLL: the poll waves do not wait (a layer without its six fabric hops)
+//   UMGEN_WIDE_EXP_NOLOAD: no weight / K/V request is made (a layer without its 57 MB)
+#ifndef UMGEN_WIDE_EXP_NOPOLL
+#define UMGEN_WIDE_EXP_NOPOLL 0
+#endif
+#ifndef UMGEN_WIDE_EXP_NOLOAD
+#define UMGEN_WIDE_EXP_NOLOAD 0
+#endif
+__device__ inline u32x4_t wld(const bf16_t* ubase, u32 off) {
+    if (UMGEN_WIDE_EXP_NOLOAD) { u32x4_t z; asm volatile("" : "=v"(z)); return z; }
+    return ldwu(ubase, off);
+}
+
 struct WRow { u32x4_t c[KC]; };
 __device__ inline void req_row(WRow& w, const bf16_t* W, long row, int lane) {
 #pragma unroll
-    for (int c = 0; c < KC; ++c) w.c[c] = ldwu(W + row * WE, (u32)(512 * c + 8 * lane));
+    for (int c = 0; c < KC; ++c) w.c[c] = wld(W + row * WE, (u32)(512 * c + 8 * lane));
 }
 struct XRegs { f32x2_t v[KC][4]; };
 // lane l's values k = 512 c + 8 l .. + 7 of a 1536-vector
@@ -133,16 +156,32 @@ __device__ inline void watt_fold_swap(WAtt& a) {
 
 }  // namespace
 
-template <typename TT>
+template <bool STAMPS, typename TT>
 __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32* ldsu = reinterpret_cast<u32*>(lds);
     const int tid0 = threadIdx.x;
-    if (tid0 == 0) ldsu[W_MISC] = atomicAdd(a.ticket, 1u) & (u32)(NWG - 1);
+    // rank = 32 x XCD + arrival order on the XCD (the census, engine.hip, has found 32 workgroups on each of the 8 XCDs): the q|k|v rows of heads 4 g .. 4 g + 3
+    // and their attention are on XCD g, so the q|k|v hand-off and the key quarters' merge stay inside the XCD's L2
+    const int xg = (int)xcc_id() & (NXCD - 1);
+    if (tid0 == 0) ldsu[W_MISC] = atomicAdd(a.ticket + xg, 1u) & (u32)(RPX - 1);
     wg_barrier();
-    const int r0 = __builtin_amdgcn_readfirstlane((int)ldsu[W_MISC]);     // this workgroup's rank
-    const bool poller = tid0 >= CT;
+    const int r0 = __builtin_amdgcn_readfirstlane(RPX * xg + (int)ldsu[W_MISC]);     // this workgroup's rank
+    // (wave-uniform, and the compiler is told so: the two roles are two loops over the layers, branched to once -- as `if (poller)` blocks inside ONE
+    //  loop every register of the compute waves that is assigned in one block and read in a later one stayed allocated around the whole loop, 40-90
+    //  spills with six K/V passes in flight.  The eight workgroup barriers of a layer are executed by both loops in the same order.)
+    const bool poller = __builtin_amdgcn_readfirstlane(tid0 >> 6) >= CW;
     Ctx c{a.err, false};
+    const bool timer = STAMPS && a.stamps != nullptr && r0 == 0 && tid0 == 0 && a.scene == 0;
+    unsigned long long t_prev = 0;
+    auto stamp = [&](int p) {      // UMGEN_DEBUG_TIMING: 100 MHz ticks per phase of rank 0's compute wave 0
+        if (STAMPS && timer) {
+            const unsigned long long t = wall_clock64();
+            if (p >= 0) a.stamps[p] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    stamp(-1);
     const int Lk = a.st->step;
     const u32 ep = a.st->epoch;
     float* xs = lds + W_XS;
@@ -158,102 +197,156 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
     u64* gxb = gatt + WE;
     u64* gpy = gxb + WE;
     const long kv_scene = (long)a.scene * a.kv_scene_stride;
-    // compute waves: the weights of the phases ahead
-    WRow wq[3], wo, wf[4];
-    u32x4_t wp[4][3];
-    int tid = tid0, r = r0;
-    int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    auto req_q = [&](const OarLayerDev& lw) {
+
+    if (poller) {
+        // =====================================================  POLL WAVES  =====================================================
+        for (int l = 0; l < a.n_layers; ++l) {
+            int tid = tid0, r = r0;
+            asm volatile("" : "+v"(tid));
+            asm volatile("" : "+s"(r));
+            const int pt = tid - CT;                                              // poll thread 0 .. 127
+            const int rl = r & (RPX - 1);
+            const bool att_rank = rl < HPX * NSP, owner = att_rank && (rl % NSP) == 0;
+            const int hh = HPX * (r / RPX) + rl / NSP;
+            const OarLayerDev lw = a.layers[l];
+            const u32 tg = ep + (u32)((a.scene * 64 + l) * 8);
+            // hand-off 1: x (+ the layer's ln_1 | ln_2 weights -> LDS: 3072 floats over 128 lanes)
+            {
+                float lnv[24];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) req_row(wq[i], lw.Wqkv, (long)WRQ * r + wave + CW * i, lane);
-    };
-    auto req_f = [&](const OarLayerDev& lw) {
+                for (int k = 0; k < 24; ++k) lnv[k] = ldg((pt + k * PT < WE ? lw.ln_a : lw.ln_b - WE) + pt + k * PT);
+                if (l == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) req_row(wf[i], lw.Wfc, (long)WRF * r + wave + CW * i, lane);
-    };
-    auto req_p = [&](const OarLayerDev& lw) {      // mlp c_proj slice of this rank, repacked [256 ranks][1536 rows][24]: rows tid, tid + 384, ...
+                    for (int k = 0; k < 12; ++k) xs[pt + k * PT] = ldg(a.xdec + (long)a.scene * WE + pt + k * PT);
+                } else {
+                    if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<12, kPollAll>(c, tid, gx, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 0, [&](int k, float v) { xs[pt + k * PT] = v; });
+                }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int k = 0; k < 24; ++k) lds[W_LN + pt + k * PT] = lnv[k];
+            }
+            wg_barrier();      // B1
+            // hand-off 2: q_h | k_h | v_h of the attention ranks (lanes 0 .. 127: values 0 .. 127, lanes 0 .. 15 also 128 .. 143)
+            if (att_rank) {
+                auto src = [&](int k) { const int e = min(pt + k * PT, 3 * kHeadDim - 1); return (u32)((e / kHeadDim) * WE + hh * kHeadDim + e % kHeadDim); };
+                if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<2, kPollAll>(c, tid, gqkv, pt < 16 ? 3u : 1u, src, tg + 1, [&](int k, float v) { qs[pt + k * PT] = v; });
+            }
+            wg_barrier();      // B2
+            wg_barrier();      // B3
+            // hand-off 3: the owner's four quarters (4 records x 50 values = 200 granules over 128 lanes)
+            if (owner) {
+                auto src = [&](int k) { const int f = min(pt + k * PT, NSP * (kHeadDim + 2) - 1); return (u32)((f / (kHeadDim + 2)) * PREC + f % (kHeadDim + 2)); };
+                if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<2, kPollAll>(c, tid, gpart + (long)(hh * NSP) * PREC, pt + PT < NSP * (kHeadDim + 2) ? 3u : 1u, src, tg + 2,
+                                     [&](int k, float v) { const int f = pt + k * PT; lds[W_SB + (f / (kHeadDim + 2)) * PREC + f % (kHeadDim + 2)] = v; });
+            }
+            wg_barrier();      // B4
+            // hand-off 4: the 1536 attention outputs
+            if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<12, kPollAll>(c, tid, gatt, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 3, [&](int k, float v) { as[pt + k * PT] = v; });
+            wg_barrier();      // B5
+            // hand-off 5: x'
+            if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<12, kPollAll>(c, tid, gxb, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 4, [&](int k, float v) { xb[pt + k * PT] = v; });
+            wg_barrier();      // B6
+            wg_barrier();      // B7
+            // hand-off 6: the 256 partials of this rank's 6 rows (slot f = producer p x 6 + row i: 1536 granules, 12 per poll lane)
+            if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<12, kPollAll>(c, tid, gpy + WRO * r, 0xfffu, [&](int k) { const u32 f = (u32)(pt + k * PT); return (f / (u32)WRO) * (u32)WE + f % (u32)WRO; }, tg + 5,
+                                  [&](int k, float v) { lds[W_PT + pt + k * PT] = v; });
+            wg_barrier();      // B8
+        }
+        return;
+    }
+
+    // =====================================================  COMPUTE WAVES  =====================================================
+    // the weights of the phases ahead, in registers
+    WRow wq[3];        // (the only weights alive across the layer boundary)
+    {
+        const int lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) wp[i][j] = ldwu(lw.Wp2 + ((long)r * WE + tid + CT * i) * WRF, (u32)(8 * j));
-    };
-    if (!poller) req_q(a.layers[0]);
+        for (int i = 0; i < 3; ++i) {
+            const int j = WRQ * (r0 & (RPX - 1)) + wave + CW * i;
+            req_row(wq[i], a.layers[0].Wqkv, (long)((j / (HPX * kHeadDim)) * WE + HPX * kHeadDim * (r0 / RPX) + j % (HPX * kHeadDim)), lane);
+        }
+    }
     for (int l = 0; l < a.n_layers; ++l) {
         // (everything of a layer is derived from these INSIDE the layer: laundered, so that no loop-invariant row / granule address is hoisted into
         //  registers -- 64-bit addresses in VGPRs were what the register allocator spilled)
-        tid = tid0; r = r0;
+        int tid = tid0, r = r0;
         asm volatile("" : "+v"(tid));
         asm volatile("" : "+s"(r));
-        lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int pt = tid - CT;                                              // poll thread 0 .. 127
-        const bool att_rank = r < WH * NSP, owner = att_rank && (r % NSP) == 0;
-        const int hh = r / NSP, sp = r % NSP;                                 // (attention ranks)
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int rl = r & (RPX - 1), xq = r / RPX;                             // rank on the XCD, XCD
+        const bool att_rank = rl < HPX * NSP, owner = att_rank && (rl % NSP) == 0;
+        const int hh = HPX * xq + rl / NSP, sp = rl % NSP;                    // (attention ranks: head, key quarter)
+        // q|k|v rows of this rank: 18 of the 576 rows {q, k, v} x heads 4 xq .. 4 xq + 3 (3 per compute wave)
+        auto qkv_row = [&](int i) { const int j = WRQ * rl + wave + CW * i; return (j / (HPX * kHeadDim)) * WE + HPX * kHeadDim * xq + j % (HPX * kHeadDim); };
         const OarLayerDev lw = a.layers[l];
         const u32 tg = ep + (u32)((a.scene * 64 + l) * 8);
-        float bq[3], bo = 0.f;
-        // ---------------- hand-off 1: x ----------------
-        if (poller) {
-            float lnv[24];      // ln_1 | ln_2 weights of the layer -> LDS (3072 floats over 128 lanes)
+        // attention geometry of this rank (head hh, key quarter sp): the compute waves split the quarter's keys in passes of 16 keys (4 lanes per key)
+        const int nk = Lk + 1;
+        const int spn = ((((nk + NSP - 1) / NSP) + KPW - 1) / KPW) * KPW;        // keys per quarter
+        const int span = ((((spn + CW - 1) / CW) + KPW - 1) / KPW) * KPW;        // keys per wave
+        const int nch = span / KPW;
+        const int k_lo = sp * spn + wave * span, k_hi = min(min(nk, (sp + 1) * spn), k_lo + span);
+        const int piece = lane & (LPK - 1), kg = lane / LPK;
+        auto dim_of = [&](int j) { return j < 4 ? piece * 8 + 2 * j : 32 + piece * 4 + 2 * (j - 4); };
+        auto kv_req = [&](KVPiece& kk, KVPiece& vv, int ci) {
+            const bf16_t* kbase = a.kvcache + (long)l * a.kv_layer_stride + kv_scene + (long)hh * a.Lmax * kHeadDim;
+            const bf16_t* vbase = kbase + (long)WH * a.Lmax * kHeadDim;
+            const u32 off = (u32)min(k_lo + KPW * min(ci, nch - 1) + kg, a.Lmax - 1) * (u32)kHeadDim;
+            kk.a = wld(kbase, off + (u32)piece * 8u);
+            vv.a = wld(vbase, off + (u32)piece * 8u);
+            if (UMGEN_WIDE_EXP_NOLOAD) { asm volatile("" : "=v"(kk.b)); asm volatile("" : "=v"(vv.b)); }
+            else { kk.b = ldwu2(kbase, off + 32u + (u32)piece * 4u); vv.b = ldwu2(vbase, off + 32u + (u32)piece * 4u); }
+        };
+        // ---------------- (hand-off 1: x) ----------------
+        // Requests go out at the START of the waits, one to two phases ahead of their use, in the order they are needed (a wave's loads return in order):
+        //   here, under the x hand-off:      K/V of the cached keys (they do not depend on this layer's q: the first KG passes, 80 keys per wave = 1920
+        //                                    positions; the passes behind them pay a round trip each), the c_proj row
+        //   behind P1, under q|k|v:          the four c_fc rows, the next layer's q|k|v rows (this layer's are used up)
+        //   behind the keys, under partials: the mlp c_proj slice
+        // so that the memory pipe is busy through the whole layer, not only between the attention and P4 (where a layer's 57 MB were 8 of its 30 us).
+        float bq[3];
 #pragma unroll
-            for (int k = 0; k < 24; ++k) lnv[k] = ldg((pt + k * PT < WE ? lw.ln_a : lw.ln_b - WE) + pt + k * PT);
-            if (l == 0) {
+        for (int i = 0; i < 3; ++i) bq[i] = ldg(lw.bqkv + qkv_row(i));
+        const float bo = ldg(lw.bo + WRO * r + wave);
+        KVPiece kc[KG], vc[KG];
+        if (att_rank) {
 #pragma unroll
-                for (int k = 0; k < 12; ++k) xs[pt + k * PT] = ldg(a.xdec + (long)a.scene * WE + pt + k * PT);
-            } else {
-                poll_ms<12>(c, tid, gx, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 0, [&](int k, float v) { xs[pt + k * PT] = v; });
-            }
-#pragma unroll
-            for (int k = 0; k < 24; ++k) lds[W_LN + pt + k * PT] = lnv[k];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) bq[i] = ldg(lw.bqkv + WRQ * r + wave + CW * i);
-            bo = ldg(lw.bo + WRO * r + wave);
-            req_row(wo, lw.Wo, (long)WRO * r + wave, lane);
+            for (int i = 0; i < KG; ++i) kv_req(kc[i], vc[i], i);
         }
+        WRow wo;
+        req_row(wo, lw.Wo, (long)WRO * r + wave, lane);
         wg_barrier();      // B1
-        // ---------------- P1: LN + this rank's 18 q|k|v rows | hand-off 2: q_h | k_h | v_h of the attention ranks ----------------
-        if (!poller) {
+        stamp(0);
+        // ---------------- P1: LN + this rank's 18 q|k|v rows (hand-off 2: q_h | k_h | v_h of the attention ranks) ----------------
+        {
             XRegs x;
             load_x(xs, lane, x);
             ln_regs(x, lds + W_LN, lane);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float v = row_dot<TT>(wq[i], x) + bq[i];
-                const int n = WRQ * r + wave + CW * i;
+                const int n = qkv_row(i);
                 if (lane == 0) {
-                    put_far(gqkv, (u32)n, tg + 1, v);
+                    put_local(gqkv, (u32)n, tg + 1, v);
                     if (n >= WE) {   // K / V rows of the new token: 16 bits into the cache (head-major [2][H][Lmax][48])
                         const int cc = n - WE, kvsel = cc / WE, hc = cc % WE;
                         (a.kvcache + (long)l * a.kv_layer_stride + kv_scene)[(u32)(((kvsel * WH + hc / kHeadDim) * a.Lmax + Lk) * kHeadDim + hc % kHeadDim)] = bits16<TT>(v);
                     }
                 }
             }
-        } else if (att_rank) {
-            // lanes 0 .. 127: values 0 .. 127 of q_h | k_h | v_h, lanes 0 .. 15 also 128 .. 143
-            auto src = [&](int k) { const int e = min(pt + k * PT, 3 * kHeadDim - 1); return (u32)((e / kHeadDim) * WE + hh * kHeadDim + e % kHeadDim); };
-            poll_ms<2>(c, tid, gqkv, pt < 16 ? 3u : 1u, src, tg + 1, [&](int k, float v) { qs[pt + k * PT] = v; });
         }
+        WRow wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) req_row(wf[i], lw.Wfc, (long)WRF * r + wave + CW * i, lane);
+        {
+            const OarLayerDev& ln = a.layers[min(l + 1, a.n_layers - 1)];      // (the last layer requests its own rows again: unconditional, no second loop form)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) req_row(wq[i], ln.Wqkv, (long)qkv_row(i), lane);
+        }
+        stamp(1);
         wg_barrier();      // B2
+        stamp(2);
         // ---------------- P2: attention of (head hh, key quarter sp): the compute waves split the quarter's keys ----------------
-        if (!poller && att_rank) {
-            const int nk = Lk + 1;
-            const int spn = ((((nk + NSP - 1) / NSP) + KPW - 1) / KPW) * KPW;        // keys per quarter
-            const int span = ((((spn + CW - 1) / CW) + KPW - 1) / KPW) * KPW;        // keys per wave
-            const int nch = span / KPW;
-            const int k_lo = sp * spn + wave * span, k_hi = min(min(nk, (sp + 1) * spn), k_lo + span);
-            const int piece = lane & (LPK - 1), kg = lane / LPK;
-            auto dim_of = [&](int j) { return j < 4 ? piece * 8 + 2 * j : 32 + piece * 4 + 2 * (j - 4); };
-            const bf16_t* kbase = a.kvcache + (long)l * a.kv_layer_stride + kv_scene + (long)hh * a.Lmax * kHeadDim;
-            const bf16_t* vbase = kbase + (long)WH * a.Lmax * kHeadDim;
-            KVPiece kc[2], vc[2];      // two 16-key passes: one in the registers being used, one in flight (plain loads: the compiler counts them)
-            auto kv_req = [&](int buf, int ci) {
-                const u32 off = (u32)min(k_lo + KPW * min(ci, nch - 1) + kg, a.Lmax - 1) * (u32)kHeadDim;
-                kc[buf].a = ldwu(kbase, off + (u32)piece * 8u);
-                kc[buf].b = ldwu2(kbase, off + 32u + (u32)piece * 4u);
-                vc[buf].a = ldwu(vbase, off + (u32)piece * 8u);
-                vc[buf].b = ldwu2(vbase, off + 32u + (u32)piece * 4u);
-            };
-            kv_req(0, 0);
+        if (att_rank) {
             WAtt st;
             st.m = -INFINITY; st.l = 0.f;
             f32x2_t q2[6];
@@ -297,11 +390,13 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                     st.m = m_new;
                 }
             };
-            for (int ci = 0; ci < nch; ci += 2) {
-                kv_req(1, ci + 1);
-                chunk(kc[0], vc[0], ci);
-                kv_req(0, ci + 2);
-                if (ci + 1 < nch) chunk(kc[1], vc[1], ci + 1);
+#pragma unroll
+            for (int i = 0; i < KG; ++i)
+                if (i < nch) chunk(kc[i], vc[i], i);
+            for (int ci = KG; ci < nch; ++ci) {      // (contexts beyond KG x 16 keys per wave: a round trip per pass)
+                KVPiece kt, vt;
+                kv_req(kt, vt, ci);
+                chunk(kt, vt, ci);
             }
             watt_fold_dpp<0x124>(st);
             watt_fold_dpp<0x128>(st);
@@ -314,10 +409,16 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                 if (lane == 0) { wpz[48] = st.m; wpz[49] = st.l; }
             }
         }
-        if (!poller) { req_f(lw); req_p(lw); }      // (behind the key loop: they stream under the next three hand-offs)
+        u32x4_t wp[4][3];      // mlp c_proj slice of this rank, repacked [256 ranks][1536 rows][24]: rows tid, tid + 384, ...
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wp[i][j] = wld(lw.Wp2 + ((long)r * WE + tid + CT * i) * WRF, (u32)(8 * j));
+        stamp(3);
         wg_barrier();      // B3
-        // ---------------- the compute waves' partials merged in wave order -> this quarter's partial (unnormalised o, m, l) | hand-off 3: the owner's four quarters ----------------
-        if (!poller && att_rank && tid < kHeadDim + 2) {
+        stamp(4);
+        // ---------------- the compute waves' partials merged in wave order -> this quarter's partial (unnormalised o, m, l) (hand-off 3: the owner's four quarters) ----------------
+        if (att_rank && tid < kHeadDim + 2) {
             const float* wz = lds + W_WP;
             float M = wz[48];
 #pragma unroll
@@ -329,17 +430,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                 Ls = fmaf(e, wz[ww * PREC + 49], Ls);
                 if (tid < kHeadDim) o = fmaf(e, wz[ww * PREC + tid], o);
             }
-            put_far(gpart + (long)r * PREC, (u32)tid, tg + 2, tid < kHeadDim ? o : (tid == kHeadDim ? M : Ls));
-        }
-        if (poller && owner) {
-            // 4 records x 50 values = 200 granules over 128 lanes
-            auto src = [&](int k) { const int f = min(pt + k * PT, NSP * (kHeadDim + 2) - 1); return (u32)((f / (kHeadDim + 2)) * PREC + f % (kHeadDim + 2)); };
-            poll_ms<2>(c, tid, gpart + (long)r * PREC, pt + PT < NSP * (kHeadDim + 2) ? 3u : 1u, src, tg + 2,
-                       [&](int k, float v) { const int f = pt + k * PT; lds[W_SB + (f / (kHeadDim + 2)) * PREC + f % (kHeadDim + 2)] = v; });
+            put_local(gpart + (long)(hh * NSP + sp) * PREC, (u32)tid, tg + 2, tid < kHeadDim ? o : (tid == kHeadDim ? M : Ls));
         }
         wg_barrier();      // B4
-        // ---------------- the owner merges its head's four quarters -> attention output | hand-off 4: the 1536 attention outputs ----------------
-        if (!poller && owner && tid < kHeadDim) {
+        stamp(5);
+        // ---------------- the owner merges its head's four quarters -> attention output (hand-off 4: the 1536 attention outputs) ----------------
+        if (owner && tid < kHeadDim) {
             const float* p0 = lds + W_SB;
             float M = p0[48];
 #pragma unroll
@@ -353,22 +449,21 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
             }
             put_far(gatt, (u32)(hh * kHeadDim + tid), tg + 3, o / Ls);
         }
-        if (poller) poll_ms<12>(c, tid, gatt, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 3, [&](int k, float v) { as[pt + k * PT] = v; });
         wg_barrier();      // B5
-        // ---------------- P3: c_proj row 6 r + wave + residual -> x' | hand-off 5: x' ----------------
-        if (!poller) {
+        stamp(6);
+        // ---------------- P3: c_proj row 6 r + wave + residual -> x' (hand-off 5: x') ----------------
+        {
             XRegs x;
             load_x(as, lane, x);
             const int n = WRO * r + wave;
             const float v = row_dot<TT>(wo, x) + bo;
             if (lane == 0) put_far(gxb, (u32)n, tg + 4, xs[n] + v);
-            if (l + 1 < a.n_layers) req_q(a.layers[l + 1]);
-        } else {
-            poll_ms<12>(c, tid, gxb, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 4, [&](int k, float v) { xb[pt + k * PT] = v; });
         }
+        stamp(7);
         wg_barrier();      // B6
+        stamp(8);
         // ---------------- P4: LN + this rank's 24 hidden units + GELU ----------------
-        if (!poller) {
+        {
             XRegs x;
             load_x(xb, lane, x);
             ln_regs(x, lds + W_LN + WE, lane);
@@ -378,9 +473,11 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                 if (lane == 0) hs[wave + CW * i] = gelu_erf(v);
             }
         }
+        stamp(9);
         wg_barrier();      // B7
-        // ---------------- this rank's partial sums of the 1536 mlp c_proj outputs | hand-off 6: the 256 partials of this rank's 6 rows ----------------
-        if (!poller) {
+        stamp(10);
+        // ---------------- this rank's partial sums of the 1536 mlp c_proj outputs (hand-off 6: the 256 partials of this rank's 6 rows) ----------------
+        {
             f32x2_t hq[3][4];
 #pragma unroll
             for (int j = 0; j < 3; ++j) load8p(hs + 8 * j, hq[j]);
@@ -391,12 +488,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                 for (int j = 0; j < 3; ++j) acc = dot8<TT>(wp[i][j], hq[j], acc);
                 put_far(gpy + (long)r * WE, (u32)(tid + CT * i), tg + 5, acc.x + acc.y);
             }
-        } else {
-            // slot f = producer p x 6 + row i (1536 granules, 12 per poll lane)
-            poll_ms<12>(c, tid, gpy + WRO * r, 0xfffu, [&](int k) { const u32 f = (u32)(pt + k * PT); return (f / (u32)WRO) * (u32)WE + f % (u32)WRO; }, tg + 5,
-                        [&](int k, float v) { lds[W_PT + pt + k * PT] = v; });
         }
+        stamp(11);
         wg_barrier();      // B8
+        stamp(12);
         // ---------------- P5: x'' = x' + the 256 partial sums (four lanes add 64 producers each, ascending; then the quad in a fixed order) ----------------
         if (tid < 4 * WRO) {
             const int i = tid >> 2, g4 = tid & 3;
@@ -411,6 +506,8 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                 else put_far(gx, (u32)n, tg + 8, xn);
             }
         }
+        stamp(13);
+        if (STAMPS && timer) a.stamps[15] += 1;
         // (no barrier: the next layer's gathers cannot complete before every rank -- this one included -- has published its x'' rows, and
         //  W_PT / xb are next written behind B6 / B8 of the next layer)
     }
@@ -435,7 +532,8 @@ hipError_t launch_oar_engine_wide_census(hipStream_t s, unsigned int* d_counts16
 }
 
 hipError_t oar_engine_wide_prepare() {
-    for (const void* f : {reinterpret_cast<const void*>(oar_engine_wide_kernel<bf16_t>), reinterpret_cast<const void*>(oar_engine_wide_kernel<f16_t>),
+    for (const void* f : {reinterpret_cast<const void*>(oar_engine_wide_kernel<false, bf16_t>), reinterpret_cast<const void*>(oar_engine_wide_kernel<false, f16_t>),
+                          reinterpret_cast<const void*>(oar_engine_wide_kernel<true, bf16_t>), reinterpret_cast<const void*>(oar_engine_wide_kernel<true, f16_t>),
                           reinterpret_cast<const void*>(oar_engine_wide_census_kernel)}) {
         hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oar_engine_wide_lds_bytes());
         if (rc != hipSuccess) return rc;
@@ -445,8 +543,14 @@ hipError_t oar_engine_wide_prepare() {
 
 hipError_t launch_oar_engine_wide(hipStream_t s, const OarWideArgs& a) {
     const dim3 grid(NWG), block(kEngThreads);
-    if (a.fp16) hipLaunchKernelGGL((oar_engine_wide_kernel<f16_t>), grid, block, oar_engine_wide_lds_bytes(), s, a);
-    else hipLaunchKernelGGL((oar_engine_wide_kernel<bf16_t>), grid, block, oar_engine_wide_lds_bytes(), s, a);
+    const size_t shm = oar_engine_wide_lds_bytes();
+    if (a.stamps) {
+        if (a.fp16) hipLaunchKernelGGL((oar_engine_wide_kernel<true, f16_t>), grid, block, shm, s, a);
+        else hipLaunchKernelGGL((oar_engine_wide_kernel<true, bf16_t>), grid, block, shm, s, a);
+    } else {
+        if (a.fp16) hipLaunchKernelGGL((oar_engine_wide_kernel<false, f16_t>), grid, block, shm, s, a);
+        else hipLaunchKernelGGL((oar_engine_wide_kernel<false, bf16_t>), grid, block, shm, s, a);
+    }
     return hipGetLastError();
 }
 
