@@ -312,6 +312,47 @@ __device__ inline void poll_ms(Ctx& c, int tid, const u64* g, u32 need, IDX idx,
     }
 }
 
+// The same hand-off with TWO requests of every slot in flight, `stagger` x 64 clocks apart (half a fabric round trip): a request that just misses the
+// producer's store is followed by one half a round trip behind it instead of a whole one.  A wave's loads return in order: s_waitcnt vmcnt(PER) is "the
+// older set is back".  Every round requests every slot (exact counts); both sets are drained before the registers are given back.
+template <int PER, typename IDX, typename SINK>
+__device__ inline void poll_stag(Ctx& c, int tid, const u64* g, u32 need, IDX idx, u32 tag, int stagger, SINK sink) {
+    if (c.failed || !__any(need != 0u)) return;
+    g = uniform_ptr(g);
+    u32 got = 0;
+    u64 va[PER], vb[PER];
+    auto issue = [&](u64 (&v)[PER]) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) poll_issue(v[k], g, idx(k));
+    };
+    auto older_back = [&](u64 (&v)[PER]) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+#pragma unroll
+        for (int k = 0; k < PER; ++k) asm volatile("" : "+v"(v[k]));
+    };
+    auto check = [&](const u64 (&v)[PER]) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if ((((need & ~got) >> k) & 1u) && (u32)(v[k] >> 32) == tag) { sink(k, __uint_as_float((u32)v[k])); got |= 1u << k; }
+        return !__any(got != need);
+    };
+    issue(va);
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    for (u32 spins = 0;;) {
+        issue(vb);
+        older_back(va);
+        if (check(va)) break;
+        issue(va);
+        older_back(vb);
+        if (check(vb)) break;
+        if (++spins > kSpinLimit / 8) { if ((tid & 63) == 0) atomicExch(c.err, tag | 0x80000000u); c.failed = true; break; }
+        if ((spins & 63u) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { c.failed = true; break; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { asm volatile("" : "+v"(va[k])); asm volatile("" : "+v"(vb[k])); }
+}
+
 }  // namespace
 
 }  // namespace umgen

@@ -51,15 +51,26 @@ constexpr int W_SB = W_PT + NWG * WRO;        // the four key quarters' partials
 constexpr int W_QS = W_SB + NSP * PREC;       // q_h | k_h | v_h [144 -> 160]
 constexpr int W_WP = W_QS + 160;              // the compute waves' attention partials [6][52]
 constexpr int W_HS = W_WP + CW * PREC;        // gelu(c_fc) of this rank's 24 hidden units [24 -> 32]
-constexpr int W_MISC = W_HS + 32;
+constexpr int W_XO = W_HS + 32;              // the six c_proj results of the workgroup (padded x' layouts) [16]
+constexpr int W_MISC = W_XO + 16;
 constexpr int W_TOTAL = W_MISC + 16;
 
 // Hand-off polls of the poll waves: 0 = request everything once, then one missing granule per lane until it is there, then everything missing again
-// (two fabric round trips behind the producers); 1 = every round requests every slot again (one round trip behind)
+// (two fabric round trips behind the producers); 1 = every round requests every slot again (one round trip behind); 2 = the far hand-offs (x, attention
+// output, x', mlp partial sums) with two requests of every slot in flight, UMGEN_WIDE_STAGGER x 64 clocks apart (oar_common.h poll_stag)
 #ifndef UMGEN_WIDE_POLL
 #define UMGEN_WIDE_POLL 1
 #endif
 constexpr bool kPollAll = UMGEN_WIDE_POLL != 0;
+constexpr bool kPollStag = UMGEN_WIDE_POLL == 2;
+#ifndef UMGEN_WIDE_STAGGER
+#define UMGEN_WIDE_STAGGER 24
+#endif
+template <typename IDX, typename SINK>
+__device__ inline void poll_far(Ctx& c, int tid, const u64* g, IDX idx, u32 tag, SINK sink) {
+    if (kPollStag) poll_stag<12>(c, tid, g, 0xfffu, idx, tag, UMGEN_WIDE_STAGGER, sink);
+    else poll_ms<12, kPollAll>(c, tid, g, 0xfffu, idx, tag, sink);
+}
 // Measurement builds (tools/build_variant.sh; results are garbage, only the step time means something):
 //   UMGEN_WIDE_EXP_NOPOLL: the poll waves do not wait (a layer without its six fabric hops)
 //   UMGEN_WIDE_EXP_NOLOAD: no weight / K/V request is made (a layer without its 57 MB)
@@ -69,6 +80,24 @@ constexpr bool kPollAll = UMGEN_WIDE_POLL != 0;
 #ifndef UMGEN_WIDE_EXP_NOLOAD
 #define UMGEN_WIDE_EXP_NOLOAD 0
 #endif
+// Granules per rank in the x / x' buffers: 6 = compact (a rank's 48 bytes share 64-byte sectors with its neighbours'), 8 / 16 = every rank writes whole
+// 64 / 128-byte pieces with ONE store instruction (x': its six rows' results collected through LDS behind one more workgroup barrier)
+#ifndef UMGEN_WIDE_PAD
+#define UMGEN_WIDE_PAD 16
+#endif
+// Where the weight requests of a layer go out (a poll's answer queues behind whatever the XCD's memory link still has to deliver):
+//   0: at the start of the waits -- K/V + c_proj row under the x hand-off, c_fc + next q|k|v rows under q|k|v, the mlp slice behind the keys
+//   1: behind the far hand-offs  -- K/V + c_proj + c_fc rows right behind B1 (x is there), the mlp slice behind P1, the next q|k|v rows behind B6 (x' is there):
+//      the link works through them during P1 / q|k|v / attention / quarters (hand-offs inside the XCD's L2) and during P4
+#ifndef UMGEN_WIDE_ORDER
+#define UMGEN_WIDE_ORDER 2
+#endif
+//   4: as 2, the c_fc rows behind the keys too          5: as 2, the next q|k|v rows behind B8 (the mlp partial sums are there)
+//   2: as 0, the next q|k|v rows behind B6 instead      3: as 0, the mlp slice with the c_fc rows behind P1, the next q|k|v rows behind the keys
+constexpr int kOrder = UMGEN_WIDE_ORDER;
+constexpr int XPAD = UMGEN_WIDE_PAD;
+constexpr int XGR = 256 * 16;      // granules reserved for each of the x / x' buffers
+__device__ inline u32 xslot(u32 n) { return XPAD == 6 ? n : (n / 6u) * (u32)XPAD + n % 6u; }
 __device__ inline u32x4_t wld(const bf16_t* ubase, u32 off) {
     if (UMGEN_WIDE_EXP_NOLOAD) { u32x4_t z; asm volatile("" : "=v"(z)); return z; }
     return ldwu(ubase, off);
@@ -191,11 +220,11 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
     float* qs = lds + W_QS;
     // granule buffers (shared by a call's scenes, one launch behind the other): x | q|k|v | key-quarter partials | attention output | x' | mlp partial sums [256][1536]
     u64* gx = a.gran;
-    u64* gqkv = gx + WE;
+    u64* gqkv = gx + XGR;
     u64* gpart = gqkv + 3 * WE;
     u64* gatt = gpart + WH * NSP * PREC;
     u64* gxb = gatt + WE;
-    u64* gpy = gxb + WE;
+    u64* gpy = gxb + XGR;
     const long kv_scene = (long)a.scene * a.kv_scene_stride;
 
     if (poller) {
@@ -219,7 +248,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
 #pragma unroll
                     for (int k = 0; k < 12; ++k) xs[pt + k * PT] = ldg(a.xdec + (long)a.scene * WE + pt + k * PT);
                 } else {
-                    if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<12, kPollAll>(c, tid, gx, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 0, [&](int k, float v) { xs[pt + k * PT] = v; });
+                    if (!UMGEN_WIDE_EXP_NOPOLL) poll_far(c, tid, gx, [&](int k) { return xslot((u32)(pt + k * PT)); }, tg + 0, [&](int k, float v) { xs[pt + k * PT] = v; });
                 }
 #pragma unroll
                 for (int k = 0; k < 24; ++k) lds[W_LN + pt + k * PT] = lnv[k];
@@ -240,14 +269,15 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
             }
             wg_barrier();      // B4
             // hand-off 4: the 1536 attention outputs
-            if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<12, kPollAll>(c, tid, gatt, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 3, [&](int k, float v) { as[pt + k * PT] = v; });
+            if (!UMGEN_WIDE_EXP_NOPOLL) poll_far(c, tid, gatt, [&](int k) { return (u32)(pt + k * PT); }, tg + 3, [&](int k, float v) { as[pt + k * PT] = v; });
             wg_barrier();      // B5
+            if (XPAD != 6) wg_barrier();      // B5b
             // hand-off 5: x'
-            if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<12, kPollAll>(c, tid, gxb, 0xfffu, [&](int k) { return (u32)(pt + k * PT); }, tg + 4, [&](int k, float v) { xb[pt + k * PT] = v; });
+            if (!UMGEN_WIDE_EXP_NOPOLL) poll_far(c, tid, gxb, [&](int k) { return xslot((u32)(pt + k * PT)); }, tg + 4, [&](int k, float v) { xb[pt + k * PT] = v; });
             wg_barrier();      // B6
             wg_barrier();      // B7
             // hand-off 6: the 256 partials of this rank's 6 rows (slot f = producer p x 6 + row i: 1536 granules, 12 per poll lane)
-            if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<12, kPollAll>(c, tid, gpy + WRO * r, 0xfffu, [&](int k) { const u32 f = (u32)(pt + k * PT); return (f / (u32)WRO) * (u32)WE + f % (u32)WRO; }, tg + 5,
+            if (!UMGEN_WIDE_EXP_NOPOLL) poll_far(c, tid, gpy + WRO * r, [&](int k) { const u32 f = (u32)(pt + k * PT); return (f / (u32)WRO) * (u32)WE + f % (u32)WRO; }, tg + 5,
                                   [&](int k, float v) { lds[W_PT + pt + k * PT] = v; });
             wg_barrier();      // B8
         }
@@ -297,25 +327,41 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
             else { kk.b = ldwu2(kbase, off + 32u + (u32)piece * 4u); vv.b = ldwu2(vbase, off + 32u + (u32)piece * 4u); }
         };
         // ---------------- (hand-off 1: x) ----------------
-        // Requests go out at the START of the waits, one to two phases ahead of their use, in the order they are needed (a wave's loads return in order):
-        //   here, under the x hand-off:      K/V of the cached keys (they do not depend on this layer's q: the first KG passes, 80 keys per wave = 1920
-        //                                    positions; the passes behind them pay a round trip each), the c_proj row
-        //   behind P1, under q|k|v:          the four c_fc rows, the next layer's q|k|v rows (this layer's are used up)
-        //   behind the keys, under partials: the mlp c_proj slice
-        // so that the memory pipe is busy through the whole layer, not only between the attention and P4 (where a layer's 57 MB were 8 of its 30 us).
+        // (K/V of the cached keys do not depend on this layer's q: the first KG passes, 80 keys per wave = 1920 positions, are requested ahead; the passes
+        //  behind them pay a round trip each.  Where the requests go out: kOrder above.)
         float bq[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) bq[i] = ldg(lw.bqkv + qkv_row(i));
         const float bo = ldg(lw.bo + WRO * r + wave);
         KVPiece kc[KG], vc[KG];
-        if (att_rank) {
+        WRow wo, wf[4];
+        u32x4_t wp[4][3];      // mlp c_proj slice of this rank, repacked [256 ranks][1536 rows][24]: rows tid, tid + 384, ...
+        auto req_kv_o = [&]() {
+            if (att_rank) {
 #pragma unroll
-            for (int i = 0; i < KG; ++i) kv_req(kc[i], vc[i], i);
-        }
-        WRow wo;
-        req_row(wo, lw.Wo, (long)WRO * r + wave, lane);
+                for (int i = 0; i < KG; ++i) kv_req(kc[i], vc[i], i);
+            }
+            req_row(wo, lw.Wo, (long)WRO * r + wave, lane);
+        };
+        auto req_f = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) req_row(wf[i], lw.Wfc, (long)WRF * r + wave + CW * i, lane);
+        };
+        auto req_p = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) wp[i][j] = wld(lw.Wp2 + ((long)r * WE + tid + CT * i) * WRF, (u32)(8 * j));
+        };
+        auto req_q_next = [&]() {
+            const OarLayerDev& ln = a.layers[min(l + 1, a.n_layers - 1)];      // (the last layer requests its own rows again: unconditional, no second loop form)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) req_row(wq[i], ln.Wqkv, (long)qkv_row(i), lane);
+        };
+        if (kOrder != 1) req_kv_o();
         wg_barrier();      // B1
         stamp(0);
+        if (kOrder == 1) { req_kv_o(); req_f(); }
         // ---------------- P1: LN + this rank's 18 q|k|v rows (hand-off 2: q_h | k_h | v_h of the attention ranks) ----------------
         {
             XRegs x;
@@ -334,14 +380,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                 }
             }
         }
-        WRow wf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) req_row(wf[i], lw.Wfc, (long)WRF * r + wave + CW * i, lane);
-        {
-            const OarLayerDev& ln = a.layers[min(l + 1, a.n_layers - 1)];      // (the last layer requests its own rows again: unconditional, no second loop form)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) req_row(wq[i], ln.Wqkv, (long)qkv_row(i), lane);
-        }
+        if (kOrder == 0) { req_f(); req_q_next(); }
+        if (kOrder == 1) req_p();
+        if (kOrder == 2 || kOrder == 5) req_f();
+        if (kOrder == 3) { req_f(); req_p(); }
         stamp(1);
         wg_barrier();      // B2
         stamp(2);
@@ -409,11 +451,9 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                 if (lane == 0) { wpz[48] = st.m; wpz[49] = st.l; }
             }
         }
-        u32x4_t wp[4][3];      // mlp c_proj slice of this rank, repacked [256 ranks][1536 rows][24]: rows tid, tid + 384, ...
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) wp[i][j] = wld(lw.Wp2 + ((long)r * WE + tid + CT * i) * WRF, (u32)(8 * j));
+        if (kOrder == 4) req_f();
+        if (kOrder == 0 || kOrder == 2 || kOrder == 4 || kOrder == 5) req_p();
+        if (kOrder == 3) req_q_next();
         stamp(3);
         wg_barrier();      // B3
         stamp(4);
@@ -457,11 +497,20 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
             load_x(as, lane, x);
             const int n = WRO * r + wave;
             const float v = row_dot<TT>(wo, x) + bo;
-            if (lane == 0) put_far(gxb, (u32)n, tg + 4, xs[n] + v);
+            if (XPAD == 6) {
+                if (lane == 0) put_far(gxb, (u32)n, tg + 4, xs[n] + v);
+            } else {
+                if (lane == 0) lds[W_XO + wave] = xs[n] + v;
+            }
+        }
+        if (XPAD != 6) {
+            wg_barrier();      // B5b
+            if (tid < XPAD) put_far(gxb, (u32)(XPAD * r + tid), tg + 4, tid < WRO ? lds[W_XO + tid] : 0.f);
         }
         stamp(7);
         wg_barrier();      // B6
         stamp(8);
+        if (kOrder == 1 || kOrder == 2 || kOrder == 4) req_q_next();
         // ---------------- P4: LN + this rank's 24 hidden units + GELU ----------------
         {
             XRegs x;
@@ -492,9 +541,10 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
         stamp(11);
         wg_barrier();      // B8
         stamp(12);
+        if (kOrder == 5) req_q_next();
         // ---------------- P5: x'' = x' + the 256 partial sums (four lanes add 64 producers each, ascending; then the quad in a fixed order) ----------------
-        if (tid < 4 * WRO) {
-            const int i = tid >> 2, g4 = tid & 3;
+        if (tid < 4 * XPAD) {
+            const int i = min(tid >> 2, WRO - 1), g4 = tid & 3;
             float s = 0.f;
             for (int p = 0; p < NWG / 4; ++p) s += lds[W_PT + (g4 * (NWG / 4) + p) * WRO + i];
             s += dpp_xor1(s);
@@ -502,8 +552,8 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
             const int n = WRO * r + i;
             const float xn = xb[n] + s;
             if (g4 == 0) {
-                if (l + 1 == a.n_layers) a.xdec[(long)a.scene * WE + n] = xn;
-                else put_far(gx, (u32)n, tg + 8, xn);
+                if (l + 1 == a.n_layers) { if ((tid >> 2) < WRO) a.xdec[(long)a.scene * WE + n] = xn; }
+                else put_far(gx, (u32)(XPAD * r + (tid >> 2)), tg + 8, (tid >> 2) < WRO ? xn : 0.f);
             }
         }
         stamp(13);
@@ -517,7 +567,7 @@ size_t oar_engine_wide_lds_bytes() {
     const size_t need = (size_t)W_TOTAL * sizeof(float);
     return need > (size_t)(96 << 10) ? need : (size_t)(96 << 10);      // > 80 KB: never two workgroups on one CU
 }
-size_t oar_engine_wide_granules() { return (size_t)WE + 3 * WE + (size_t)WH * NSP * PREC + WE + WE + (size_t)NWG * WE; }
+size_t oar_engine_wide_granules() { return (size_t)XGR + 3 * WE + (size_t)WH * NSP * PREC + WE + XGR + (size_t)NWG * WE; }
 
 __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_census_kernel(unsigned int* count) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
