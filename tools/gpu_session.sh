@@ -96,7 +96,7 @@ widestep)  # tools/wide_step_time.py with the shipped library and the measuremen
     lib=$PWD/umgen_amd/libumgen_hip_$v.so; [ $v = shipped ] && lib=$PWD/umgen_amd/libumgen_hip.so
     echo "--- $v" >> gpurun_out/${R}_wide_step_time.txt
     if [ $v = shipped ]; then env ${WIDE_ENV} UMGEN_LIB_PATH=$lib python tools/wide_step_time.py >> gpurun_out/${R}_wide_step_time.txt 2>&1
-    else env ${WIDE_ENV} ENGINE_ONLY=1 UMGEN_LIB_PATH=$lib python tools/wide_step_time.py >> gpurun_out/${R}_wide_step_time.txt 2>&1; fi
+    else env ${WIDE_ENV} ENGINE_ONLY=1 LS=${WIDE_LS:-64,1100,2200} UMGEN_LIB_PATH=$lib python tools/wide_step_time.py >> gpurun_out/${R}_wide_step_time.txt 2>&1; fi
   done; cat gpurun_out/${R}_wide_step_time.txt ;;
 mapgiven)  # a given-map rollout (the predefined-token prefix): one pass over the given positions vs the step-by-step replay of rounds 1-4
   b mapgiven python bench.py --steps 3 --warmup 1 --no-cpu-baseline --task mapgiven

@@ -21,7 +21,7 @@ eng.finalize()
 rng = np.random.default_rng(0)
 x = rng.standard_normal((1, cfg.n_embd)).astype(np.float32)
 modes = [(3, "chip-wide engine"), (0, "five launches")] if not os.environ.get("ENGINE_ONLY") else [(3, "chip-wide engine")]
-for L in (64, 1100, 2200):
+for L in [int(v) for v in os.environ.get("LS", "64,1100,2200").split(",")]:
     for mode, name in modes:
         for _ in range(3):
             eng.dbg_oar_step(x, L, mode)

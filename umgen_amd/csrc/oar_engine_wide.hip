@@ -80,24 +80,36 @@ __device__ inline void poll_far(Ctx& c, int tid, const u64* g, IDX idx, u32 tag,
 #ifndef UMGEN_WIDE_EXP_NOLOAD
 #define UMGEN_WIDE_EXP_NOLOAD 0
 #endif
-// Granules per rank in the x / x' buffers: 6 = compact (a rank's 48 bytes share 64-byte sectors with its neighbours'), 8 / 16 = every rank writes whole
-// 64 / 128-byte pieces with ONE store instruction (x': its six rows' results collected through LDS behind one more workgroup barrier)
+// Granules per rank in the x / x' buffers: 8 / 16 = every rank writes whole 64 / 128-byte pieces with ONE store instruction (x': its six rows' results
+// collected through LDS behind one more workgroup barrier).  Compact (6 per rank: 48 bytes that share 64-byte sectors with the neighbours', written by six
+// waves' lane 0 one after the other) the x' hand-off took 5.3 us instead of 2.5 (profiles/r05_wide2x_engine.txt).
 #ifndef UMGEN_WIDE_PAD
 #define UMGEN_WIDE_PAD 16
 #endif
-// Where the weight requests of a layer go out (a poll's answer queues behind whatever the XCD's memory link still has to deliver):
-//   0: at the start of the waits -- K/V + c_proj row under the x hand-off, c_fc + next q|k|v rows under q|k|v, the mlp slice behind the keys
-//   1: behind the far hand-offs  -- K/V + c_proj + c_fc rows right behind B1 (x is there), the mlp slice behind P1, the next q|k|v rows behind B6 (x' is there):
-//      the link works through them during P1 / q|k|v / attention / quarters (hand-offs inside the XCD's L2) and during P4
-#ifndef UMGEN_WIDE_ORDER
-#define UMGEN_WIDE_ORDER 2
+// Where the requests of a layer go out -- a poll's answer queues behind whatever the XCD's memory link still has to deliver, and a compute wave's loads
+// return in the order they were made.  Slots: 0 before B1 (under the x hand-off), 1 behind B1, 2 behind P1 (under q|k|v), 3 behind the keys, 4 behind B3's
+// merge (under the quarters), 5 behind B4's merge (under the attention output), 6 behind B5, 7 behind B6 (x' is there), 8 behind B7, 9 behind B8.
+// Measured (profiles/r05_wide2x_engine.txt): K/V + the c_proj row at 0, the c_fc rows at 3, the mlp slice at 5, the next layer's q|k|v rows at 7 -- "as late
+// as the registers' consumer allows" beats "as early as the registers are free": what is in the link's queue delays the polls.
+#ifndef UMGEN_WIDE_AT_KV
+#define UMGEN_WIDE_AT_KV 0
 #endif
-//   4: as 2, the c_fc rows behind the keys too          5: as 2, the next q|k|v rows behind B8 (the mlp partial sums are there)
-//   2: as 0, the next q|k|v rows behind B6 instead      3: as 0, the mlp slice with the c_fc rows behind P1, the next q|k|v rows behind the keys
-constexpr int kOrder = UMGEN_WIDE_ORDER;
+#ifndef UMGEN_WIDE_AT_O
+#define UMGEN_WIDE_AT_O 0
+#endif
+#ifndef UMGEN_WIDE_AT_F
+#define UMGEN_WIDE_AT_F 3
+#endif
+#ifndef UMGEN_WIDE_AT_P
+#define UMGEN_WIDE_AT_P 5
+#endif
+#ifndef UMGEN_WIDE_AT_Q
+#define UMGEN_WIDE_AT_Q 7
+#endif
 constexpr int XPAD = UMGEN_WIDE_PAD;
 constexpr int XGR = 256 * 16;      // granules reserved for each of the x / x' buffers
-__device__ inline u32 xslot(u32 n) { return XPAD == 6 ? n : (n / 6u) * (u32)XPAD + n % 6u; }
+static_assert(XPAD == 8 || XPAD == 16, "x / x' granules per rank");
+__device__ inline u32 xslot(u32 n) { return (n / 6u) * (u32)XPAD + n % 6u; }
 __device__ inline u32x4_t wld(const bf16_t* ubase, u32 off) {
     if (UMGEN_WIDE_EXP_NOLOAD) { u32x4_t z; asm volatile("" : "=v"(z)); return z; }
     return ldwu(ubase, off);
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
             // hand-off 4: the 1536 attention outputs
             if (!UMGEN_WIDE_EXP_NOPOLL) poll_far(c, tid, gatt, [&](int k) { return (u32)(pt + k * PT); }, tg + 3, [&](int k, float v) { as[pt + k * PT] = v; });
             wg_barrier();      // B5
-            if (XPAD != 6) wg_barrier();      // B5b
+            wg_barrier();      // B5b
             // hand-off 5: x'
             if (!UMGEN_WIDE_EXP_NOPOLL) poll_far(c, tid, gxb, [&](int k) { return xslot((u32)(pt + k * PT)); }, tg + 4, [&](int k, float v) { xb[pt + k * PT] = v; });
             wg_barrier();      // B6
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
         };
         // ---------------- (hand-off 1: x) ----------------
         // (K/V of the cached keys do not depend on this layer's q: the first KG passes, 80 keys per wave = 1920 positions, are requested ahead; the passes
-        //  behind them pay a round trip each.  Where the requests go out: kOrder above.)
+        //  behind them pay a round trip each.  Where the requests go out: the UMGEN_WIDE_AT_* slots above.)
         float bq[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) bq[i] = ldg(lw.bqkv + qkv_row(i));
@@ -336,13 +348,14 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
         KVPiece kc[KG], vc[KG];
         WRow wo, wf[4];
         u32x4_t wp[4][3];      // mlp c_proj slice of this rank, repacked [256 ranks][1536 rows][24]: rows tid, tid + 384, ...
-        auto req_kv_o = [&]() {
+        auto req_kv = [&]() {
             if (att_rank) {
 #pragma unroll
-                for (int i = 0; i < KG; ++i) kv_req(kc[i], vc[i], i);
+                for (int i = 0; i < KG; ++i)
+                    if (i < nch) kv_req(kc[i], vc[i], i);      // (only the passes this wave has: requests at clamped addresses for the others cost 0.9 us per layer)
             }
-            req_row(wo, lw.Wo, (long)WRO * r + wave, lane);
         };
+        auto req_o = [&]() { req_row(wo, lw.Wo, (long)WRO * r + wave, lane); };
         auto req_f = [&]() {
 #pragma unroll
             for (int i = 0; i < 4; ++i) req_row(wf[i], lw.Wfc, (long)WRF * r + wave + CW * i, lane);
@@ -358,10 +371,17 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
 #pragma unroll
             for (int i = 0; i < 3; ++i) req_row(wq[i], ln.Wqkv, (long)qkv_row(i), lane);
         };
-        if (kOrder != 1) req_kv_o();
+        auto at = [&](int slot) {      // (compile-time slots: each group's requests appear once)
+            if (slot == UMGEN_WIDE_AT_KV) req_kv();
+            if (slot == UMGEN_WIDE_AT_O) req_o();
+            if (slot == UMGEN_WIDE_AT_F) req_f();
+            if (slot == UMGEN_WIDE_AT_P) req_p();
+            if (slot == UMGEN_WIDE_AT_Q) req_q_next();
+        };
+        at(0);
         wg_barrier();      // B1
         stamp(0);
-        if (kOrder == 1) { req_kv_o(); req_f(); }
+        at(1);
         // ---------------- P1: LN + this rank's 18 q|k|v rows (hand-off 2: q_h | k_h | v_h of the attention ranks) ----------------
         {
             XRegs x;
@@ -380,10 +400,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                 }
             }
         }
-        if (kOrder == 0) { req_f(); req_q_next(); }
-        if (kOrder == 1) req_p();
-        if (kOrder == 2 || kOrder == 5) req_f();
-        if (kOrder == 3) { req_f(); req_p(); }
+        at(2);
         stamp(1);
         wg_barrier();      // B2
         stamp(2);
@@ -451,9 +468,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
                 if (lane == 0) { wpz[48] = st.m; wpz[49] = st.l; }
             }
         }
-        if (kOrder == 4) req_f();
-        if (kOrder == 0 || kOrder == 2 || kOrder == 4 || kOrder == 5) req_p();
-        if (kOrder == 3) req_q_next();
+        at(3);
         stamp(3);
         wg_barrier();      // B3
         stamp(4);
@@ -472,6 +487,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
             }
             put_local(gpart + (long)(hh * NSP + sp) * PREC, (u32)tid, tg + 2, tid < kHeadDim ? o : (tid == kHeadDim ? M : Ls));
         }
+        at(4);
         wg_barrier();      // B4
         stamp(5);
         // ---------------- the owner merges its head's four quarters -> attention output (hand-off 4: the 1536 attention outputs) ----------------
@@ -489,28 +505,24 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
             }
             put_far(gatt, (u32)(hh * kHeadDim + tid), tg + 3, o / Ls);
         }
+        at(5);
         wg_barrier();      // B5
         stamp(6);
+        at(6);
         // ---------------- P3: c_proj row 6 r + wave + residual -> x' (hand-off 5: x') ----------------
         {
             XRegs x;
             load_x(as, lane, x);
             const int n = WRO * r + wave;
             const float v = row_dot<TT>(wo, x) + bo;
-            if (XPAD == 6) {
-                if (lane == 0) put_far(gxb, (u32)n, tg + 4, xs[n] + v);
-            } else {
-                if (lane == 0) lds[W_XO + wave] = xs[n] + v;
-            }
+            if (lane == 0) lds[W_XO + wave] = xs[n] + v;
         }
-        if (XPAD != 6) {
-            wg_barrier();      // B5b
-            if (tid < XPAD) put_far(gxb, (u32)(XPAD * r + tid), tg + 4, tid < WRO ? lds[W_XO + tid] : 0.f);
-        }
+        wg_barrier();      // B5b
+        if (tid < XPAD) put_far(gxb, (u32)(XPAD * r + tid), tg + 4, tid < WRO ? lds[W_XO + tid] : 0.f);      // (ONE store of whole 64-byte pieces)
         stamp(7);
         wg_barrier();      // B6
         stamp(8);
-        if (kOrder == 1 || kOrder == 2 || kOrder == 4) req_q_next();
+        at(7);
         // ---------------- P4: LN + this rank's 24 hidden units + GELU ----------------
         {
             XRegs x;
@@ -525,6 +537,7 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
         stamp(9);
         wg_barrier();      // B7
         stamp(10);
+        at(8);
         // ---------------- this rank's partial sums of the 1536 mlp c_proj outputs (hand-off 6: the 256 partials of this rank's 6 rows) ----------------
         {
             f32x2_t hq[3][4];
@@ -541,19 +554,21 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
         stamp(11);
         wg_barrier();      // B8
         stamp(12);
-        if (kOrder == 5) req_q_next();
-        // ---------------- P5: x'' = x' + the 256 partial sums (four lanes add 64 producers each, ascending; then the quad in a fixed order) ----------------
-        if (tid < 4 * XPAD) {
-            const int i = min(tid >> 2, WRO - 1), g4 = tid & 3;
+        at(9);
+        // ---------------- P5: x'' = x' + the 256 partial sums (eight lanes add 32 producers each, ascending; then the eight in a fixed order) ----------------
+        if (tid < 64) {      // wave 0: eight lanes per row (rows 6, 7: copies of row 5, never polled), 32 producers per lane
+            const int i = min(tid >> 3, WRO - 1), g8 = tid & 7;
             float s = 0.f;
-            for (int p = 0; p < NWG / 4; ++p) s += lds[W_PT + (g4 * (NWG / 4) + p) * WRO + i];
+#pragma unroll 8
+            for (int p = 0; p < NWG / 8; ++p) s += lds[W_PT + (g8 * (NWG / 8) + p) * WRO + i];
             s += dpp_xor1(s);
             s += dpp_xor2(s);
+            s += dpp_mov<0x141>(s);      // row_half_mirror: the other quad of the eight
             const int n = WRO * r + i;
             const float xn = xb[n] + s;
-            if (g4 == 0) {
-                if (l + 1 == a.n_layers) { if ((tid >> 2) < WRO) a.xdec[(long)a.scene * WE + n] = xn; }
-                else put_far(gx, (u32)(XPAD * r + (tid >> 2)), tg + 8, (tid >> 2) < WRO ? xn : 0.f);
+            if (g8 == 0) {      // lanes 0, 8, .. 56: ONE store of 8 consecutive granules (64 bytes)
+                if (l + 1 == a.n_layers) { if ((tid >> 3) < WRO) a.xdec[(long)a.scene * WE + n] = xn; }
+                else put_far(gx, (u32)(XPAD * r + (tid >> 3)), tg + 8, (tid >> 3) < WRO ? xn : 0.f);
             }
         }
         stamp(13);
