@@ -212,7 +212,10 @@ hipError_t launch_oar_engine_ms(hipStream_t s, const OarMsArgs& a);
 // ------------------------------------------------------------------------------------------------
 constexpr int kWideE = 1536;                   // the width this engine is built for (configs[4]: 2x UMGen_Large)
 constexpr int kWideGroups = 256;               // workgroups = ranks (one per CU)
-constexpr int kWideSplits = 4;                 // key quarters per head in the attention phase (32 heads x 4 = 128 ranks)
+#ifndef UMGEN_WIDE_SPLITS
+#define UMGEN_WIDE_SPLITS 4
+#endif
+constexpr int kWideSplits = UMGEN_WIDE_SPLITS; // key splits per head in the attention phase: 4 = ranks 0..15 of an XCD (8 = every rank: 30 us per step slower below 1500 keys, 30 faster at 2200)
 struct OarWideArgs {
     const OarLayerDev* layers; int n_layers;   // Wp2: mlp c_proj repacked [256 ranks][1536 rows][24 hidden units of the rank] (engine.hip repack_wide)
     bf16_t* kvcache; long kv_layer_stride, kv_scene_stride; int Lmax;   // [layer][scene][2][H][Lmax][48]

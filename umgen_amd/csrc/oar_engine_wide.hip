@@ -36,9 +36,9 @@ constexpr int WRF = WF / NWG;                    // 24 hidden units: 4 per compu
 constexpr int NSP = kWideSplits;                 // key splits per head (H x NSP attention ranks)
 constexpr int NXCD = 8, RPX = NWG / NXCD;        // XCDs, ranks per XCD
 constexpr int HPX = WH / NXCD;                   // heads per XCD (4): RPX / 2 attention ranks per XCD
-constexpr int KG = 5;                            // 16-key passes of a wave in flight at once
+constexpr int KG = NSP == 8 ? 3 : 5;                            // 16-key passes of a wave in flight at once
 constexpr int PREC = 52;                         // floats per attention partial record: o[48] | m | l | pad
-static_assert(WE == 1536 && WRQ == 3 * CW && WRO == CW && WRF == 4 * CW && WE == 4 * CT && WH * NSP <= NWG && NSP == 4, "wide engine geometry");
+static_assert(WE == 1536 && WRQ == 3 * CW && WRO == CW && WRF == 4 * CW && WE == 4 * CT && WH * NSP <= NWG && (NSP == 4 || NSP == 8), "wide engine geometry");
 static_assert(WE == 12 * PT, "gathers of 1536 granules: 12 per poll lane");
 
 // LDS carve (floats)
@@ -275,8 +275,12 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_wide_kernel(OarWideArg
             wg_barrier();      // B3
             // hand-off 3: the owner's four quarters (4 records x 50 values = 200 granules over 128 lanes)
             if (owner) {
-                auto src = [&](int k) { const int f = min(pt + k * PT, NSP * (kHeadDim + 2) - 1); return (u32)((f / (kHeadDim + 2)) * PREC + f % (kHeadDim + 2)); };
-                if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<2, kPollAll>(c, tid, gpart + (long)(hh * NSP) * PREC, pt + PT < NSP * (kHeadDim + 2) ? 3u : 1u, src, tg + 2,
+                constexpr int NREC = NSP * (kHeadDim + 2), PERQ = (NREC + PT - 1) / PT;      // NSP records x 50 values over 128 lanes
+                auto src = [&](int k) { const int f = min(pt + k * PT, NREC - 1); return (u32)((f / (kHeadDim + 2)) * PREC + f % (kHeadDim + 2)); };
+                u32 need = 0;
+#pragma unroll
+                for (int k = 0; k < PERQ; ++k) need |= (pt + k * PT < NREC) ? 1u << k : 0u;
+                if (!UMGEN_WIDE_EXP_NOPOLL) poll_ms<PERQ, kPollAll>(c, tid, gpart + (long)(hh * NSP) * PREC, need, src, tg + 2,
                                      [&](int k, float v) { const int f = pt + k * PT; lds[W_SB + (f / (kHeadDim + 2)) * PREC + f % (kHeadDim + 2)] = v; });
             }
             wg_barrier();      // B4
