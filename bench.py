@@ -36,7 +36,7 @@ MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak
 PMC_FILES = ["r05_pmc_fetch_size_engine.csv", "r04_pmc_fetch_size_engine.csv", "r03_pmc_fetch_size_engine.csv"]   # newest first
 
 
-def pmc_traffic_per_launch(engine_on: bool):
+def pmc_traffic_per_launch(engine_on: bool, files=None, kernel="oar_engine_kernel"):
     """(HBM bytes per launch of the dominant kernel, source) from the newest committed rocprofv3 PMC pass (tools/gpu_session.sh pmc:
     `rocprofv3 --pmc FETCH_SIZE`, decode steps 1101..1104 only via UMGEN_DEBUG_OAR_STEPS, i.e. at the MEAN KV length of a frame --
     the same L the algorithmic bytes per launch are quoted at; mean FETCH_SIZE [KB] x 2 = the gfx950 correction of
@@ -44,13 +44,13 @@ def pmc_traffic_per_launch(engine_on: bool):
     this run: `roofline.traffic_source` says which file the number comes from.  (None, None) when absent or the engine did not run."""
     if not engine_on:
         return None, None
-    for fn in PMC_FILES:
+    for fn in (files or PMC_FILES):
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
             continue
         for line in open(path).read().splitlines()[1:]:
             name, _, rest = line.rpartition('",')
-            if "oar_engine_kernel" in name:
+            if kernel in name:
                 return float(rest.split(",")[2]) * 2.0 * 1024.0, f"profiles/{fn} (separate rocprofv3 --pmc FETCH_SIZE pass at KV length 1101..1104, x2 gfx950 correction; not measured in this run)"
     return None, None
 
@@ -263,7 +263,12 @@ def main():
         oar_gbs = (tm["oar_bytes"] / (tm["oar_ms"] * 1e-3) / 1e9) if tm["oar_ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic_per_launch(engine_on and B == 1 and args.config == "large")
         lanes = int(tm.get("decode_lanes", 0))
-        if engine_on:
+        if int(tm["decode_engine"]) == 3:
+            kname = ("umgen::oar_engine_wide_kernel (chip-wide decode engine of the 2x-width layers: the 36 BlockOAR layers of a decode step of one scene "
+                     "in one launch of 256 workgroups)")
+            if B == 1 and args.config == "wide2x":
+                traffic, traffic_src = pmc_traffic_per_launch(True, ["r05_pmc_fetch_size_wide_engine.csv"], "oar_engine_wide_kernel")
+        elif engine_on:
             kname = "umgen::oar_engine_kernel (XCD-resident decode engine: the 36 BlockOAR layers of a decode step in one launch)"
         elif tm.get("decode_batched"):
             kname = ("batched decode layer (rows_mfma_kernel x144 + attn_decode_batched_kernel x36 per step and lane; scenes as the MFMA's B-columns)" +

@@ -98,6 +98,12 @@ widestep)  # tools/wide_step_time.py with the shipped library and the measuremen
     if [ $v = shipped ]; then env ${WIDE_ENV} UMGEN_LIB_PATH=$lib python tools/wide_step_time.py >> gpurun_out/${R}_wide_step_time.txt 2>&1
     else env ${WIDE_ENV} ENGINE_ONLY=1 LS=${WIDE_LS:-64,1100,2200} UMGEN_LIB_PATH=$lib python tools/wide_step_time.py >> gpurun_out/${R}_wide_step_time.txt 2>&1; fi
   done; cat gpurun_out/${R}_wide_step_time.txt ;;
+wideprof)  # rocprofv3 kernel statistics of the 2x-width bench (chip-wide engine)                          -> r05_prof_wide2x.csv
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof3 -- python /root/repo/bench.py --no-cpu-baseline --config wide2x --steps 2 --warmup 0 > /tmp/prof3_bench.json 2>/tmp/prof3.err
+   f=$(find /tmp/prof3 -name "*kernel_stats.csv" | head -1); cp "$f" /root/repo/gpurun_out/${R}_prof_wide2x.csv; cp /tmp/prof3_bench.json /root/repo/gpurun_out/${R}_prof_wide2x_bench.json; head -8 "$f" | cut -c1-220) ;;
+widepmc)   # rocprofv3 --pmc FETCH_SIZE of the chip-wide engine at the mean KV length (decode steps 1101..1104)     -> r05_pmc_fetch_size_wide_engine.csv
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmcw && UMGEN_DEBUG_OAR_STEPS=1101:1105 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmcw -- python /root/repo/bench.py --config wide2x --steps 1 --warmup 0 --no-cpu-baseline > /tmp/pmcw.log 2>&1
+   f=$(find /tmp/pmcw -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python /root/repo/tools/pmc_summary.py "$f" > /root/repo/gpurun_out/${R}_pmc_fetch_size_wide_engine.csv && head -4 /root/repo/gpurun_out/${R}_pmc_fetch_size_wide_engine.csv || tail -5 /tmp/pmcw.log) ;;
 mapgiven)  # a given-map rollout (the predefined-token prefix): one pass over the given positions vs the step-by-step replay of rounds 1-4
   b mapgiven python bench.py --steps 3 --warmup 1 --no-cpu-baseline --task mapgiven
   b mapgiven_replay env UMGEN_PREFIX_PASS=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --task mapgiven ;;
