@@ -254,7 +254,7 @@ def test_bf16_teacher_forced_logits_at_2x_width_vs_rounding_aware_oracle_golden(
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 def test_wide_engine_matches_the_five_launch_path_at_2x_width(precision):
     """The chip-wide decode engine of the wide layers (csrc/oar_engine_wide.hip: n_embd 1536, 256 workgroups of 6 compute + 2 poll waves, hand-offs
-    across the fabric; the default decode path of configs[4] at up to 4 scenes per call) against the five-launch layer it replaces
+    across the fabric; the default decode path of configs[4] for engines of one scene per call, UMGEN_DECODE_WIDE=n for up to 4) against the five-launch layer it replaces
     (UMGEN_DECODE_WIDE=0): same rounding points, another fp32 summation order -- teacher-forced logits within the north-star's 1e-3, at most a
     handful of sampled tokens on the other side of a near-tie; its graph-replayed steps equal its eager launches token for token; a batch of three
     scenes equals the three one-scene rollouts (one engine launch per scene and step on shared hand-off buffers)."""
@@ -269,7 +269,8 @@ def test_wide_engine_matches_the_five_launch_path_at_2x_width(precision):
     toks_ref, tr_ref = ref.frame(window, frame_idx=0, seed=3, trace=True)
     assert ref.timings()["decode_engine"] == 0
     ref.close()
-    e = Engine(cfg, precision=precision, max_batch=3, max_cond_frames=4)
+    with env(UMGEN_DECODE_WIDE=4):      # (the default is engines of one scene per call: scenes are launches one behind the other, and from two on the
+        e = Engine(cfg, precision=precision, max_batch=3, max_cond_frames=4)      #  five-launch layer, which reads the weights once for the batch, is faster)
     e.load_state_dict(sd)
     e.finalize()
     toks, tr = e.frame(window, frame_idx=0, seed=3, trace=True, forced=toks_ref)

@@ -140,7 +140,9 @@ struct umgen_engine {
     unsigned long long* eng_gloc_ms = nullptr;
     unsigned long long* eng_stamps_ms = nullptr;
     size_t eng_gloc_ms_bytes = 0;
-    // Chip-wide decode engine for wide layers (oar_engine_wide.hip; n_embd 1536, up to 4 scenes per call, one launch each; UMGEN_DECODE_WIDE=0: five launches per layer)
+    // Chip-wide decode engine for wide layers (oar_engine_wide.hip; n_embd 1536; one launch per scene and step).  Default: engines created for ONE scene per
+    // call (two scenes as two launches: step 1696 us against 1523 on five launches per layer, four: 3382 against 2217 -- profiles/r05_wide2x_engine.txt);
+    // UMGEN_DECODE_WIDE=n (1..4): engines of up to n scenes per call; =0: five launches per layer
     bool wide_enabled = false;
     OarLayerDev* d_layers_wide = nullptr;
     std::vector<void*> wide_wp2;            // per BlockOAR: mlp c_proj repacked [256 ranks][E rows][24 hidden units of the rank]
@@ -1570,7 +1572,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     // census as the XCD-resident engine's, 32 workgroups on each of 8 XCDs, twice) and, like it, gives up the CU-masked background TAR pass.
     const char* dw_env = getenv("UMGEN_DECODE_WIDE");
     if (cfg->precision != UMGEN_PREC_FP32 && cfg->n_embd == kWideE && cfg->n_head == kWideE / kHeadDim && cfg->n_oar_layer <= 64 &&
-        !(dw_env && dw_env[0] == '0') && !(ov_env && ov_env[0] != '0')) {
+        cfg->max_batch <= std::max(0, std::min(4, dw_env ? atoi(dw_env) : 1)) && !(ov_env && ov_env[0] != '0')) {
         HIPCHK(e, hipStreamCreate(&e->stream));
         HIPCHK(e, oar_engine_wide_prepare());
         unsigned* d_cnt = nullptr;
