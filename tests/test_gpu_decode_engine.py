@@ -375,3 +375,28 @@ def test_ms_engine_two_frames_of_a_control_rollout(setup):
     for m in MOD_ORDER:
         for i, ref in single.items():
             np.testing.assert_array_equal(out[m][i:i + 1], ref[m], err_msg=f"scene {i} {m}")
+
+
+def test_decode_chain_tokens_equal_the_five_launch_batched_layer(setup):
+    """UMGEN_DECODE_CHAIN=1 (opt-in; measured slower, profiles/r05_decode_chain.txt): the layers of a lane's decode step as ONE persistent launch -- the
+    five launches of a layer as phases with a grid barrier behind each (decode_batched.hip decode_chain_kernel).  Same arithmetic element for element:
+    a batch on two lanes gives the five-launch batched layer's tokens bit for bit."""
+    cfg, sd = setup
+    scenes = [synthetic_scene(60 + i, n_frames=2) for i in range(17)]
+    batch = {m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}
+    outs = {}
+    for chain in ("0", "1"):
+        old = os.environ.get("UMGEN_DECODE_CHAIN")
+        os.environ["UMGEN_DECODE_CHAIN"] = chain
+        try:
+            e = make_batched(cfg, sd, 1, max_batch=17)
+        finally:
+            if old is None:
+                del os.environ["UMGEN_DECODE_CHAIN"]
+            else:
+                os.environ["UMGEN_DECODE_CHAIN"] = old
+        outs[chain] = e.rollout(batch, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(17)))
+        assert e.timings()["decode_batched"] == 1
+        e.close()
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(outs["1"][m], outs["0"][m], err_msg=m)

@@ -181,8 +181,14 @@ struct umgen_engine {
         hipEvent_t done = nullptr;
         OarState* st = nullptr;
         float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;
+        float* chain_work = nullptr;         // decode_chain_kernel's per-layer workspaces and barrier words of this lane
+        unsigned* chain_bar = nullptr;
         hipGraphExec_t graph[4][3] = {};
     };
+    // The layers of a lane's decode step as ONE persistent launch (decode_batched.hip decode_chain_kernel; UMGEN_DECODE_CHAIN=0: five launches per layer)
+    bool chain_enabled = false;
+    float* chain_work = nullptr;             // (the current view's: a lane's, or the engine's own for a batch that is one lane)
+    unsigned* chain_bar = nullptr;
     DecLane lane[kMaxLanes];
     hipEvent_t ev_lane_fork = nullptr;
     int lanes_env = -1;                  // UMGEN_DECODE_LANES=n: n lanes whenever the batched layer runs (1 = off); -1: by batch size
@@ -553,6 +559,15 @@ int oar_layers(umgen_engine* e, int B, int ns) {
         if (e->use_batched(B)) {      // five launches per layer for the whole batch: LN + q|k|v, attention, c_proj (+x), LN + c_fc + GELU, mlp c_proj (+x)
             // activations between the launches are fragment-major (decode_batched.hip); x also stays row-major in xdec (sampler, residual)
             launch_rows_to_frag(e->stream, e->xdec, E, B, E, e->xfrag);
+            if (e->chain_enabled && e->chain_work && B <= 16 && !e->dbg_same_layer) {      // one lane: the 36 layers as one persistent launch
+                ChainArgs c{};
+                c.layers = e->d_layers; c.n_layers = (int)e->oar.size();
+                c.kvcache = e->kvcache; c.kv_layer_stride = e->kv_layer_stride; c.kv_scene_stride = e->kv_scene_stride; c.Lmax = e->Lmax;
+                c.d_len = d_len; c.xdec = e->xdec; c.xfrag_in = e->xfrag; c.xfrag_out = e->xfrag; c.work = e->chain_work; c.bar = e->chain_bar;
+                c.M = B; c.E = E; c.H = H;
+                HIPCHK(e, launch_decode_chain<T>(e->stream, c));      // (xfrag: read by the first phase, rewritten by the last -- the head launch streams it)
+                return 0;
+            }
             for (size_t li = 0; li < e->oar.size(); ++li) {
                 const SubW& w = e->oar[e->dbg_same_layer ? 0 : li];
                 T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
@@ -782,20 +797,24 @@ struct DecView {
     double* d_boxes;
     unsigned long long* d_seeds;
     OarState* d_state;
+    float* chain_work;
+    unsigned* chain_bar;
 };
 DecView current_view(const umgen_engine* e) {
     return DecView{e->stream, e->xdec, e->qdec, e->logits, e->logits_tar, e->cond, e->xfrag, e->afrag, e->hfrag, e->kvcache,
-                   e->d_tokens, e->d_prev_box, e->d_nboxes, e->d_control, e->d_boxes, e->d_seeds, e->d_state};
+                   e->d_tokens, e->d_prev_box, e->d_nboxes, e->d_control, e->d_boxes, e->d_seeds, e->d_state, e->chain_work, e->chain_bar};
 }
 void apply_view(umgen_engine* e, const DecView& v) {
     e->stream = v.stream; e->xdec = v.xdec; e->qdec = v.qdec; e->logits = v.logits; e->logits_tar = v.logits_tar; e->cond = v.cond;
     e->xfrag = v.xfrag; e->afrag = v.afrag; e->hfrag = v.hfrag; e->kvcache = v.kvcache; e->d_tokens = v.d_tokens; e->d_prev_box = v.d_prev_box;
     e->d_nboxes = v.d_nboxes; e->d_control = v.d_control; e->d_boxes = v.d_boxes; e->d_seeds = v.d_seeds; e->d_state = v.d_state;
+    e->chain_work = v.chain_work; e->chain_bar = v.chain_bar;
 }
 DecView lane_view(const umgen_engine* e, const DecView& all, const umgen_engine::DecLane& ln, int b0) {
     const long E = e->E;
     DecView v = all;
     v.stream = ln.s; v.d_state = ln.st; v.xfrag = ln.xfrag; v.afrag = ln.afrag; v.hfrag = ln.hfrag;
+    v.chain_work = ln.chain_work; v.chain_bar = ln.chain_bar;
     v.xdec = all.xdec + b0 * E; v.qdec = all.qdec + b0 * E; v.logits = all.logits + (long)b0 * 8192;
     v.logits_tar = all.logits_tar + (long)b0 * kNBox * e->cfg.bbox3d_vocab; v.cond = all.cond + (long)b0 * kSeq * E;
     v.kvcache = static_cast<unsigned char*>(all.kvcache) + (size_t)b0 * e->kv_scene_stride * e->tsz;
@@ -1801,6 +1820,23 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
             HIPCHK(e, hipMemset(ln.hfrag, 0, (size_t)kRowsMaxM * 4 * E * 4));
         }
         HIPCHK(e, hipEventCreateWithFlags(&e->ev_lane_fork, hipEventDisableTiming));
+    }
+    {
+        const char* ch = getenv("UMGEN_DECODE_CHAIN");
+        e->chain_enabled = e->eng_enabled && e->tsz == 2 && E == kEngE && Bm >= 2 && ch && ch[0] != '0';
+        if (e->chain_enabled) {
+            const size_t wf = decode_chain_work_floats(cfg->n_oar_layer, E);
+            auto mk = [&](float** w, unsigned** b) -> int {
+                if (int rc = dalloc(e, w, wf)) return rc;
+                if (int rc = dalloc(e, b, (size_t)4)) return rc;
+                HIPCHK(e, hipMemset(*w, 0, wf * 4));
+                HIPCHK(e, hipMemset(*b, 0, 16));
+                return UMGEN_OK;
+            };
+            if (int rc = mk(&e->chain_work, &e->chain_bar)) return rc;
+            for (auto& ln : e->lane)
+                if (ln.s) { if (int rc = mk(&ln.chain_work, &ln.chain_bar)) return rc; }
+        }
     }
     if (int rc = dalloc(e, &e->logits, 3 * Bm * 8192)) return rc;
     if (int rc = dalloc(e, &e->logits_tar, Bm * kNBox * (size_t)cfg->bbox3d_vocab)) return rc;

@@ -143,6 +143,24 @@ void launch_rows_to_frag(hipStream_t s, const float* x, long ldx, int M, int K, 
 template <typename TT> void launch_attn_decode_batched(hipStream_t s, const float* q, const TT* cache, long scene_stride, int B, int H, int Lmax,
                                                         const int* d_len, float* y);
 
+// The BlockOAR layers of a decode step of one lane (<= 16 scenes) as ONE persistent launch of kChainWG workgroups: the five launches of a layer as
+// phases with a grid barrier behind each (decode_batched.hip decode_chain_kernel)
+constexpr int kChainWG = 64;                   // workgroups per lane (4 lanes: one per CU -- every lane's launch is resident whatever else runs)
+struct OarLayerDev;
+struct ChainArgs {
+    const OarLayerDev* layers; int n_layers;
+    void* kvcache; long kv_layer_stride, kv_scene_stride; int Lmax;   // [layer][scene][2][H][Lmax][48] (the lane's first scene)
+    const int* d_len;                          // cached keys before this step
+    float* xdec;                               // [M][E] row-major: in = input of layer 0, out = output of the last layer
+    const float* xfrag_in;                     // the same input, fragment-major
+    float* xfrag_out;                          // the output once more, fragment-major (head launch)
+    float* work;                               // decode_chain_work_floats() per lane
+    unsigned* bar;                             // [4]: arrivals, generation, error flag
+    int M, E, H;
+};
+template <typename TT> hipError_t launch_decode_chain(hipStream_t s, const ChainArgs& a);
+size_t decode_chain_work_floats(int n_layers, int E);
+
 // ------------------------------------------------------------------------------------------------
 // XCD-resident decode engine (oar_engine.hip): all BlockOAR layers of one decode step in one launch, bf16 weights, n_embd 768
 // ------------------------------------------------------------------------------------------------
