@@ -1289,6 +1289,18 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         e->launch_status = hipSuccess;
         if (le != hipSuccess) return e->fail(UMGEN_E_HIP, "a kernel launch of this frame was refused: %s", hipGetErrorString(le));
     }
+    if (e->chain_enabled && batched) {      // a grid barrier of decode_chain_kernel timed out in this frame: never return its tokens
+        unsigned words[4 * (umgen_engine::kMaxLanes + 1)] = {};
+        unsigned* bars[umgen_engine::kMaxLanes + 1] = {e->chain_bar};
+        for (int l = 0; l < umgen_engine::kMaxLanes; ++l) bars[l + 1] = e->lane[l].chain_bar;
+        for (int i = 0; i <= umgen_engine::kMaxLanes; ++i)
+            if (bars[i]) HIPCHK(e, hipMemcpy(words + 4 * i, bars[i], 16, hipMemcpyDeviceToHost));
+        for (int i = 0; i <= umgen_engine::kMaxLanes; ++i)
+            if (words[4 * i + 2]) {
+                (void)hipMemset(bars[i] + 2, 0, 4);
+                return e->fail(UMGEN_E_HIP, "decode chain kernel gave up waiting at a grid barrier (arrival target 0x%08x)", words[4 * i + 2]);
+            }
+    }
     if (eng_err) {   // a hand-off of the decode engine timed out (e.g. two engines sharing one GPU): never return tokens from such a frame
         (void)hipMemset(wide ? e->wide_err : e->eng_err, 0, sizeof(unsigned));
         return e->fail(UMGEN_E_HIP, "decode engine gave up waiting for hand-off tag 0x%08x (is another persistent kernel using this GPU?)", eng_err);
