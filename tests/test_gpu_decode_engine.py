@@ -396,7 +396,10 @@ def test_decode_chain_tokens_equal_the_five_launch_batched_layer(setup):
             else:
                 os.environ["UMGEN_DECODE_CHAIN"] = old
         outs[chain] = e.rollout(batch, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(17)))
-        assert e.timings()["decode_batched"] == 1
+        t = e.timings()
+        assert t["decode_batched"] == 1 and t["decode_lanes"] == 2
+        per_step = t["oar_kernels"] / t["oar_steps"]      # layer launches + head / sampler, summed over the lanes
+        assert (per_step < 2 * 5) if chain == "1" else (per_step > 2 * 5 * cfg.n_oar_layer), (chain, per_step)
         e.close()
     for m in MOD_ORDER:
         np.testing.assert_array_equal(outs["1"][m], outs["0"][m], err_msg=m)

@@ -1224,7 +1224,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                     hipEventRecord(e->layer_ev[e->layer_ev_used++].second, ln.s);
                     e->tm.layers_launches += run - 1;      // (the frame's bookkeeping below adds one per event pair)
                 }
-                e->tm.oar_kernels += (int64_t)run * (5 * (int64_t)e->oar.size() + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
+                e->tm.oar_kernels += (int64_t)run * ((e->chain_enabled && ln.chain_work ? 1 : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
             }
             j += run - 1;
         }
