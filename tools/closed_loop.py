@@ -1,7 +1,7 @@
 """Closed-loop effect of the 16-bit modes at full size: a greedy (k = 1 / 1 / 1) 30-frame video rollout of
 UMGen_Large in bf16 and in fp16 against the SAME rollout of the engine's fp32 parity mode (token-exact against the reference
 goldens at tiny width): per-frame token agreement and, at the first diverging token, the fp32 engine's top-2 logit gap (how close
-to a tie the arg-max was where the 16-bit rollout left the fp32 one; from the fp32 frame re-run free-running with logit capture).  Writes gpurun_out/r04_closed_loop.json.
+to a tie the arg-max was where the 16-bit rollout left the fp32 one; from the fp32 frame re-run free-running with logit capture).  Writes gpurun_out/r05_closed_loop.json.
 
     python tools/closed_loop.py [--frames 30]"""
 import argparse, json, os, sys, time
@@ -64,4 +64,4 @@ for prec in ("bf16", "fp16"):
     print(prec, "mean agreement", np.mean(agree), "first divergence", first, flush=True)
 e32.close()
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(res, open("gpurun_out/r04_closed_loop.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/r05_closed_loop.json", "w"), indent=1)
