@@ -2,19 +2,25 @@
 // of ONE scene in one persistent launch of 256 workgroups (one per CU).
 //
 // At 2x width a layer is 57 MB: through ONE XCD's memory link (the XCD-resident engine, oar_engine.hip) that is 45-85 us per layer, as five launches
-// (gemv.hip) 33.5 us of which 11 us are the weight stream and the rest kernel boundaries.  Here all 256 CUs work on every layer -- rank r (a ticket)
-// owns q|k|v rows 18 r .., c_proj rows 6 r .., the hidden units 24 r .. of c_fc and the matching 24 columns of the mlp c_proj (hidden-unit split: what is
-// exchanged are the ranks' partial sums of the 1536 outputs) -- and a layer's hand-offs are {tag, value} granules across the fabric.
+// (gemv.hip) 33.5 us of which 11 us are the weight stream and the rest kernel boundaries.  Here all 256 CUs work on every layer: 23.3 us per layer
+// (profiles/r05_wide2x_engine.txt: every step from 33 to 23 us with its measurement).
 //
-// ROLES.  The first form of this engine (round 5, profiles/r05_wide2x_engine.txt) ran at the five launches' 33 us per layer: a wave's loads return in
-// order, so a hand-off poll's s_waitcnt also waited for the weight requests in front of it and every phase paid first-byte latency + its 11-19 MB
-// weight stream + a fabric round trip one behind the other.  Wait counters are PER WAVE: here waves 6, 7 of a workgroup are POLL waves that issue
-// nothing but granule polls (and the layer's LayerNorm weights) and hand the gathered vectors over through LDS + the workgroup barrier (which
-// does not drain vmcnt, oar_common.h wg_barrier); waves 0..5 are COMPUTE waves that never poll: their weight requests (one to two phases ahead, into
-// registers) stream in the shadow of the hand-offs, and their K/V requests of the attention phase are only behind weights requested a whole phase earlier.
-//   per layer: x -> [P1 LN + 18 q|k|v rows] -> q|k|v -> [attention: head r / 4, key quarter r % 4, ranks 0..127] -> 4 partials per head ->
-//              [owner rank merges] -> attention output -> [P3 c_proj + residual] -> x' -> [P4 LN + 24 hidden units + GELU + partial sums] -> [P5 adds 256 partials]
-//   six fabric hops and eight workgroup barriers per layer.
+// OWNERSHIP.  Rank r = 32 x XCD + arrival order on the XCD (per-XCD tickets; the census at umgen_create has found 32 workgroups on each of the 8 XCDs).
+// It owns 18 of the 576 q|k|v rows of ITS XCD's four heads (heads 4 g .. 4 g + 3 on XCD g), c_proj rows 6 r .., the hidden units 24 r .. of c_fc and the
+// matching 24 columns of the mlp c_proj (hidden-unit split: what is exchanged are the ranks' partial sums of the 1536 outputs).  Ranks 0..15 of an XCD are
+// the attention ranks of its heads (head = rank / 4, key quarter = rank % 4; the six compute waves split the quarter's keys).
+//
+// ROLES.  The first form of this engine ran at the five launches' 33 us per layer: a wave's loads return in order, so a hand-off poll's s_waitcnt also
+// waited for the weight requests in front of it.  Wait counters are PER WAVE: waves 6, 7 of a workgroup are POLL waves that issue nothing but granule
+// polls (and the layer's LayerNorm weights) and hand the gathered vectors over through LDS + the workgroup barrier (which does not drain vmcnt,
+// oar_common.h wg_barrier); waves 0..5 are COMPUTE waves that never poll.  The two roles are two loops over the layers that execute the same nine
+// barriers per layer.
+//   per layer: x -> [P1 LN + 18 q|k|v rows] -> q|k|v (XCD-local) -> [attention of a key quarter] -> 4 partials per head (XCD-local) -> [owner merges]
+//              -> attention output -> [P3 c_proj + residual] -> x' -> [P4 LN + 24 hidden units + GELU + partial sums] -> 256 partials per row -> [P5 adds] -> x
+//   Hand-offs are 8-byte {tag, value} granules: inside the XCD's L2 0.8-1.0 us, across the fabric 2.1-2.3 us PROVIDED the producer writes whole 64-byte
+//   pieces with one store instruction (x and x' live in one 128-byte line per rank for that; 8-byte stores of six waves into shared sectors: 3.5-5.3 us).
+//   Requests: a poll's answer queues behind whatever the XCD's link still has to deliver -- the weight groups go out as LATE as their consumer allows
+//   (UMGEN_WIDE_AT_* slots below), not as early as their registers are free.
 // Arithmetic (fixed, independent of the placement): fp32 activations, 16-bit weights and K/V cache, fp32 accumulation; row dot products as in gemv.hip
 // (lane l owns k = 512 c + 8 l .. + 7, packed fp32 FMAs, wave sum); weight-only LayerNorm (eps 1e-5) with gemv.hip's statistics; exact erf-GELU; the
 // attention's new key / value out of the q|k|v exchange rounded to 16 bits.  Against the five-launch form only fp32 summation orders differ.
