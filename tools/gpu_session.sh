@@ -22,6 +22,10 @@
 #   vq         umgen_vq_decode of the two production decoders, 20 frames              -> r04_vq_decode_time{,_valu}.json
 #   cpubase    the oracle over one whole UMGen_Large frame on this host (32 threads)     -> r04_cpu_baseline_full.json
 #   ab:<name>  bench.py --steps 3 with UMGEN_LIB_PATH=umgen_amd/libumgen_hip_<name>.so (tools/build_variant.sh) next to the shipped library
+#   wide       configs[4] (2x width) on the chip-wide engine, T = 20 and T = 40          -> r05_bench_wide2x{,_h40}.json
+#   widestep   tools/wide_step_time.py: one 2x-width decode step at 64 / 1100 / 2200 keys, shipped library + measurement builds WIDE_VARIANTS="..." -> r05_wide_step_time.txt
+#   widevar    the 2x-width bench with per-phase stamps of the chip-wide engine, shipped + WIDE_VARIANTS        -> r05_bench_widevar_<v>.{json,err}
+#   wideprof / widepmc   rocprofv3 kernel statistics / FETCH_SIZE of the chip-wide engine  -> r05_prof_wide2x.csv, r05_pmc_fetch_size_wide_engine.csv
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 R=r05
