@@ -311,7 +311,7 @@ def main():
             "prefill_ms_unoverlapped": {"ego": tp["ego_ms"], "tar": tp["tar_ms"]},
             "weight_load_s": t_load,
             "closed_loop": closed_loop_record(args.precision) if args.config == "large" else None,
-            "decode_engine": int(engine_on), "engine_fallback": int(tm["engine_fallback"]), "decode_batched": int(tm.get("decode_batched", 0)),
+            "decode_engine": int(tm["decode_engine"]), "engine_fallback": int(tm["engine_fallback"]), "decode_batched": int(tm.get("decode_batched", 0)),
             "decode_lanes": lanes,
         }
         if force_dist:

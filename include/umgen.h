@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define UMGEN_ABI_VERSION 3   /* 2: umgen_rollout takes given_map / given_bbox3d; umgen_timings::decode_batched.  3: umgen_timings::prefix_passes; decode_engine == 2 */
+#define UMGEN_ABI_VERSION 3   /* 2: umgen_rollout takes given_map / given_bbox3d; umgen_timings::decode_batched.  3: umgen_timings::prefix_passes; decode_engine values 1 / 3 (2 retired) */
 
 enum {
     UMGEN_OK = 0,
@@ -104,8 +104,10 @@ typedef struct umgen_timings {
     double layers_ms;       /* sum over launches of the decode step's layer kernel(s): the decode engine's one launch per step, or the
                              * 5 x n_oar_layer launches of the five-launch form (when profiling enabled; HIP events on the decode stream) */
     int64_t layers_launches; /* decode steps timed that way */
-    int32_t decode_engine;  /* 1 when the last frame's decode steps ran on the XCD-resident decode engine, 2: on its multi-scene form
-                             * (csrc/oar_engine_ms.hip; UMGEN_DECODE_MS=n) */
+    int32_t decode_engine;  /* which persistent decode engine ran the last frame's decode steps: 0 none (five launches per layer, or the batched layer:
+                             * see decode_batched), 1 the XCD-resident engine (csrc/oar_engine.hip; n_embd 768, up to 23 scenes), 3 the chip-wide engine
+                             * of the 2x-width layers (csrc/oar_engine_wide.hip; n_embd 1536).  2 was round 5's multi-scene engine: measured behind the
+                             * other paths and removed in round 6 -- the value is not reused */
     int32_t engine_fallback; /* 1 when this configuration would use the decode engine (16-bit mode, n_embd 768) but its census failed at
                               * umgen_create: the five-launch decode layer runs instead (a warning is printed at create) */
     int32_t decode_batched; /* 1 when the last frame's decode steps ran on the batched decode layer (24 and more scenes per call: the scenes
@@ -138,8 +140,10 @@ int umgen_finalize_weights(umgen_engine *e);
  *                           (init_tokens["map"], init_tokens["bbox3d"] without control_test: infer_oar_net's predefined-token prefix,
  *                           UMGen.py:1184-1201 -- "use the predefined tokens and don't infer these tokens any more").  They must continue
  *                           the pose prefix in scene order: the map, or the map and the boxes (the reference concatenates whatever is
- *                           given back to back, so boxes without the map would sit on the map's positions: refused).  The decode loop
- *                           replays the given positions (no head, no sampler) and starts sampling behind them; the given tokens are
+ *                           given back to back, so boxes without the map would sit on the map's positions: refused).  The given
+ *                           positions go through the BlockOAR layers as ONE forward pass like the reference's first iteration (no head, no
+ *                           sampler; engines created with the overlapped background pass, UMGEN_OVERLAP=1, replay them as decode steps instead
+ *                           -- a property of the engine, the same for every frame), sampling starts behind them; the given tokens are
  *                           returned verbatim (UMGen.py:1640-1651).  given_bbox3d and control_test exclude each other.
  *   out_*                 : [B][T_in + new_frames][S_mod], caller-allocated
  */

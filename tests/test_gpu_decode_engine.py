@@ -21,10 +21,9 @@ pytestmark = pytest.mark.gpu
 def make(cfg, sd, engine_on, max_batch=1, graphs=True):
     """engine_on: the XCD-resident engine for EVERY batch size (its systolic / rounds schedules included: the batched decode layer that
     takes 24 and more scenes by default is switched off), else the five-launch layer."""
-    old = {k: os.environ.get(k) for k in ("UMGEN_DECODE_ENGINE", "UMGEN_DECODE_BATCHED", "UMGEN_DECODE_MS")}
+    old = {k: os.environ.get(k) for k in ("UMGEN_DECODE_ENGINE", "UMGEN_DECODE_BATCHED")}
     os.environ["UMGEN_DECODE_ENGINE"] = "1" if engine_on else "0"
     os.environ["UMGEN_DECODE_BATCHED"] = "0"
-    os.environ["UMGEN_DECODE_MS"] = "0"        # (the multi-scene engine that takes 16 .. 64 scenes by default has its own tests below)
     try:
         e = Engine(cfg, precision="bf16", max_batch=max_batch, max_cond_frames=4, use_graphs=graphs)
     finally:
@@ -99,9 +98,8 @@ def test_engine_is_batch_invariant(setup, B, engine_on):
 # ---------------------------------------------------------------------------------------------------------------------
 def make_batched(cfg, sd, threshold, max_batch=1, precision="bf16"):
     """UMGEN_DECODE_BATCHED=<threshold>: batches of at least that many scenes run the batched decode layer (1: every call does)."""
-    old = {k: os.environ.get(k) for k in ("UMGEN_DECODE_BATCHED", "UMGEN_DECODE_MS")}
+    old = {k: os.environ.get(k) for k in ("UMGEN_DECODE_BATCHED",)}
     os.environ["UMGEN_DECODE_BATCHED"] = str(threshold)
-    os.environ["UMGEN_DECODE_MS"] = "0"        # (the multi-scene engine takes precedence from 16 scenes on: off for these tests)
     try:
         e = Engine(cfg, precision=precision, max_batch=max_batch, max_cond_frames=4)
     finally:
@@ -241,8 +239,8 @@ def test_decode_lanes_in_control_mode_with_a_growing_window(setup):
 
 def test_default_path_selection_by_batch_size(setup):
     """Up to 23 scenes per call the XCD-resident engine takes the decode step (its systolic schedule from 5 on), from 24 on the batched
-    layer (measured crossover, profiles/r04_lanes_sweep.txt; UMGEN_DECODE_BATCHED moves the threshold); the multi-scene engine only when
-    asked for (UMGEN_DECODE_MS=n: measured behind both at 16 / 32 / 64 scenes, profiles/r05_ms_experiments.txt): umgen_timings says which ran."""
+    layer (measured crossover, profiles/r04_lanes_sweep.txt; UMGEN_DECODE_BATCHED moves the threshold): umgen_timings says which ran.  (Round 5's
+    multi-scene engine and chain launch measured behind both -- profiles/r05_ms_experiments.txt, r05_decode_chain.txt -- and left the library in round 6.)"""
     cfg, sd = setup
     e = Engine(cfg, precision="bf16", max_batch=24, max_cond_frames=4)
     e.load_state_dict(sd)
@@ -255,151 +253,3 @@ def test_default_path_selection_by_batch_size(setup):
     t = e.timings()
     assert t["decode_engine"] == 0 and t["decode_batched"] == 1 and t["decode_lanes"] == 2
     e.close()
-    old = os.environ.get("UMGEN_DECODE_MS")
-    os.environ["UMGEN_DECODE_MS"] = "16"
-    try:
-        e = Engine(cfg, precision="bf16", max_batch=16, max_cond_frames=4)
-    finally:
-        if old is None:
-            del os.environ["UMGEN_DECODE_MS"]
-        else:
-            os.environ["UMGEN_DECODE_MS"] = old
-    e.load_state_dict(sd)
-    e.finalize()
-    e.rollout({m: np.concatenate([s[m] for s in scenes[:16]]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(16)))
-    assert e.timings()["decode_engine"] == 2 and e.timings()["decode_batched"] == 0
-    e.close()
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# the multi-scene decode engine (csrc/oar_engine_ms.hip): 16 .. 64 scenes per call, work item = (block of <= 8 scenes, layer)
-# ---------------------------------------------------------------------------------------------------------------------
-def make_ms(cfg, sd, max_batch=1, precision="bf16", graphs=True, scenes_per_block=None):
-    """UMGEN_DECODE_MS=1: every call runs the multi-scene engine (a single scene as a block of one)."""
-    env = {"UMGEN_DECODE_MS": "1", "UMGEN_DECODE_ENGINE": "1"}
-    if scenes_per_block:
-        env["UMGEN_MS_SCENES"] = str(scenes_per_block)
-    old = {k: os.environ.get(k) for k in list(env) + ["UMGEN_MS_SCENES"]}
-    os.environ.pop("UMGEN_MS_SCENES", None)
-    os.environ.update(env)
-    try:
-        e = Engine(cfg, precision=precision, max_batch=max_batch, max_cond_frames=4, use_graphs=graphs)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    e.load_state_dict(sd)
-    e.finalize()
-    return e
-
-
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-def test_ms_engine_logits_match_the_five_launch_path_under_teacher_forcing(setup, precision):
-    """Same rounding points as the five-launch layer (16-bit weights and K/V cache, fp32 activations -- as hi + lo 16-bit column pairs on
-    the matrix cores), another fp32 summation order: teacher-forced logits within the north-star's 1e-3 of the five-launch path."""
-    cfg, sd = setup
-    scene = synthetic_scene(31, n_frames=2)
-    window = {m: scene[m][0] for m in MOD_ORDER}
-    old = os.environ.get("UMGEN_DECODE_ENGINE")
-    os.environ["UMGEN_DECODE_ENGINE"] = "0"
-    try:
-        ref = make_batched(cfg, sd, 0, precision=precision)          # five launches per layer
-    finally:
-        if old is None:
-            del os.environ["UMGEN_DECODE_ENGINE"]
-        else:
-            os.environ["UMGEN_DECODE_ENGINE"] = old
-    toks_ref, tr_ref = ref.frame(window, frame_idx=0, seed=3, trace=True)
-    assert ref.timings()["decode_engine"] == 0 and ref.timings()["decode_batched"] == 0
-    ref.close()
-    e = make_ms(cfg, sd, precision=precision)
-    toks, tr = e.frame(window, frame_idx=0, seed=3, trace=True, forced=toks_ref)
-    assert e.timings()["decode_engine"] == 2
-    worst = 0.0
-    for m in ("map", "bbox3d", "image"):
-        worst = max(worst, float(np.abs(tr[f"logits_{m}"] - tr_ref[f"logits_{m}"]).max()))
-        np.testing.assert_allclose(tr[f"logits_{m}"], tr_ref[f"logits_{m}"], atol=1e-3, rtol=0, err_msg=m)
-    print(f"multi-scene engine vs launches ({precision}): max |dlogit| = {worst:.2e}, sampled != forced: {tr['counters']['sampled_ne_forced']}")
-    assert tr["counters"]["sampled_ne_forced"] <= 4, tr["counters"]
-    # graph replay == eager launches, token for token
-    out_g = e.rollout(scene, 1, cond_frames=3, input_cond_frames=2, seeds=[5])
-    e.close()
-    eager = make_ms(cfg, sd, precision=precision, graphs=False)
-    out_e = eager.rollout(scene, 1, cond_frames=3, input_cond_frames=2, seeds=[5])
-    eager.close()
-    for m in MOD_ORDER:
-        np.testing.assert_array_equal(out_g[m], out_e[m], err_msg=m)
-
-
-@pytest.mark.parametrize("B,spb", [(2, None), (9, None), (16, None), (17, None), (33, None), (64, None), (24, 8), (24, 5), (12, 1)])
-def test_ms_engine_is_batch_invariant(setup, B, spb):
-    """A scene's results are a function of its own column pair of the matrix-core instruction, of its own LayerNorm wave and of its own
-    (scene, head) attention pairs -- not of the block it sits in, the block's size, or the number of blocks: a batch of B scenes
-    (blocks of ceil(B / 8) scenes, ragged last block; `spb` forces other block sizes: 8 + 8 + 8, 5 x 5 - 1, twelve blocks of one) ==
-    the B one-scene runs of the same engine, bit for bit."""
-    cfg, sd = setup
-    scenes = [synthetic_scene(40 + i, n_frames=2) for i in range(B)]
-    seeds = [100 + i for i in range(B)]
-    e = make_ms(cfg, sd, max_batch=B, scenes_per_block=spb)
-    pick = sorted(set(range(min(B, 10))) | (set(range(B)) & {15, 16, 21, 31, 32, 47, 48, 56, 63}))
-    single = {i: e.rollout(scenes[i], 1, cond_frames=3, input_cond_frames=2, seeds=[seeds[i]]) for i in pick}
-    both = e.rollout({m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}, 1, cond_frames=3, input_cond_frames=2, seeds=seeds)
-    assert e.timings()["decode_engine"] == 2
-    e.close()
-    bad = []
-    for i, ref in sorted(single.items()):
-        for m in MOD_ORDER:
-            d = np.argwhere(both[m][i:i + 1] != ref[m])
-            if len(d):
-                bad.append((i, m, len(d), d[:3].tolist()))
-    assert not bad, bad
-
-
-def test_ms_engine_two_frames_of_a_control_rollout(setup):
-    """Per-scene state next to the engine (control mask, previous boxes, rule-constraint boxes, seeds) over two frames of a 20-scene control
-    rollout with a growing window: equals the scenes' own one-scene rollouts of the same engine."""
-    from umgen_amd.synth import synthetic_control
-    cfg, sd = setup
-    B = 20
-    scenes = [synthetic_scene(90 + i, n_frames=2) for i in range(B)]
-    inits = [synthetic_control(90 + i, n_frames=2, slot=2 + i % 5) for i in range(B)]
-    cat = lambda ds: {k: np.concatenate([d[k] for d in ds]) for k in ds[0]}
-    seeds = [700 + i for i in range(B)]
-    kw = dict(cond_frames=3, input_cond_frames=2, control_test=True)
-    e = make_ms(cfg, sd, max_batch=B)
-    out = e.rollout(cat(scenes), 2, init_tokens=cat(inits), seeds=seeds, **kw)
-    single = {i: e.rollout(scenes[i], 2, init_tokens=inits[i], seeds=[seeds[i]], **kw) for i in (0, 7, 8, 19)}
-    e.close()
-    for m in MOD_ORDER:
-        for i, ref in single.items():
-            np.testing.assert_array_equal(out[m][i:i + 1], ref[m], err_msg=f"scene {i} {m}")
-
-
-def test_decode_chain_tokens_equal_the_five_launch_batched_layer(setup):
-    """UMGEN_DECODE_CHAIN=1 (opt-in; measured slower, profiles/r05_decode_chain.txt): the layers of a lane's decode step as ONE persistent launch -- the
-    five launches of a layer as phases with a grid barrier behind each (decode_batched.hip decode_chain_kernel).  Same arithmetic element for element:
-    a batch on two lanes gives the five-launch batched layer's tokens bit for bit."""
-    cfg, sd = setup
-    scenes = [synthetic_scene(60 + i, n_frames=2) for i in range(17)]
-    batch = {m: np.concatenate([s[m] for s in scenes]) for m in MOD_ORDER}
-    outs = {}
-    for chain in ("0", "1"):
-        old = os.environ.get("UMGEN_DECODE_CHAIN")
-        os.environ["UMGEN_DECODE_CHAIN"] = chain
-        try:
-            e = make_batched(cfg, sd, 1, max_batch=17)
-        finally:
-            if old is None:
-                del os.environ["UMGEN_DECODE_CHAIN"]
-            else:
-                os.environ["UMGEN_DECODE_CHAIN"] = old
-        outs[chain] = e.rollout(batch, 1, cond_frames=3, input_cond_frames=2, seeds=list(range(17)))
-        t = e.timings()
-        assert t["decode_batched"] == 1 and t["decode_lanes"] == 2
-        per_step = t["oar_kernels"] / t["oar_steps"]      # layer launches + head / sampler, summed over the lanes
-        assert (per_step < 2 * 5) if chain == "1" else (per_step > 2 * 5 * cfg.n_oar_layer), (chain, per_step)
-        e.close()
-    for m in MOD_ORDER:
-        np.testing.assert_array_equal(outs["1"][m], outs["0"][m], err_msg=m)

@@ -172,33 +172,6 @@ def test_batched_decode_layer_lies_inside_the_oracle_ensemble_at_depth():
         check_inside_ensemble(ens, tr, COND_ROWS, LOGIT_POS, f"deep {precision} (batched decode layer)")
 
 
-def test_multi_scene_engine_lies_inside_the_oracle_ensemble_at_depth():
-    """The multi-scene decode engine (16 .. 64 scenes per call: csrc/oar_engine_ms.hip, blocks of scenes as the matrix-core instruction's
-    column pairs inside the XCD-resident groups) facing the ORACLE: the `deep` production-width frame (10 BlockOAR layers: the layer ->
-    group rotation wraps, shared tail layers) teacher-forced through it (UMGEN_DECODE_MS=1 sends a single scene down the same kernel;
-    its results do not depend on the batch) within 2 x the spread of the rounding-aware oracle's accumulation-order ensemble, and
-    within the absolute bars against the fp32 oracle golden."""
-    from tests.test_gpu_parity import check_inside_ensemble
-    for precision in ("bf16", "fp16"):
-        ens = np.load(os.path.join(GOLD, f"ensemble_deep_{precision}_engine.npz"))
-        g32 = np.load(os.path.join(GOLD, "deep_fp32.npz"))
-        cfg = width_config("deep")
-        scene = synthetic_scene(SCENE_ID, n_frames=2)
-        forced = {m: ens[f"tok_{m}"].astype(np.int64) for m in MOD_ORDER}
-        with env(UMGEN_DECODE_MS=1):
-            e = Engine(cfg, precision=precision, max_cond_frames=4)
-        e.load_state_dict(synthetic_state_dict(cfg, seed=WEIGHT_SEED))
-        e.finalize()
-        toks, tr = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, trace=True, forced=forced)
-        assert e.timings()["decode_engine"] == 2
-        e.close()
-        check_inside_ensemble(ens, tr, COND_ROWS, LOGIT_POS, f"deep {precision} (multi-scene engine)")
-        bar = ABS_BAR_VS_FP32["deep"][precision]
-        for m, pos in LOGIT_POS.items():
-            d = float(np.abs(tr[f"logits_{m}"][pos] - g32[f"logits_{m}"]).max())
-            assert d <= bar["logits"], (precision, m, d)
-
-
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 def test_given_map_prefix_pass_at_production_width_batch_and_engine(precision):
     """The given-map prefix as one pass at production width (E = 768: the 256-tile GEMM, the matrix-core attention with the causal mask, the

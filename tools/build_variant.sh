@@ -6,7 +6,7 @@
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../umgen_amd/csrc"
-ALL="engine.hip gemm.hip gemm256.hip attn.hip gemv.hip oar_engine.hip oar_engine_ms.hip oar_engine_wide.hip decode_batched.hip rowops.hip frame.hip tokenizers.hip vqdec.hip debug_api.hip"
+ALL="engine.hip gemm.hip gemm256.hip attn.hip gemv.hip oar_engine.hip oar_engine_wide.hip decode_batched.hip rowops.hip frame.hip tokenizers.hip vqdec.hip debug_api.hip"
 SRC=${VARIANT_SOURCES:-$ALL}
 objs=""
 for f in $ALL; do

@@ -28,7 +28,7 @@
 #   wideprof / widepmc   rocprofv3 kernel statistics / FETCH_SIZE of the chip-wide engine  -> r05_prof_wide2x.csv, r05_pmc_fetch_size_wide_engine.csv
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
-R=r05
+R=r06
 line() {  # one-line summary of a bench JSON
 python - "$1" <<'PY'
 import json, sys
@@ -65,22 +65,6 @@ batched)
   b b64 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 64
   b b16_engine env UMGEN_DECODE_BATCHED=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 16
   b b32_engine env UMGEN_DECODE_BATCHED=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 32 ;;
-ms)   # the multi-scene decode engine (oar_engine_ms.hip) at MS_B scenes per GPU, with per-phase stamps of an item           -> r05_bench_ms_b<n>.json, r05_ms_stamps.txt
-  : > gpurun_out/${R}_ms_stamps.txt
-  for n in ${MS_B:-16 32 64}; do
-    b ms_b$n env UMGEN_DEBUG_TIMING=1 ${MS_ENV} python bench.py --steps ${MS_STEPS:-1} --warmup 1 --no-cpu-baseline --batch $n
-    echo "--- $n scenes ${MS_ENV}" >> gpurun_out/${R}_ms_stamps.txt; grep "multi-scene decode engine" gpurun_out/${R}_bench_ms_b$n.err | tail -1 >> gpurun_out/${R}_ms_stamps.txt
-  done; cat gpurun_out/${R}_ms_stamps.txt | cut -c1-400 ;;
-msvar)  # measurement builds of the multi-scene engine (MS_VARIANTS="nb2 ..." -> umgen_amd/libumgen_hip_<v>.so) at MS_B scenes, stamps of an item
-  for v in ${MS_VARIANTS}; do for n in ${MS_B:-64}; do
-    b msvar_${v}_b$n env UMGEN_DEBUG_TIMING=1 UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_$v.so ${MS_ENV} python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch $n
-    grep "multi-scene decode engine" gpurun_out/${R}_bench_msvar_${v}_b$n.err | tail -1 | cut -c1-400
-  done; done ;;
-msab)  # the same batch on the multi-scene engine, the one-scene engine and the batched layer + lanes (round 4's path)
-  for n in ${MS_B:-16 32 64}; do
-    b ms_b$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch $n
-    b r4path_b$n env UMGEN_DECODE_MS=0 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch $n
-  done ;;
 lanes)   # decode lanes (sub-batches of the batched layer on their own streams): lane count sweep at 16 / 32 / 64 scenes
   for n in ${LANES_B32:-1 2 4 8}; do b b32_lanes$n env UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 32; done
   for n in ${LANES_B64:-2 4 8}; do b b64_lanes$n env UMGEN_DECODE_LANES=$n python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 64; done
@@ -152,6 +136,16 @@ cpubase) python tools/cpu_baseline_full.py --runs 1 --frames 1 --threads 32 --ou
 ab:*) v=${s#ab:}
   b ab_shipped python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${AB_ARGS}
   b ab_$v env UMGEN_LIB_PATH=$PWD/umgen_amd/libumgen_hip_$v.so python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${AB_ARGS} ;;
+contention)  # what the one-scene decode step costs on 4 XCD groups, and while the other 4 XCDs run a synthetic load (measurement build -DUMGEN_ENG_BURN: tools/build_variant.sh burn)
+  : > gpurun_out/${R}_engine_contention.txt
+  c() { name=$1; shift; b cont_$name "$@" python bench.py --steps 2 --warmup 1 --no-cpu-baseline >> gpurun_out/${R}_engine_contention.txt; }
+  c d8 env
+  c d4 env UMGEN_DEBUG_ENGINE_D=4
+  BL=$PWD/umgen_amd/libumgen_hip_burn.so
+  for spec in ${BURN_SPECS:-350,64,0,0 350,64,8,0 350,64,24,0 350,0,0,262144 350,64,8,262144}; do
+    c d4_burn_${spec//,/_} env UMGEN_DEBUG_ENGINE_D=4 UMGEN_LIB_PATH=$BL UMGEN_DEBUG_BURN=$spec
+  done
+  cat gpurun_out/${R}_engine_contention.txt ;;
 *) echo "unknown session $s" ;;
 esac
 done

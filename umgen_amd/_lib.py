@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # UMGEN_LIB_PATH selects an alternative build of the SAME library (kernel experiments with extra -D flags); never a fallback
 LIB_PATH = os.environ.get("UMGEN_LIB_PATH") or os.path.join(HERE, "libumgen_hip.so")
-SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "oar_engine_ms.hip", "oar_engine_wide.hip", "decode_batched.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "vqdec.hip", "debug_api.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "gemm256.hip", "attn.hip", "gemv.hip", "oar_engine.hip", "oar_engine_wide.hip", "decode_batched.hip", "rowops.hip", "frame.hip", "tokenizers.hip", "vqdec.hip", "debug_api.hip"]
 EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen_rollout", "umgen_frame",
            "umgen_set_profiling", "umgen_get_timings", "umgen_last_error", "umgen_version", "umgen_destroy",
            "umgen_tokenize_ego", "umgen_detokenize_ego", "umgen_tokenize_boxes", "umgen_detokenize_boxes",

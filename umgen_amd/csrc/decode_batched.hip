@@ -306,354 +306,6 @@ __global__ __launch_bounds__(kABThreads) void attn_decode_batched_kernel(const f
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// The 36 layers of a decode step of ONE LANE (<= 16 scenes: one column block) as ONE persistent launch: the five launches of a layer become five
-// phases of kChainWG workgroups with a grid barrier behind each -- the arithmetic of rows_mfma_kernel / attn_decode_batched_kernel element for element
-// (same k-split over the waves, same summation orders: tokens equal the five-launch form's bit for bit), 180 dispatches per lane and step fewer.
-// With 4 lanes x 5 launches per layer the step sat on the dispatch rate (~2.6 us per kernel over all queues: 52 of the 70 us per layer at 64 scenes).
-//   Coherence inside the launch (the XCDs' L2s are not coherent with each other): every value a phase hands to the next is stored write-through
-//   (agent-scope relaxed atomic store) and acknowledged (vmcnt(0)) before the workgroup arrives at the barrier; every buffer is written ONCE per launch
-//   and read only behind the barrier that follows its writers (per-layer workspaces: 1.5 MB per layer and lane), so no L2 can hold a stale line of it
-//   -- plain loads on the consumer side.  The barrier: one monotonic arrival counter per lane (wrap-safe compare), generation kept on the device.
-//   The next phase's weights, biases and residual values are requested BEFORE the barrier wait (they do not depend on it).
-// ---------------------------------------------------------------------------------------------------------------------------
-template <typename V> __device__ inline void st_wt(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-struct ChainBar {
-    unsigned* ctr;       // [0] arrivals (monotonic), [1] generation (launches so far), [2] error flag
-    unsigned base;       // generation x barriers per launch x workgroups
-    unsigned k;          // barriers passed in this launch
-    bool failed;
-};
-// arrive (every thread's stores acknowledged first) ...
-__device__ inline void chain_arrive(ChainBar& b) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(b.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// ... and wait until all kChainWG workgroups of the lane have
-__device__ inline void chain_wait(ChainBar& b) {
-    b.k += 1;
-    const unsigned target = b.base + b.k * (unsigned)kChainWG;
-    if (threadIdx.x == 0 && !b.failed) {
-        unsigned spins = 0;
-        while ((int)(__hip_atomic_load(b.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) { __hip_atomic_store(b.ctr + 2, target | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-    }
-    __syncthreads();
-}
-
-// One 16 RT-row tile of out[m][n] = act[m][:] . W[n][:] for the lane's <= 16 scenes: rows_mfma_kernel<TT, MODE, 1, RT, JB, LN> in two halves.
-template <typename TT, int MODE, int RT, int JB, bool LN>
-struct ChainRows {
-    typedef typename Mma16<TT>::vec vec;
-    static constexpr int kEpi = (RT * 256 + kRowsThreads - 1) / kRowsThreads;
-    vec wf[RT][JB];
-    float4 lw[JB][2];
-    float bias_e[kEpi];
-    const TT* wrow[RT];
-    int n0, nsteps;
-    bool active;
-    // weights of the wave's first batch of k-steps, LayerNorm weights, bias + residual values: nothing here depends on the previous phase
-    __device__ inline void prefetch(const RowsArgs& a, const float* resid, int tile, int ntiles, int tid) {
-        // (workgroups beyond the phase's tiles compute its last tile once more and store nothing: every register of the phase is defined on every
-        //  path -- as conditional definitions they stayed allocated around the whole layer loop)
-        active = tile < ntiles;
-        const int lane = tid & 63, wave = tid >> 6;
-        const int row = lane & 15, kg = lane >> 4;
-        n0 = min(tile, ntiles - 1) * 16 * RT;
-        nsteps = a.K >> 5;
-        const TT* W = reinterpret_cast<const TT*>(a.W);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) wrow[t] = W + (long)min(n0 + 16 * t + row, a.N - 1) * a.K + 8 * kg;
-        reqw(a, 0, wave, kg);
-#pragma unroll
-        for (int q = 0; q < kEpi; ++q) {
-            const int e = tid + q * kRowsThreads;
-            const int n = n0 + 16 * (e >> 8) + (e & 15);
-            bias_e[q] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
-            if (MODE == ROWS_RESID) {
-                const int m = (e >> 4) & 15;
-                if (e < RT * 256 && m < a.M && n < a.N) bias_e[q] += resid[(long)m * a.ldo + n];
-            }
-        }
-    }
-    __device__ inline void reqw(const RowsArgs& a, int j0, int wave, int kg) {
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            const int s = min(wave + 8 * (j0 + j), nsteps - 1);
-#pragma unroll
-            for (int t = 0; t < RT; ++t) wf[t][j] = *reinterpret_cast<const vec*>(wrow[t] + 32 * s);
-            if (LN) {
-                lw[j][0] = *reinterpret_cast<const float4*>(a.ln_w + 32 * s + 8 * kg);
-                lw[j][1] = *reinterpret_cast<const float4*>(a.ln_w + 32 * s + 8 * kg + 4);
-            }
-        }
-    }
-    // behind the barrier: the activations, LayerNorm, the matrix-core k-loop, the eight waves' sums, the epilogue (write-through)
-    __device__ inline void run(const RowsArgs& a, int pos, float (*s_red)[kRowsWaves][16], float (*s_part)[3][256], int tid) {
-        const int lane = tid & 63, wave = tid >> 6;
-        const int row = lane & 15, kg = lane >> 4;
-        const int M = active ? a.M : 0, K = a.K;
-        float4 xa[JB][2];
-        auto reqx = [&](int j0) {
-#pragma unroll
-            for (int j = 0; j < JB; ++j) {
-                const int s = min(wave + 8 * (j0 + j), nsteps - 1);
-                const float* xp = a.x + ((((long)s * kRowsMaxNB) * 64 + lane) << 3);
-                xa[j][0] = *reinterpret_cast<const float4*>(xp);
-                xa[j][1] = *reinterpret_cast<const float4*>(xp + 4);
-            }
-        };
-        reqx(0);
-        if (LN) {
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < JB; ++j)
-                if (wave + 8 * j < nsteps)
-                    sum += ((xa[j][0].x + xa[j][0].y) + (xa[j][0].z + xa[j][0].w)) + ((xa[j][1].x + xa[j][1].y) + (xa[j][1].z + xa[j][1].w));
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            if (kg == 0) s_red[0][wave][row] = sum;
-            __syncthreads();
-            float t = s_red[0][0][row];
-#pragma unroll
-            for (int w = 1; w < kRowsWaves; ++w) t += s_red[0][w][row];
-            const float mean = t / (float)K;
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < JB; ++j)
-                if (wave + 8 * j < nsteps) {
-                    const float4 u0 = xa[j][0], u1 = xa[j][1];
-                    const float d0 = u0.x - mean, d1 = u0.y - mean, d2 = u0.z - mean, d3 = u0.w - mean;
-                    const float d4 = u1.x - mean, d5 = u1.y - mean, d6 = u1.z - mean, d7 = u1.w - mean;
-                    q += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
-                }
-            q += __shfl_xor(q, 16);
-            q += __shfl_xor(q, 32);
-            if (kg == 0) s_red[1][wave][row] = q;
-            __syncthreads();
-            t = s_red[1][0][row];
-#pragma unroll
-            for (int w = 1; w < kRowsWaves; ++w) t += s_red[1][w][row];
-            const float rstd = 1.0f / sqrtf(t / (float)K + 1e-5f);
-#pragma unroll
-            for (int j = 0; j < JB; ++j) {
-                float4& u0 = xa[j][0];
-                float4& u1 = xa[j][1];
-                u0.x = (u0.x - mean) * rstd * lw[j][0].x; u0.y = (u0.y - mean) * rstd * lw[j][0].y;
-                u0.z = (u0.z - mean) * rstd * lw[j][0].z; u0.w = (u0.w - mean) * rstd * lw[j][0].w;
-                u1.x = (u1.x - mean) * rstd * lw[j][1].x; u1.y = (u1.y - mean) * rstd * lw[j][1].y;
-                u1.z = (u1.z - mean) * rstd * lw[j][1].z; u1.w = (u1.w - mean) * rstd * lw[j][1].w;
-            }
-        }
-        f32x4_t acc[RT];
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int j0 = 0; wave + 8 * j0 < nsteps; j0 += JB) {
-            if (j0 > 0) { reqw(a, j0, wave, kg); reqx(j0); }
-#pragma unroll
-            for (int j = 0; j < JB; ++j) {
-                if (wave + 8 * (j0 + j) < nsteps) {
-                    const float v[8] = {xa[j][0].x, xa[j][0].y, xa[j][0].z, xa[j][0].w, xa[j][1].x, xa[j][1].y, xa[j][1].z, xa[j][1].w};
-                    vec hi, lo;
-                    split8<TT>(v, hi, lo);
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        acc[t] = Mma16<TT>::mfma(wf[t][j], hi, acc[t]);
-                        acc[t] = Mma16<TT>::mfma(wf[t][j], lo, acc[t]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_part[wave][t][(lane & 15) * 16 + 4 * kg + r] = acc[t][r];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < kEpi; ++q) {
-            const int e = tid + q * kRowsThreads;
-            if (e >= RT * 256) break;
-            const int t = e >> 8, col = (e >> 4) & 15, r = e & 15;
-            const int m = col, n = n0 + 16 * t + r;
-            if (m >= M || n >= a.N) continue;
-            float v = s_part[0][t][col * 16 + r];
-#pragma unroll
-            for (int w = 1; w < kRowsWaves; ++w) v += s_part[w][t][col * 16 + r];
-            v += bias_e[q];
-            if (MODE == ROWS_QKV) {
-                if (n < a.E) st_wt(a.out + (long)m * a.ldo + n, v);
-                else {
-                    const int c = n - a.E, kvsel = c / a.E, hc = c % a.E;
-                    const long H = a.E / kHeadDim;
-                    typedef typename Mma16<TT>::elem elem;
-                    st_wt(reinterpret_cast<unsigned short*>(a.cache) + (long)m * a.scene_stride + ((kvsel * H + hc / kHeadDim) * a.Lmax + pos) * kHeadDim + hc % kHeadDim,
-                          __builtin_bit_cast(unsigned short, Cvt<TT>::from_f(v)));
-                }
-            } else if (MODE == ROWS_GELU) {
-                st_wt(a.out_frag + frag_index(m, n), gelu_erf(v));
-            } else {
-                st_wt(a.out + (long)m * a.ldo + n, v);
-                st_wt(a.out_frag + frag_index(m, n), v);
-            }
-        }
-        __syncthreads();      // (s_part / s_red are the next phase's too)
-    }
-};
-
-// attention of (scene b, head h) by four waves (attn_decode_batched_kernel's walk: 4 lanes per key, 16 keys per wave pass, kABFlight passes in flight)
-template <typename TT>
-__device__ inline void chain_attn_task(const float* __restrict__ q, const TT* __restrict__ cache, long scene_stride, int H, int Lmax, int L, int b, int h,
-                                        float* __restrict__ y, int wave, int lane, float* s_m, float* s_l, float (*s_o)[kHeadDim], bool valid) {
-    const int part = lane & 3, grp = lane >> 2;
-    const int E = H * kHeadDim;
-    float m = -INFINITY, l = 0.f, o[12];
-#pragma unroll
-    for (int d = 0; d < 12; ++d) o[d] = 0.f;
-    if (valid) {
-        const TT* kb = cache + (long)b * scene_stride + (long)h * Lmax * kHeadDim + 12 * part;
-        const TT* vb = kb + (long)H * Lmax * kHeadDim;
-        float qv[12];
-        {
-            const float* qp = q + (long)b * E + h * kHeadDim + 12 * part;
-#pragma unroll
-            for (int d = 0; d < 12; d += 4) load4(qp + d, *reinterpret_cast<float(*)[4]>(&qv[d]));
-        }
-        const int npass = (L + 63) / 64;
-        for (int p0 = 0; p0 < npass; p0 += kABFlight) {
-            float kf[kABFlight][12], vf[kABFlight][12];
-#pragma unroll
-            for (int f = 0; f < kABFlight; ++f) {
-                const int key = min(16 * (wave + 4 * (p0 + f)) + grp, L - 1);
-                const TT* kp = kb + (long)key * kHeadDim;
-                const TT* vp = vb + (long)key * kHeadDim;
-#pragma unroll
-                for (int d = 0; d < 12; d += 4) {
-                    load4(kp + d, *reinterpret_cast<float(*)[4]>(&kf[f][d]));
-                    load4(vp + d, *reinterpret_cast<float(*)[4]>(&vf[f][d]));
-                }
-            }
-#pragma unroll
-            for (int f = 0; f < kABFlight; ++f) {
-                const int key = 16 * (wave + 4 * (p0 + f)) + grp;
-                float s = 0.f;
-#pragma unroll
-                for (int d = 0; d < 12; ++d) s = fmaf(qv[d], kf[f][d], s);
-                s += dpp_xor1(s);
-                s += dpp_xor2(s);
-                if (key < L) {
-                    s *= kScaleQKb;
-                    const float mn = fmaxf(m, s);
-                    const float alpha = __expf(m - mn), pr = __expf(s - mn);
-                    m = mn;
-                    l = l * alpha + pr;
-#pragma unroll
-                    for (int d = 0; d < 12; ++d) o[d] = fmaf(pr, vf[f][d], o[d] * alpha);
-                }
-            }
-        }
-    }
-    const int g = wave * 16 + grp;
-    if (part == 0) { s_m[g] = m; s_l[g] = l; }
-#pragma unroll
-    for (int d = 0; d < 12; ++d) s_o[g][12 * part + d] = o[d];
-    __syncthreads();
-    const int t4 = wave * 64 + lane;      // 0 .. 255 within the task's four waves
-    if (valid && t4 < kHeadDim) {
-        float mx = -INFINITY;
-        for (int i = 0; i < 64; ++i) mx = fmaxf(mx, s_m[i]);
-        float lt = 0.f, ot = 0.f;
-        for (int i = 0; i < 64; ++i) {
-            const float w = s_m[i] == -INFINITY ? 0.f : __expf(s_m[i] - mx);
-            lt = fmaf(s_l[i], w, lt);
-            ot = fmaf(s_o[i][t4], w, ot);
-        }
-        st_wt(y + frag_index(b, h * kHeadDim + t4), ot / lt);
-    }
-    __syncthreads();
-}
-
-template <typename TT>
-__global__ __launch_bounds__(kRowsThreads) void decode_chain_kernel(ChainArgs a) {
-    __shared__ float s_red[2][kRowsWaves][16];
-    __shared__ __attribute__((aligned(16))) float s_part[kRowsWaves][3][256];      // (up to three 16-row tiles per workgroup)
-    __shared__ float s_m[2][64], s_l[2][64], s_o[2][64][kHeadDim];
-    const int tid0 = threadIdx.x, wg0 = blockIdx.x;
-    const int E = a.E, H = a.H, M = a.M;
-    const int pos = *a.d_len;
-    ChainBar bar{a.bar, 0u, 0u, false};
-    bar.base = __hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (unsigned)(5 * a.n_layers) * (unsigned)kChainWG;
-    const long XF = 0, Q = (long)E * 64, YF = Q + 16L * E, XMR = YF + (long)E * 64, XMF = XMR + 16L * E, HF = XMF + (long)E * 64, XNR = HF + 4L * E * 64;
-    const long LS = XNR + 16L * E;      // floats per layer (fragment-major buffers: K x 4 column blocks x 16 scenes = 64 K floats)
-    for (int l = 0; l < a.n_layers; ++l) {
-        // (laundered per layer: nothing derived from the thread / workgroup index is hoisted out of the loop into registers)
-        int tid = tid0, wg = wg0;
-        asm volatile("" : "+v"(tid));
-        asm volatile("" : "+s"(wg));
-        const int wave = tid >> 6, lane = tid & 63;
-        const OarLayerDev lw = a.layers[l];
-        float* wl = a.work + (long)l * LS;
-        const float* x_frag = l == 0 ? a.xfrag_in : wl + XF;
-        const float* x_row = l == 0 ? a.xdec : wl - LS + XNR;
-        TT* cache = reinterpret_cast<TT*>(a.kvcache) + (long)l * a.kv_layer_stride;
-        const bool last = l + 1 == a.n_layers;
-        // ---- A: LN + q|k|v rows (48-row tiles: 48 workgroups)
-        {
-            RowsArgs r{};
-            r.x = x_frag; r.M = M; r.ln_w = lw.ln_a; r.W = lw.Wqkv; r.bias = lw.bqkv; r.N = 3 * E; r.K = E; r.out = wl + Q; r.ldo = E;
-            r.cache = cache; r.scene_stride = a.kv_scene_stride; r.Lmax = a.Lmax; r.E = E;
-            ChainRows<TT, ROWS_QKV, 3, 3, true> ph;
-            ph.prefetch(r, nullptr, wg, (3 * E + 47) / 48, tid);
-            if (l > 0) chain_wait(bar);
-            ph.run(r, pos, s_red, s_part, tid);
-            chain_arrive(bar);
-        }
-        // ---- B: attention, two (scene, head) tasks per workgroup round
-        chain_wait(bar);
-        for (int t0 = 2 * wg; t0 < M * H; t0 += 2 * kChainWG) {
-            const int task = t0 + (wave >> 2);
-            chain_attn_task<TT>(wl + Q, cache, a.kv_scene_stride, H, a.Lmax, pos + 1, task / H, task % H, wl + YF, wave & 3, lane,
-                                s_m[wave >> 2], s_l[wave >> 2], s_o[wave >> 2], task < M * H);
-        }
-        chain_arrive(bar);
-        // ---- C: attention c_proj + residual -> x' (row-major + fragment-major)
-        {
-            RowsArgs r{};
-            r.x = wl + YF; r.M = M; r.W = lw.Wo; r.bias = lw.bo; r.N = E; r.K = E; r.out = wl + XMR; r.ldo = E; r.out_frag = wl + XMF; r.E = E;
-            ChainRows<TT, ROWS_RESID, 1, 3, false> ph;
-            ph.prefetch(r, x_row, wg, (E + 15) / 16, tid);
-            chain_wait(bar);
-            ph.run(r, pos, s_red, s_part, tid);
-            chain_arrive(bar);
-        }
-        // ---- D: LN + c_fc + GELU (48-row tiles: 64 workgroups)
-        {
-            RowsArgs r{};
-            r.x = wl + XMF; r.M = M; r.ln_w = lw.ln_b; r.W = lw.Wfc; r.N = 4 * E; r.K = E; r.out_frag = wl + HF; r.E = E;
-            ChainRows<TT, ROWS_GELU, 3, 3, true> ph;
-            ph.prefetch(r, nullptr, wg, (4 * E + 47) / 48, tid);
-            chain_wait(bar);
-            ph.run(r, pos, s_red, s_part, tid);
-            chain_arrive(bar);
-        }
-        // ---- E: mlp c_proj + residual -> the next layer's x (the last layer's: the step's output)
-        {
-            RowsArgs r{};
-            r.x = wl + HF; r.M = M; r.W = lw.Wproj; r.N = E; r.K = 4 * E; r.out = last ? a.xdec : wl + XNR; r.ldo = E; r.out_frag = last ? a.xfrag_out : wl + LS + XF; r.E = E;
-            ChainRows<TT, ROWS_RESID, 1, 6, false> ph;
-            ph.prefetch(r, wl + XMR, wg, (E + 15) / 16, tid);
-            chain_wait(bar);
-            ph.run(r, pos, s_red, s_part, tid);
-            chain_arrive(bar);
-        }
-    }
-    chain_wait(bar);      // everybody has arrived at the last barrier: the generation can move on
-    if (wg0 == 0 && tid0 == 0) __hip_atomic_fetch_add(a.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 }  // namespace
 
 template <typename TT, int MODE, int NB, int RT, int JB, bool LN>
@@ -695,14 +347,5 @@ void launch_attn_decode_batched(hipStream_t s, const float* q, const TT* cache, 
 }
 template void launch_attn_decode_batched<bf16_t>(hipStream_t, const float*, const bf16_t*, long, int, int, int, const int*, float*);
 template void launch_attn_decode_batched<f16_t>(hipStream_t, const float*, const f16_t*, long, int, int, int, const int*, float*);
-
-template <typename TT>
-hipError_t launch_decode_chain(hipStream_t s, const ChainArgs& a) {
-    hipLaunchKernelGGL((decode_chain_kernel<TT>), dim3(kChainWG), dim3(kRowsThreads), 0, s, a);
-    return hipGetLastError();
-}
-template hipError_t launch_decode_chain<bf16_t>(hipStream_t, const ChainArgs&);
-template hipError_t launch_decode_chain<f16_t>(hipStream_t, const ChainArgs&);
-size_t decode_chain_work_floats(int n_layers, int E) { return (size_t)n_layers * ((size_t)E * 64 * 3 + (size_t)4 * E * 64 + (size_t)16 * E * 3) + (size_t)E * 64; }
 
 }  // namespace umgen

@@ -135,11 +135,6 @@ struct umgen_engine {
     std::vector<void*> eng_wf2;             // per BlockOAR: c_fc as matrix-core fragments (UMGEN_ENG_MFMA & 4)
     unsigned long long* eng_stamps = nullptr;   // UMGEN_DEBUG_TIMING: per-phase ticks of the engine (printed at destroy)
     size_t eng_gloc_bytes = 0;
-    // Multi-scene decode engine (oar_engine_ms.hip): from `ms_min` scenes per call on, a work item is (block of ceil(B / 8) scenes, layer) with the
-    // scenes as (hi, lo) column pairs of the matrix-core instruction (UMGEN_DECODE_MS=n: from n scenes on; default 0 = never)
-    unsigned long long* eng_gloc_ms = nullptr;
-    unsigned long long* eng_stamps_ms = nullptr;
-    size_t eng_gloc_ms_bytes = 0;
     // Chip-wide decode engine for wide layers (oar_engine_wide.hip; n_embd 1536; one launch per scene and step).  Default: engines created for ONE scene per
     // call (two scenes as two launches: step 1696 us against 1523 on five launches per layer, four: 3382 against 2217 -- profiles/r05_wide2x_engine.txt);
     // UMGEN_DECODE_WIDE=n (1..4): engines of up to n scenes per call; =0: five launches per layer
@@ -150,8 +145,7 @@ struct umgen_engine {
     unsigned int *wide_ticket = nullptr, *wide_err = nullptr;
     unsigned long long* wide_stamps = nullptr;
     bool use_wide(int B) const { return wide_enabled && tsz == 2 && B <= 4; }
-    int ms_min = 0;                       // off by default: measured behind the one-scene engine (<= 23 scenes) and the batched layer + lanes (24 .. 64) at 16 / 32 / 64 scenes
-    bool use_ms(int B) const { return eng_enabled && tsz == 2 && ms_min > 0 && B >= ms_min && B <= kEngMsMaxBatch && E == kEngE; }
+    void* burn_buf = nullptr;             // UMGEN_DEBUG_BURN (measurement builds): the synthetic load's stream buffer
     int fg_xcds = 8;
     unsigned eng_epoch = 16u;             // first hand-off tag of the next frame (see run_frame)
     int step_graph_NG = -1;
@@ -167,7 +161,7 @@ struct umgen_engine {
     int batched_min = 24;               // measured crossover with the engine (profiles/r04_lanes_sweep.txt): 20 scenes 1546 (engine) vs 1674 us per step, 24: 1843 vs 1708, 28: 2104 vs 1775
     float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;   // fragment-major x / attention output [64 E], gelu(c_fc) [64 x 4E] of the batched layer
     bool use_batched(int B) const {      // (in_lanes: a lane's sub-batch of a batch that qualified)
-        return tsz == 2 && !use_ms(B) && (in_lanes || (batched_min > 0 && B >= batched_min)) && B <= kRowsMaxM && E % 32 == 0 && E <= 768;
+        return tsz == 2 && (in_lanes || (batched_min > 0 && B >= batched_min)) && B <= kRowsMaxM && E % 32 == 0 && E <= 768;
     }
     // Decode LANES: the scenes of a batch are independent until the frame is complete (own K/V rows, own sampler state, own RNG
     // stream), and a batched layer launch for <= 16 scenes is latency-bound (5 dependent launches per layer, 48 - 96 workgroups each,
@@ -181,14 +175,8 @@ struct umgen_engine {
         hipEvent_t done = nullptr;
         OarState* st = nullptr;
         float *xfrag = nullptr, *afrag = nullptr, *hfrag = nullptr;
-        float* chain_work = nullptr;         // decode_chain_kernel's per-layer workspaces and barrier words of this lane
-        unsigned* chain_bar = nullptr;
         hipGraphExec_t graph[4][3] = {};
     };
-    // The layers of a lane's decode step as ONE persistent launch (decode_batched.hip decode_chain_kernel; UMGEN_DECODE_CHAIN=0: five launches per layer)
-    bool chain_enabled = false;
-    float* chain_work = nullptr;             // (the current view's: a lane's, or the engine's own for a batch that is one lane)
-    unsigned* chain_bar = nullptr;
     DecLane lane[kMaxLanes];
     hipEvent_t ev_lane_fork = nullptr;
     int lanes_env = -1;                  // UMGEN_DECODE_LANES=n: n lanes whenever the batched layer runs (1 = off); -1: by batch size
@@ -559,15 +547,6 @@ int oar_layers(umgen_engine* e, int B, int ns) {
         if (e->use_batched(B)) {      // five launches per layer for the whole batch: LN + q|k|v, attention, c_proj (+x), LN + c_fc + GELU, mlp c_proj (+x)
             // activations between the launches are fragment-major (decode_batched.hip); x also stays row-major in xdec (sampler, residual)
             launch_rows_to_frag(e->stream, e->xdec, E, B, E, e->xfrag);
-            if (e->chain_enabled && e->chain_work && B <= 16 && !e->dbg_same_layer) {      // one lane: the 36 layers as one persistent launch
-                ChainArgs c{};
-                c.layers = e->d_layers; c.n_layers = (int)e->oar.size();
-                c.kvcache = e->kvcache; c.kv_layer_stride = e->kv_layer_stride; c.kv_scene_stride = e->kv_scene_stride; c.Lmax = e->Lmax;
-                c.d_len = d_len; c.xdec = e->xdec; c.xfrag_in = e->xfrag; c.xfrag_out = e->xfrag; c.work = e->chain_work; c.bar = e->chain_bar;
-                c.M = B; c.E = E; c.H = H;
-                HIPCHK(e, launch_decode_chain<T>(e->stream, c));      // (xfrag: read by the first phase, rewritten by the last -- the head launch streams it)
-                return 0;
-            }
             for (size_t li = 0; li < e->oar.size(); ++li) {
                 const SubW& w = e->oar[e->dbg_same_layer ? 0 : li];
                 T* cache = reinterpret_cast<T*>(e->kvcache) + (long)li * e->kv_layer_stride;
@@ -602,22 +581,6 @@ int oar_layers(umgen_engine* e, int B, int ns) {
         }
         return 0;
     }
-    if (const umgen_engine::EngStream* es = (sizeof(T) == 2 && e->use_ms(B)) ? e->eng_for(e->stream) : nullptr) {
-        OarMsArgs a{};
-        a.layers = e->d_layers; a.n_layers = (int)e->oar.size();
-        a.kvcache = reinterpret_cast<bf16_t*>(e->kvcache); a.kv_layer_stride = e->kv_layer_stride; a.kv_scene_stride = e->kv_scene_stride; a.Lmax = e->Lmax;
-        a.xdec = e->xdec; a.xfrag = e->xfrag; a.st = e->d_state; a.gx = e->eng_gx; a.gloc = e->eng_gloc_ms; a.ticket = e->eng_ticket; a.err = e->eng_err;
-        a.B = B; a.NG = es->NG;
-        a.ns = (B + 7) / 8;                      // at most 8 blocks: (35 + blocks) item slots per step
-        if (const char* fs = getenv("UMGEN_MS_SCENES")) a.ns = std::max(1, std::min(kEngMsScenes, atoi(fs)));   // measurement knob
-        a.nb = (B + a.ns - 1) / a.ns;
-        if ((unsigned)(a.nb * 64 * 8) > kEpochPerStep) return e->fail(UMGEN_E_UNSUPPORTED, "decode engine: %d blocks need more hand-off tags than one step has", a.nb);
-        memcpy(a.xcc_group, es->map, 16);
-        a.stamps = e->eng_stamps_ms;
-        a.fp16 = std::is_same<T, f16_t>::value ? 1 : 0;
-        HIPCHK(e, launch_oar_engine_ms(e->stream, a));
-        return 0;
-    }
     if (const umgen_engine::EngStream* es = sizeof(T) == 2 ? e->eng_for(e->stream) : nullptr) {
         OarEngineArgs a{};
         a.layers = e->d_layers; a.n_layers = (int)e->oar.size();
@@ -634,6 +597,12 @@ int oar_layers(umgen_engine* e, int B, int ns) {
         }
         a.D = es->NG / a.R;
         memcpy(a.xcc_group, es->map, 16);
+        if (const char* bs = getenv("UMGEN_DEBUG_BURN")) {      // measurement builds (-DUMGEN_ENG_BURN): "us,mfma,sleep,kb"
+            int us = 0, mf = 0, sl = 0, kb = 0;
+            if (sscanf(bs, "%d,%d,%d,%d", &us, &mf, &sl, &kb) >= 1) {
+                a.burn_ticks = us * 100; a.burn_mfma = mf; a.burn_sleep = sl; a.burn_kb = e->burn_buf ? kb : 0; a.burn_buf = e->burn_buf;
+            }
+        }
         a.stamps = e->eng_stamps;
         a.fp16 = std::is_same<T, f16_t>::value ? 1 : 0;
         // More than 4 scenes: the systolic schedule (oar_engine.hip) -- the scenes flow through the 8 groups, group g working on layers
@@ -797,24 +766,20 @@ struct DecView {
     double* d_boxes;
     unsigned long long* d_seeds;
     OarState* d_state;
-    float* chain_work;
-    unsigned* chain_bar;
 };
 DecView current_view(const umgen_engine* e) {
     return DecView{e->stream, e->xdec, e->qdec, e->logits, e->logits_tar, e->cond, e->xfrag, e->afrag, e->hfrag, e->kvcache,
-                   e->d_tokens, e->d_prev_box, e->d_nboxes, e->d_control, e->d_boxes, e->d_seeds, e->d_state, e->chain_work, e->chain_bar};
+                   e->d_tokens, e->d_prev_box, e->d_nboxes, e->d_control, e->d_boxes, e->d_seeds, e->d_state};
 }
 void apply_view(umgen_engine* e, const DecView& v) {
     e->stream = v.stream; e->xdec = v.xdec; e->qdec = v.qdec; e->logits = v.logits; e->logits_tar = v.logits_tar; e->cond = v.cond;
     e->xfrag = v.xfrag; e->afrag = v.afrag; e->hfrag = v.hfrag; e->kvcache = v.kvcache; e->d_tokens = v.d_tokens; e->d_prev_box = v.d_prev_box;
     e->d_nboxes = v.d_nboxes; e->d_control = v.d_control; e->d_boxes = v.d_boxes; e->d_seeds = v.d_seeds; e->d_state = v.d_state;
-    e->chain_work = v.chain_work; e->chain_bar = v.chain_bar;
 }
 DecView lane_view(const umgen_engine* e, const DecView& all, const umgen_engine::DecLane& ln, int b0) {
     const long E = e->E;
     DecView v = all;
     v.stream = ln.s; v.d_state = ln.st; v.xfrag = ln.xfrag; v.afrag = ln.afrag; v.hfrag = ln.hfrag;
-    v.chain_work = ln.chain_work; v.chain_bar = ln.chain_bar;
     v.xdec = all.xdec + b0 * E; v.qdec = all.qdec + b0 * E; v.logits = all.logits + (long)b0 * 8192;
     v.logits_tar = all.logits_tar + (long)b0 * kNBox * e->cfg.bbox3d_vocab; v.cond = all.cond + (long)b0 * kSeq * E;
     v.kvcache = static_cast<unsigned char*>(all.kvcache) + (size_t)b0 * e->kv_scene_stride * e->tsz;
@@ -859,7 +824,7 @@ int enqueue_step(umgen_engine* e, int B, int mod, int ns, const umgen_trace* tr,
         const int V = mod == 1 ? e->cfg.map_vocab : (mod == 2 ? e->cfg.bbox3d_vocab : e->cfg.img_vocab);
         bool head_done = false;
         if constexpr (sizeof(T) == 2) {
-            if (e->use_batched(B) || (e->use_ms(B) && e->eng_for(e->stream))) {
+            if (e->use_batched(B)) {
                 RowsArgs r{};
                 r.x = e->xfrag; r.M = B; r.ln_w = e->ln_oar; r.W = head; r.N = V; r.K = E; r.mode = ROWS_F32; r.out = e->logits; r.ldo = sa.ld_logits; r.E = E;   // (xfrag: the last layer's copy of x)
                 launch_rows_mfma<T>(e->stream, r);
@@ -1051,7 +1016,6 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         HIPCHK(e, hipDeviceSynchronize());
         HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
         HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
-        HIPCHK(e, hipMemset(e->eng_gloc_ms, 0, e->eng_gloc_ms_bytes));
         e->eng_epoch = 16u;
     }
     OarState s0{j_begin, io.frame_idx, forced ? 1 : 0, io.control_slot ? 1 : 0, 0, e->eng_epoch, sp};
@@ -1130,18 +1094,22 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
     }
     // given map (/ boxes): positions 0 .. given_end - 2 as one pass, the step loop starts at given_end - 1 (UMGEN_PREFIX_PASS=0: replay every
-    // given position as a decode step, rounds 1-4).  Not beside a background TAR pass: it works in the stacks' buffers.
+    // given position as a decode step, rounds 1-4).  WHICH form runs is a property of the engine, never of the frame: the pass works in the stacks'
+    // buffers, so an engine created with the overlapped background TAR pass (e->overlap) replays on every frame, and every other engine takes the
+    // pass on every frame -- traced or not, followed by another frame or not -- so that rollout(n) stays a token prefix of rollout(n + 1) in the
+    // 16-bit modes, whose two forms differ in arithmetic.
     const char* ppe = getenv("UMGEN_PREFIX_PASS");      // (read per frame: the tests compare both forms in one process)
     const bool prefix_pass_off = ppe && ppe[0] == '0';
-    if (given_end > kPoseEos + 1 && !prefix_pass_off && !(ov_active && io.next_follows) && !e->bg_pending && j_begin == 0 && !tr) {
+    OarState s1 = s0;                                   // (function scope: the asynchronous uploads below read it until the stream is drained)
+    if (given_end > kPoseEos + 1 && !prefix_pass_off && !e->overlap && j_begin == 0) {
         if (int rc = run_prefix_prefill<T>(e, B, given_end)) return rc;
         j_begin = given_end - 1;
-        OarState s1 = s0;
         s1.step = j_begin;
         HIPCHK(e, hipMemcpyAsync(e->d_state, &s1, sizeof(s1), hipMemcpyHostToDevice, st));
         for (int l = 0; l < n_lanes && n_lanes > 1; ++l) HIPCHK(e, hipMemcpyAsync(e->lane[l].st, &s1, sizeof(s1), hipMemcpyHostToDevice, st));
         e->tm.prefix_passes += 1;
     }
+    const int steps_run = j_end - j_begin;             // decode steps of this frame (a prefix pass replaces the given positions' steps)
     const bool graphs = e->cfg.use_graphs && !tr && !e->profiling;   // profiled frames time every decode step's layer kernel(s) with events
     const bool batched = sizeof(T) == 2 && e->use_batched(B);       // the batched decode layer takes the step (oar_layers)
     const bool wide = sizeof(T) == 2 && e->use_wide(B);           // the chip-wide engine of the wide layers: one launch per scene and step
@@ -1224,7 +1192,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                     hipEventRecord(e->layer_ev[e->layer_ev_used++].second, ln.s);
                     e->tm.layers_launches += run - 1;      // (the frame's bookkeeping below adds one per event pair)
                 }
-                e->tm.oar_kernels += (int64_t)run * ((e->chain_enabled && ln.chain_work ? 1 : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
+                e->tm.oar_kernels += (int64_t)run * (5 * (int64_t)e->oar.size() + (mod == 0 ? 1 : (mod == 2 ? 3 : 2)));
             }
             j += run - 1;
         }
@@ -1276,7 +1244,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         }
         e->tm.oar_kernels += (eng ? (wide ? B : 1) : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
     }
-    e->tm.oar_steps += kImgEos;
+    e->tm.oar_steps += steps_run;
     HIPCHK(e, hipEventRecord(e->ev[3], st));
     HIPCHK(e, hipMemcpyAsync(io.out_tokens, e->d_tokens, (size_t)B * kTokPerFrame * 4, hipMemcpyDeviceToHost, st));
     int counters[8] = {};
@@ -1288,18 +1256,6 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         const hipError_t le = e->launch_status != hipSuccess ? e->launch_status : hipGetLastError();
         e->launch_status = hipSuccess;
         if (le != hipSuccess) return e->fail(UMGEN_E_HIP, "a kernel launch of this frame was refused: %s", hipGetErrorString(le));
-    }
-    if (e->chain_enabled && batched) {      // a grid barrier of decode_chain_kernel timed out in this frame: never return its tokens
-        unsigned words[4 * (umgen_engine::kMaxLanes + 1)] = {};
-        unsigned* bars[umgen_engine::kMaxLanes + 1] = {e->chain_bar};
-        for (int l = 0; l < umgen_engine::kMaxLanes; ++l) bars[l + 1] = e->lane[l].chain_bar;
-        for (int i = 0; i <= umgen_engine::kMaxLanes; ++i)
-            if (bars[i]) HIPCHK(e, hipMemcpy(words + 4 * i, bars[i], 16, hipMemcpyDeviceToHost));
-        for (int i = 0; i <= umgen_engine::kMaxLanes; ++i)
-            if (words[4 * i + 2]) {
-                (void)hipMemset(bars[i] + 2, 0, 4);
-                return e->fail(UMGEN_E_HIP, "decode chain kernel gave up waiting at a grid barrier (arrival target 0x%08x)", words[4 * i + 2]);
-            }
     }
     if (eng_err) {   // a hand-off of the decode engine timed out (e.g. two engines sharing one GPU): never return tokens from such a frame
         (void)hipMemset(wide ? e->wide_err : e->eng_err, 0, sizeof(unsigned));
@@ -1318,7 +1274,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     }
     hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->tm.total_ms += ms;
     e->tm.frames += 1;
-    e->tm.decode_engine = eng ? (wide ? 3 : (e->use_ms(B) ? 2 : 1)) : 0;      // 2: the multi-scene engine (oar_engine_ms.hip), 3: the chip-wide engine of the wide layers
+    e->tm.decode_engine = eng ? (wide ? 3 : 1) : 0;      // 1: the XCD-resident engine, 3: the chip-wide engine of the wide layers (2: the retired multi-scene engine of round 5)
     e->tm.decode_batched = batched ? 1 : 0;
     e->tm.decode_lanes = batched ? n_lanes : 0;
     e->tm.engine_fallback = e->eng_fallback ? 1 : 0;
@@ -1560,7 +1516,6 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         // falls back to the five-launch decode layer WITH the overlapped TAR pass, and says so.
         HIPCHK(e, hipStreamCreate(&e->stream));
         HIPCHK(e, oar_engine_prepare());
-        HIPCHK(e, oar_engine_ms_prepare());
         unsigned* d_cnt = nullptr;
         HIPCHK(e, hipMalloc(&d_cnt, 64));
         umgen_engine::EngStream& es = e->eng_fg;
@@ -1833,23 +1788,6 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         }
         HIPCHK(e, hipEventCreateWithFlags(&e->ev_lane_fork, hipEventDisableTiming));
     }
-    {
-        const char* ch = getenv("UMGEN_DECODE_CHAIN");
-        e->chain_enabled = e->eng_enabled && e->tsz == 2 && E == kEngE && Bm >= 2 && ch && ch[0] != '0';
-        if (e->chain_enabled) {
-            const size_t wf = decode_chain_work_floats(cfg->n_oar_layer, E);
-            auto mk = [&](float** w, unsigned** b) -> int {
-                if (int rc = dalloc(e, w, wf)) return rc;
-                if (int rc = dalloc(e, b, (size_t)4)) return rc;
-                HIPCHK(e, hipMemset(*w, 0, wf * 4));
-                HIPCHK(e, hipMemset(*b, 0, 16));
-                return UMGEN_OK;
-            };
-            if (int rc = mk(&e->chain_work, &e->chain_bar)) return rc;
-            for (auto& ln : e->lane)
-                if (ln.s) { if (int rc = mk(&ln.chain_work, &ln.chain_bar)) return rc; }
-        }
-    }
     if (int rc = dalloc(e, &e->logits, 3 * Bm * 8192)) return rc;
     if (int rc = dalloc(e, &e->logits_tar, Bm * kNBox * (size_t)cfg->bbox3d_vocab)) return rc;
     e->kv_scene_stride = (long)e->Lmax * 2 * E;
@@ -1908,17 +1846,12 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         HIPCHK(e, hipMemset(e->eng_gx, 0, Bm * kEngE * 8));
         HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
         HIPCHK(e, hipMemset(e->eng_err, 0, 16));
-        if (const char* mm = getenv("UMGEN_DECODE_MS")) e->ms_min = atoi(mm);
-        if (e->tsz == 2 && Bm >= 1 && e->ms_min > 0 && (int)Bm >= std::min(e->ms_min, kEngMsMaxBatch)) {
-            e->eng_gloc_ms_bytes = (size_t)16 * kEngMsLocStride * 8;
-            if (int rc = dev_alloc(e, reinterpret_cast<void**>(&e->eng_gloc_ms), e->eng_gloc_ms_bytes)) return rc;
-            HIPCHK(e, hipMemset(e->eng_gloc_ms, 0, e->eng_gloc_ms_bytes));
-            if (getenv("UMGEN_DEBUG_TIMING")) {
-                if (int rc = dalloc(e, &e->eng_stamps_ms, (size_t)16)) return rc;
-                HIPCHK(e, hipMemset(e->eng_stamps_ms, 0, 128));
+        if (const char* bs = getenv("UMGEN_DEBUG_BURN")) {
+            int us = 0, mf = 0, sl = 0, kb = 0;
+            if (sscanf(bs, "%d,%d,%d,%d", &us, &mf, &sl, &kb) == 4 && kb > 0) {
+                if (int rc = dev_alloc(e, &e->burn_buf, (size_t)kb << 10)) return rc;
+                HIPCHK(e, hipMemset(e->burn_buf, 1, (size_t)kb << 10));
             }
-        } else {
-            e->ms_min = 0;
         }
         if (getenv("UMGEN_DEBUG_TIMING")) fprintf(stderr, "[umgen] decode engine: on (8 XCD groups)\n");
     }
@@ -2249,12 +2182,15 @@ int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in,
     if (!e->finalized) return e->fail(UMGEN_E_STATE, "umgen_finalize_weights has not been called");
     if (e->cfg.precision == UMGEN_PREC_FP32) return e->fail(UMGEN_E_UNSUPPORTED, "16-bit engines only");
     if (B < 1 || B > e->cfg.max_batch || L < 0 || L >= e->Lmax) return e->fail(UMGEN_E_INVALID, "B=%d L=%d", B, L);
-    if (use_engine && use_engine != 3 && !e->eng_enabled) return e->fail(UMGEN_E_UNSUPPORTED, "decode engine not available on this engine");
-    if (e->eng_enabled && e->eng_epoch > 0xE0000000u) {   // same wrap rule as run_frame
+    if (use_engine != 0 && use_engine != 1 && use_engine != 3) return e->fail(UMGEN_E_INVALID, "use_engine %d (0: five launches per layer, 1: XCD-resident engine, 3: chip-wide engine)", use_engine);
+    if (use_engine == 1 && !e->eng_enabled) return e->fail(UMGEN_E_UNSUPPORTED, "decode engine not available on this engine");
+    if (e->eng_epoch > 0xE0000000u) {   // same wrap rule as run_frame, for both engines' granule buffers
         HIPCHK(e, hipDeviceSynchronize());
-        HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
-        HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
-        HIPCHK(e, hipMemset(e->eng_gloc_ms, 0, e->eng_gloc_ms_bytes));
+        if (e->eng_enabled) {
+            HIPCHK(e, hipMemset(e->eng_gx, 0, (size_t)e->cfg.max_batch * kEngE * 8));
+            HIPCHK(e, hipMemset(e->eng_gloc, 0, e->eng_gloc_bytes));
+        }
+        if (e->wide_enabled) HIPCHK(e, hipMemset(e->wide_gran, 0, oar_engine_wide_granules() * 8));
         e->eng_epoch = 16u;
     }
     const unsigned epoch = e->eng_epoch;   // tags never repeat across calls
@@ -2265,29 +2201,21 @@ int umgen_dbg_oar_step(umgen_engine* e, int32_t B, int32_t L, const float* x_in,
     HIPCHK(e, hipMemcpyAsync(e->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(e->xdec, x_in, (size_t)B * e->E * 4, hipMemcpyHostToDevice, st));
     const bool en = e->eng_enabled, wide_keep = e->wide_enabled;
-    const int ms_keep = e->ms_min;
     if (use_engine == 3 && !e->wide_enabled) return e->fail(UMGEN_E_UNSUPPORTED, "chip-wide decode engine not available on this engine");
     e->wide_enabled = wide_keep && use_engine == 3;
-    e->eng_enabled = en && use_engine && use_engine != 3;
-    if (use_engine == 2) {      // the multi-scene engine whatever B is
-        if (!e->eng_gloc_ms) return e->fail(UMGEN_E_UNSUPPORTED, "multi-scene decode engine not available on this engine");
-        e->ms_min = 1;
-    } else {
-        e->ms_min = 0;
-    }
+    e->eng_enabled = en && use_engine == 1;
     e->stream = st;
     const int lrc = e->cfg.precision == UMGEN_PREC_FP16 ? oar_layers<f16_t>(e, B, attn_nsplit(L + 1)) : oar_layers<bf16_t>(e, B, attn_nsplit(L + 1));
     e->stream = keep;
     e->eng_enabled = en;
     e->wide_enabled = wide_keep;
-    e->ms_min = ms_keep;
     if (lrc) return lrc;
     HIPCHK(e, hipMemcpyAsync(x_out, e->xdec, (size_t)B * e->E * 4, hipMemcpyDeviceToHost, st));
     unsigned eng_err = 0;
     if (use_engine) HIPCHK(e, hipMemcpyAsync(&eng_err, use_engine == 3 ? e->wide_err : e->eng_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
-    if (eng_err) {
-        (void)hipMemset(e->eng_err, 0, sizeof(unsigned));
+    if (eng_err) {      // clear the word of the engine that ran (the other engine's may not exist: ADVICE r5)
+        (void)hipMemset(use_engine == 3 ? e->wide_err : e->eng_err, 0, sizeof(unsigned));
         return e->fail(UMGEN_E_HIP, "decode engine gave up waiting for hand-off tag 0x%08x", eng_err);
     }
     return UMGEN_OK;
@@ -2297,16 +2225,6 @@ int umgen_destroy(umgen_engine* e) {
     if (!e) return UMGEN_OK;
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();   // every stream of this engine (decode, background, side, unmasked) is idle before anything is freed
-    if (e->eng_stamps_ms) {
-        unsigned long long st[16];
-        if (hipMemcpy(st, e->eng_stamps_ms, 128, hipMemcpyDeviceToHost) == hipSuccess && st[15]) {
-            const char* nm[11] = {"wait x", "LN + qkv rows", "wait qkv", "attention", "wait att", "c_proj", "wait x'", "LN + c_fc + GELU", "mlp partial sums", "wait partial sums", "add partials"};
-            fprintf(stderr, "[umgen] multi-scene decode engine, group 0 rank 0, us per item over %llu items:", st[15]);
-            double tot = 0;
-            for (int p = 0; p < 11; ++p) { fprintf(stderr, " %s %.2f", nm[p], (double)st[p] / 100.0 / (double)st[15]); tot += (double)st[p] / 100.0 / (double)st[15]; }
-            fprintf(stderr, " | total %.2f\n", tot);
-        }
-    }
     if (e->wide_stamps) {
         unsigned long long st[16];
         if (hipMemcpy(st, e->wide_stamps, 128, hipMemcpyDeviceToHost) == hipSuccess && st[15]) {

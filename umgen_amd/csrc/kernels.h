@@ -143,24 +143,6 @@ void launch_rows_to_frag(hipStream_t s, const float* x, long ldx, int M, int K, 
 template <typename TT> void launch_attn_decode_batched(hipStream_t s, const float* q, const TT* cache, long scene_stride, int B, int H, int Lmax,
                                                         const int* d_len, float* y);
 
-// The BlockOAR layers of a decode step of one lane (<= 16 scenes) as ONE persistent launch of kChainWG workgroups: the five launches of a layer as
-// phases with a grid barrier behind each (decode_batched.hip decode_chain_kernel)
-constexpr int kChainWG = 64;                   // workgroups per lane (4 lanes: one per CU -- every lane's launch is resident whatever else runs)
-struct OarLayerDev;
-struct ChainArgs {
-    const OarLayerDev* layers; int n_layers;
-    void* kvcache; long kv_layer_stride, kv_scene_stride; int Lmax;   // [layer][scene][2][H][Lmax][48] (the lane's first scene)
-    const int* d_len;                          // cached keys before this step
-    float* xdec;                               // [M][E] row-major: in = input of layer 0, out = output of the last layer
-    const float* xfrag_in;                     // the same input, fragment-major
-    float* xfrag_out;                          // the output once more, fragment-major (head launch)
-    float* work;                               // decode_chain_work_floats() per lane
-    unsigned* bar;                             // [4]: arrivals, generation, error flag
-    int M, E, H;
-};
-template <typename TT> hipError_t launch_decode_chain(hipStream_t s, const ChainArgs& a);
-size_t decode_chain_work_floats(int n_layers, int E);
-
 // ------------------------------------------------------------------------------------------------
 // XCD-resident decode engine (oar_engine.hip): all BlockOAR layers of one decode step in one launch, bf16 weights, n_embd 768
 // ------------------------------------------------------------------------------------------------
@@ -197,33 +179,11 @@ struct OarEngineArgs {
     unsigned long long* stamps;                // optional [8]: 100 MHz ticks per phase + item count, accumulated by rank 0 of group 0
     int fp16;                                  // 0: weights and K/V cache hold bfloat16 bits, 1: IEEE half (UMGEN_PREC_FP16)
     int systolic;                              // 1: layer-resident groups, the scenes flow through all NG groups (R, D unused); B * 64 * 8 tags
+    // measurement builds only (-DUMGEN_ENG_BURN, UMGEN_DEBUG_BURN="us,mfma,sleep,kb"): the groups no scene uses run a synthetic matrix-core / streaming
+    // load for burn_ticks (100 MHz) -- what the decode step costs while the other XCDs work (profiles/r06_engine_contention.txt)
+    int burn_ticks, burn_mfma, burn_sleep, burn_kb;
+    const void* burn_buf;
 };
-// ------------------------------------------------------------------------------------------------
-// multi-scene XCD-resident decode engine (oar_engine_ms.hip): work item = (block of <= 8 scenes, layer), the scenes as (hi, lo) column
-// pairs of the matrix-core instruction; same groups / tickets / epoch tags as the one-scene engine
-// ------------------------------------------------------------------------------------------------
-constexpr int kEngMsScenes = 8;                // scenes per work item (16 MFMA columns)
-constexpr int kEngMsMaxBatch = 64;             // 8 blocks of 8 scenes
-constexpr int kEngMsLocStride = kEngMsScenes * (3 * kEngE + kEngE + kEngE) + kEngGroup * kEngMsScenes * kEngE;   // granules per group: q|k|v, attention out, x' [8][..], mlp partial sums [32][8][768]
-struct OarMsArgs {
-    const OarLayerDev* layers; int n_layers;
-    bf16_t* kvcache; long kv_layer_stride, kv_scene_stride; int Lmax;   // [layer][scene][2][H][Lmax][48]
-    float* xdec;                               // [B][E]: in = input of layer 0, out = output of the last layer
-    float* xfrag;                              // nullable: the last layer's x once more, fragment-major (frag_index) for the head launch
-    const OarState* st;
-    unsigned long long* gx;                    // [max_batch][E] cross-group x granules (shared with the one-scene engine)
-    unsigned long long* gloc;                  // [NG][kEngMsLocStride] group-private granules
-    unsigned int* ticket;
-    unsigned int* err;
-    int B, NG, ns, nb;                         // scenes; groups; scenes per block; blocks (ns * nb >= B, nb <= 32: tag budget)
-    unsigned char xcc_group[16];
-    unsigned long long* stamps;                // optional [16]
-    int fp16;
-};
-size_t oar_engine_ms_lds_bytes();
-hipError_t oar_engine_ms_prepare();
-hipError_t launch_oar_engine_ms(hipStream_t s, const OarMsArgs& a);
-
 // ------------------------------------------------------------------------------------------------
 // chip-wide decode engine for wide layers (oar_engine_wide.hip): n_embd 1536, one scene per launch, 256 workgroups (6 compute + 2 poll waves),
 // hand-offs across the fabric

@@ -1,5 +1,4 @@
-// Helpers shared by the XCD-resident decode engines (oar_engine.hip: one scene per work item; oar_engine_ms.hip: several scenes per
-// work item): XCD identification, {tag, value} hand-off granules and their bounded polling, wave-uniform-base loads, 16-bit weight
+// Helpers shared by the decode engines (oar_engine.hip: XCD-resident, one scene per work item; oar_engine_wide.hip: chip-wide, 2x width): XCD identification, {tag, value} hand-off granules and their bounded polling, wave-uniform-base loads, 16-bit weight
 // widening, transposed / whole-wave reductions, matrix-core weight fragments.  Everything here is internal to the two engine files.
 #pragma once
 #include "frame.h"

@@ -372,6 +372,43 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
     const int R = SYS ? 1 : a.R, D = SYS ? a.NG : a.D;
     const int rounds = (a.B + R - 1) / R;
     const int pipe = g / D, q = g % D;      // pipeline (scene slot of the round) and position in it
+#ifdef UMGEN_ENG_BURN
+    if (!SYS && a.burn_ticks > 0 && pipe >= a.B) {      // measurement: an idle pipeline's XCDs under a synthetic load
+        typedef typename Mma16<TT>::vec vec8;
+        f32x4_t acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        vec8 fa, fb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fa[j] = (typename Mma16<TT>::elem)(float)((tid0 + j) & 3); fb[j] = (typename Mma16<TT>::elem)(float)((tid0 * 3 + j) & 1); }
+        const unsigned long long until = t_k0 + (unsigned long long)a.burn_ticks;
+        const u32x4_t* buf = reinterpret_cast<const u32x4_t*>(a.burn_buf);
+        const long n16 = (long)a.burn_kb * 64;     // 16-byte pieces of the buffer
+        long pos = ((long)blockIdx.x * NT + tid0) % (n16 > 0 ? n16 : 1);
+        u32x4_t sink{0u, 0u, 0u, 0u};
+        while (wall_clock64() < until) {
+            for (int i = 0; i < a.burn_mfma; i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = Mma16<TT>::mfma(fa, fb, acc[j]);
+            }
+            if (n16 > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const u32x4_t v = __builtin_nontemporal_load(buf + pos);
+                    sink.x ^= v.x; sink.y ^= v.y; sink.z ^= v.z; sink.w ^= v.w;
+                    pos += (long)gridDim.x * NT;
+                    if (pos >= n16) pos -= n16;
+                }
+            }
+            for (int i = 0; i < a.burn_sleep; ++i) __builtin_amdgcn_s_sleep(4);
+        }
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tot += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+        if (tot == 1234.5f || (sink.x ^ sink.y ^ sink.z ^ sink.w) == 0x12345u) a.err[1] = 1u;     // (never true: keeps the loop alive)
+        return;
+    }
+#endif
     float* xs = lds + L_XS;
     float* xb = lds + L_XB;
     float* as = lds + L_AS;

@@ -162,7 +162,7 @@ __device__ inline float row_dot(const WRow& w, const XRegs& x) {
     return wave_sum_all(acc.x + acc.y);
 }
 
-// online-softmax state of a lane (its 12 of the head's 48 dimensions) and its folds (the multi-scene engine's, oar_engine_ms.hip)
+// online-softmax state of a lane (its 12 of the head's 48 dimensions) and its folds
 struct WAtt { float m, l; f32x2_t o[6]; };
 __device__ inline void watt_merge(WAtt& a, float mb, float lb, const f32x2_t (&ob)[6]) {
     const float M = fmaxf(a.m, mb);
