@@ -21,6 +21,8 @@ EXPORTS = ["umgen_create", "umgen_load_tensor", "umgen_finalize_weights", "umgen
            "umgen_vq_create", "umgen_vq_load_tensor", "umgen_vq_finalize", "umgen_vq_decode", "umgen_vq_last_error", "umgen_vq_destroy",
            "umgen_dbg_linear", "umgen_dbg_attn_spatial", "umgen_dbg_attn_temporal", "umgen_dbg_attn_decode", "umgen_dbg_gemv", "umgen_dbg_gemm_bench", "umgen_dbg_oar_step", "umgen_dbg_sample_topk", "umgen_dbg_batched_layer_bench"]
 
+HEADERS = ("common.h", "kernels.h", "frame.h", "oar_common.h", "bg_queue.h", "bg_worker.h", "gemm256_body.h", "attn_body.h", "rowops_body.h", "frame_body.h")
+
 PREC_FP32, PREC_BF16, PREC_FP16 = 0, 1, 2
 DT_F32, DT_BF16, DT_F16, DT_F64 = 0, 1, 2, 3
 
@@ -77,7 +79,7 @@ def source_hash() -> str:
     """sha256 over every source the library is built from (and the compile flags): the staleness check of build_library."""
     import hashlib
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, x) for x in ("common.h", "kernels.h", "frame.h", "oar_common.h")] + \
+    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, x) for x in HEADERS] + \
         [os.path.join(os.path.dirname(HERE), "include", "umgen.h")]
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -105,7 +107,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     from concurrent.futures import ThreadPoolExecutor
     objdir = os.path.join(CSRC, ".obj")
     os.makedirs(objdir, exist_ok=True)
-    hdr = b"".join(open(os.path.join(CSRC, x), "rb").read() for x in ("common.h", "kernels.h", "frame.h", "oar_common.h")) + \
+    hdr = b"".join(open(os.path.join(CSRC, x), "rb").read() for x in HEADERS) + \
         open(os.path.join(os.path.dirname(HERE), "include", "umgen.h"), "rb").read()
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
 

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdarg>
 #include <cstdio>
 #include <chrono>
@@ -14,10 +15,13 @@
 #include <vector>
 
 #include "../../include/umgen.h"
+#include "bg_queue.h"
 #include "frame.h"
 #include "kernels.h"
 
 using namespace umgen;
+
+namespace umgen { thread_local BgRecorder* g_bg_rec = nullptr; }      // bg_queue.h: installed around the recording of a background pass
 
 #define HIPCHK(e, call)                                                                              \
     do {                                                                                             \
@@ -96,6 +100,15 @@ struct umgen_engine {
     hipEvent_t ev_pre_done = nullptr;
     hipEvent_t ev_tar_done = nullptr, ev_bg_done = nullptr, ev_bg0 = nullptr;
     bool bg_pending = false;
+    // The overlapped pass ON THE DECODE ENGINE'S IDLE XCDs (round 6; bg_worker.h): one scene per GPU runs the engine on 4 of the 8 XCD groups (same step
+    // time) and the engine workgroups of the other four execute the pass as an op list, recorded from the very launchers of the stand-alone kernels
+    // (BgRecorder).  No second stream, no CU masks: the pass advances inside the decode steps' launches and is drained behind the frame's last step.
+    bool bg_engine = false;
+    BgQueue* d_bgq = nullptr;
+    struct BgHead { unsigned w[4]; EmbedTables tb; } bg_head{};      // staging of the queue's header (must outlive the asynchronous upload)
+    BgRecorder bg_rec;                   // host copy of the op list in flight (kept: the asynchronous uploads read it, and the next pass is compared with it)
+    std::vector<unsigned> bg_state_host; // worker states read back behind the drain
+    hipEvent_t ev_drain0 = nullptr, ev_drain1 = nullptr;
     std::vector<void*> tcache[4];        // per stack, per BlockTAR: [max_batch][max_cond_frames][S_stack][2E] of T
     // Growing window in the FOREGROUND (control mode starts with 13 history frames and grows to the cap,
     // infer_fun.py:64-71, UMGen.py:1600-1603): while the window grows, slot t of frame n + 1's window is slot t of frame n's window --
@@ -596,6 +609,10 @@ int oar_layers(umgen_engine* e, int B, int ns) {
             if (want >= 1 && es->NG % want == 0 && es->NG / want >= std::min(B, es->NG)) a.R = es->NG / want;
         }
         a.D = es->NG / a.R;
+        if (e->bg_engine && B == 1 && es->NG == 8 && !e->eng_stamps) {      // one scene on 4 XCD groups, the other 4 XCDs' workgroups are background workers (bg_worker.h)
+            a.R = 2; a.D = 4;
+            a.bg = e->d_bgq;
+        }
         memcpy(a.xcc_group, es->map, 16);
         if (const char* bs = getenv("UMGEN_DEBUG_BURN")) {      // measurement builds (-DUMGEN_ENG_BURN): "us,mfma,sleep,kb"
             int us = 0, mf = 0, sl = 0, kb = 0;
@@ -878,19 +895,49 @@ int launch_prefix(umgen_engine* e, const FrameIO& io, const std::vector<int>& eg
     std::vector<int> zero((size_t)B * 3, 0);
     decode_pose_shift(up[0]->data(), zero.data(), B, Tnext, e->px_pshift, e->px_pdiff);   // slot P (unknown) is not touched by this pass
 
-    hipStream_t fg = e->stream, bg = e->bg_stream;
-    HIPCHK(e, hipEventRecord(e->ev_tar_done, fg));
-    HIPCHK(e, hipStreamWaitEvent(bg, e->ev_tar_done, 0));
+    hipStream_t fg = e->stream, bg = e->bg_engine ? e->stream : e->bg_stream;
+    if (!e->bg_engine) {
+        HIPCHK(e, hipEventRecord(e->ev_tar_done, fg));
+        HIPCHK(e, hipStreamWaitEvent(bg, e->ev_tar_done, 0));
+    }
     HIPCHK(e, hipMemcpyAsync(e->d_pose, up[0]->data(), up[0]->size() * 4, hipMemcpyHostToDevice, bg));
     HIPCHK(e, hipMemcpyAsync(e->d_map, up[1]->data(), up[1]->size() * 4, hipMemcpyHostToDevice, bg));
     HIPCHK(e, hipMemcpyAsync(e->d_box, up[2]->data(), up[2]->size() * 4, hipMemcpyHostToDevice, bg));
     HIPCHK(e, hipMemcpyAsync(e->d_img, up[3]->data(), up[3]->size() * 4, hipMemcpyHostToDevice, bg));
     HIPCHK(e, hipMemcpyAsync(e->d_pose_shift, e->px_pshift.data(), e->px_pshift.size() * 4, hipMemcpyHostToDevice, bg));
     HIPCHK(e, hipMemcpyAsync(e->pose_diff, e->px_pdiff.data(), e->px_pdiff.size() * 4, hipMemcpyHostToDevice, bg));
+    const WindowTokens ws{e->d_pose_shift, e->d_map, e->d_box, e->d_img, B, P, Tnext, 0};
+    if (e->bg_engine) {
+        // the pass as an op list for the decode engine's background workers: the same run_stack calls, with the launchers recording instead of launching
+        BgRecorder rec;
+        g_bg_rec = &rec;
+        if (px.has_ego) run_stack<T>(e, STACK_EGO, WindowTokens{e->d_pose, e->d_map, e->d_box, e->d_img, B, P, Tnext, 0}, 1);
+        run_stack<T>(e, STACK_MAP, ws, 1);
+        run_stack<T>(e, STACK_BOX, ws, 1);
+        run_stack<T>(e, STACK_TAR, ws, 1);
+        g_bg_rec = nullptr;
+        if (rec.failed || rec.ops.empty() || rec.ops.size() > (size_t)kBgMaxOps) {
+            if (getenv("UMGEN_DEBUG_TIMING")) fprintf(stderr, "[umgen] background pass not recordable (%s): this frame's successor computes its whole window\n", rec.failed ? rec.failed : "op count");
+            return 0;      // (px.valid stays false: the next frame takes the plain path)
+        }
+        // unit times: the workers' own measurements survive from pass to pass while the list keeps its shape; a new shape starts from the host's guesses
+        bool same = rec.ops.size() == e->bg_rec.ops.size();
+        for (size_t i = 0; same && i < rec.ops.size(); ++i) same = memcmp(&rec.ops[i].h, &e->bg_rec.ops[i].h, sizeof(BgOpHead)) == 0;
+        e->bg_rec = std::move(rec);
+        // header: op count, engine_ticks = 0 (the first launch measures, the workers start with the second), margin 10 us, the embedding tables
+        e->bg_head.w[0] = (unsigned)e->bg_rec.ops.size(); e->bg_head.w[1] = 0u; e->bg_head.w[2] = 1000u; e->bg_head.w[3] = 0u;
+        e->bg_head.tb = e->tb;
+        static_assert(offsetof(BgQueue, tb) == 16 && offsetof(BgQueue, state) == 16 + sizeof(EmbedTables), "BgQueue header layout");
+        HIPCHK(e, hipMemcpyAsync(&e->d_bgq->n_ops, &e->bg_head, sizeof(e->bg_head), hipMemcpyHostToDevice, fg));
+        HIPCHK(e, hipMemsetAsync(&e->d_bgq->state[0][0], 0, sizeof(e->d_bgq->state) + sizeof(e->d_bgq->arrive), fg));
+        if (!same) HIPCHK(e, hipMemcpyAsync(&e->d_bgq->est[0], e->bg_rec.est.data(), e->bg_rec.est.size() * sizeof(unsigned), hipMemcpyHostToDevice, fg));
+        HIPCHK(e, hipMemcpyAsync(&e->d_bgq->ops[0], e->bg_rec.ops.data(), e->bg_rec.ops.size() * sizeof(BgOp), hipMemcpyHostToDevice, fg));
+        e->bg_pending = true;      // (px.valid: once the drain behind the frame's last step has seen every worker at the end of the list, run_frame)
+        return 0;
+    }
     HIPCHK(e, hipEventRecord(e->ev_bg0, bg));
     e->stream = bg;
     if (px.has_ego) run_stack<T>(e, STACK_EGO, WindowTokens{e->d_pose, e->d_map, e->d_box, e->d_img, B, P, Tnext, 0}, 1);
-    const WindowTokens ws{e->d_pose_shift, e->d_map, e->d_box, e->d_img, B, P, Tnext, 0};
     run_stack<T>(e, STACK_MAP, ws, 1);
     run_stack<T>(e, STACK_BOX, ws, 1);
     run_stack<T>(e, STACK_TAR, ws, 1);
@@ -914,7 +961,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                      io.smp->rule_constrain, io.smp->merge_ar_tar, io.smp->only_ar};
     const umgen_trace* tr = io.trace;
     const bool forced = tr && tr->forced_map;
-    if (e->bg_pending) {   // the background pass reads the token arrays and owns the TAR scratch buffers until it is done
+    if (e->bg_pending && !e->bg_engine) {   // the background pass reads the token arrays and owns the TAR scratch buffers until it is done
         const auto tw0 = std::chrono::steady_clock::now();
         HIPCHK(e, hipEventSynchronize(e->ev_bg_done));
         const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
@@ -933,7 +980,8 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     // the background pass runs on a quarter of the CUs (measured 3.1x the whole-window time of the same stacks on all CUs): only
     // worth launching when that is expected to hide behind the decode loop (numbers of the previous frames of this engine)
     if (e->last_B != B) { e->last_B = B; e->last_full_pre_ms = 0.f; }
-    const bool hides = e->overlap_mode == 2 || e->last_full_pre_ms <= 0.f || 3.3f * e->last_full_pre_ms < 0.95f * e->last_oar_ms;
+    // (on the decode engine's idle XCDs -- half the chip, the launches' tails idle -- ~2.3x)
+    const bool hides = e->overlap_mode == 2 || e->last_full_pre_ms <= 0.f || (e->bg_engine ? 2.3f : 3.3f) * e->last_full_pre_ms < 0.95f * e->last_oar_ms;
     const bool ov_active = e->overlap && !e->overlap_suspended && hides && !e->profiling && !tr && (B == 1 || e->overlap_mode == 2);
     // the ego / TAR phase runs on all CUs; the decode loop leaves the background stream's XCDs alone only when a pass can follow
     hipStream_t const pre = e->full_stream ? e->full_stream : fg;   // (the background stream is idle until this phase is over)
@@ -1095,13 +1143,14 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     }
     // given map (/ boxes): positions 0 .. given_end - 2 as one pass, the step loop starts at given_end - 1 (UMGEN_PREFIX_PASS=0: replay every
     // given position as a decode step, rounds 1-4).  WHICH form runs is a property of the engine, never of the frame: the pass works in the stacks'
-    // buffers, so an engine created with the overlapped background TAR pass (e->overlap) replays on every frame, and every other engine takes the
+    // buffers, so an engine created with the overlapped background TAR pass ON A SECOND STREAM (UMGEN_OVERLAP=1) replays on every frame, and every
+    // other engine -- the decode engine's background workers included: their pass starts with the first decode step, behind this one -- takes the
     // pass on every frame -- traced or not, followed by another frame or not -- so that rollout(n) stays a token prefix of rollout(n + 1) in the
     // 16-bit modes, whose two forms differ in arithmetic.
     const char* ppe = getenv("UMGEN_PREFIX_PASS");      // (read per frame: the tests compare both forms in one process)
     const bool prefix_pass_off = ppe && ppe[0] == '0';
     OarState s1 = s0;                                   // (function scope: the asynchronous uploads below read it until the stream is drained)
-    if (given_end > kPoseEos + 1 && !prefix_pass_off && !e->overlap && j_begin == 0) {
+    if (given_end > kPoseEos + 1 && !prefix_pass_off && (!e->overlap || e->bg_engine) && j_begin == 0) {
         if (int rc = run_prefix_prefill<T>(e, B, given_end)) return rc;
         j_begin = given_end - 1;
         s1.step = j_begin;
@@ -1115,7 +1164,7 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     const bool wide = sizeof(T) == 2 && e->use_wide(B);           // the chip-wide engine of the wide layers: one launch per scene and step
     static const umgen_engine::EngStream wide_stream{true, 8, {}};
     const umgen_engine::EngStream* eng = wide ? &wide_stream : ((sizeof(T) == 2 && !batched) ? e->eng_for(st) : nullptr);
-    const int eng_ng = wide ? -3 : (eng ? eng->NG : (batched ? -2 : 0));     // the engine's grid depends on the stream's XCDs: graphs are per (B, NG)
+    const int eng_ng = wide ? -3 : (eng ? eng->NG + (e->bg_engine && B == 1 ? 100 : 0) : (batched ? -2 : 0));     // the engine's grid depends on the stream's XCDs: graphs are per (B, NG)
     if (graphs && (e->step_graph_B != B || e->step_graph_NG != eng_ng)) {
         for (auto& row : e->step_graph)
             for (auto& g : row)
@@ -1245,6 +1294,19 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         e->tm.oar_kernels += (eng ? (wide ? B : 1) : 5 * (int64_t)e->oar.size()) + (mod == 0 ? 1 : (mod == 2 ? 3 : 2));
     }
     e->tm.oar_steps += steps_run;
+    const bool drained = e->bg_engine && e->bg_pending;
+    if (drained) {      // what the decode steps' launches left of the background pass: one launch without an engine part runs it to the end
+        HIPCHK(e, hipEventRecord(e->ev_drain0, st));
+        OarEngineArgs a{};
+        a.NG = 8; a.R = 2; a.D = 4; a.B = 1; a.bg = e->d_bgq; a.bg_only = 1;
+        a.st = e->d_state; a.ticket = e->eng_ticket; a.err = e->eng_err;
+        memcpy(a.xcc_group, e->eng_fg.map, 16);
+        a.fp16 = std::is_same<T, f16_t>::value ? 1 : 0;
+        HIPCHK(e, launch_oar_engine(st, a));
+        HIPCHK(e, hipEventRecord(e->ev_drain1, st));
+        e->bg_state_host.assign((size_t)kBgMaxWorkers * 4, 0u);
+        HIPCHK(e, hipMemcpyAsync(e->bg_state_host.data(), &e->d_bgq->state[0][0], sizeof(e->d_bgq->state), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(e, hipEventRecord(e->ev[3], st));
     HIPCHK(e, hipMemcpyAsync(io.out_tokens, e->d_tokens, (size_t)B * kTokPerFrame * 4, hipMemcpyDeviceToHost, st));
     int counters[8] = {};
@@ -1256,6 +1318,29 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
         const hipError_t le = e->launch_status != hipSuccess ? e->launch_status : hipGetLastError();
         e->launch_status = hipSuccess;
         if (le != hipSuccess) return e->fail(UMGEN_E_HIP, "a kernel launch of this frame was refused: %s", hipGetErrorString(le));
+    }
+    if (drained) {
+        e->bg_pending = false;
+        float dms = 0.f;
+        hipEventElapsedTime(&dms, e->ev_drain0, e->ev_drain1);
+        e->tm.bg_ms += dms;
+        for (int wk = 0; wk < kBgMaxWorkers; ++wk)
+            if (e->bg_state_host[(size_t)wk * 4] < e->bg_rec.ops.size()) {
+                e->px.valid = false;
+                if (getenv("UMGEN_DEBUG_TIMING")) {
+                    fprintf(stderr, "[umgen] worker states (op, units done | arrived):");
+                    for (int k = 0; k < kBgMaxWorkers; ++k) fprintf(stderr, " %u:%x", e->bg_state_host[(size_t)k * 4], e->bg_state_host[(size_t)k * 4 + 1]);
+                    const unsigned o0 = e->bg_state_host[(size_t)wk * 4];
+                    unsigned arr[4] = {};
+                    (void)hipMemcpy(arr, &e->d_bgq->arrive[o0 > 0 ? o0 - 1 : 0], sizeof(arr), hipMemcpyDeviceToHost);
+                    const BgOpHead& h = e->bg_rec.ops[o0].h;
+                    fprintf(stderr, "\n[umgen] arrivals from op %u on: %u %u %u %u; op %u: kind %d mode %d units %d chunk %d i0..3 %d %d %d %d\n", o0 > 0 ? o0 - 1 : 0, arr[0], arr[1], arr[2], arr[3], o0,
+                            h.kind, h.mode, h.n_units, h.chunk, h.i0, h.i1, h.i2, h.i3);
+                }
+                return e->fail(UMGEN_E_HIP, "background pass incomplete: worker %d stopped at op %u of %zu", wk, e->bg_state_host[(size_t)wk * 4], e->bg_rec.ops.size());
+            }
+        e->px.valid = true;
+        if (getenv("UMGEN_DEBUG_TIMING")) fprintf(stderr, "[umgen] background pass: %zu ops, drain launch %.2f ms\n", e->bg_rec.ops.size(), dms);
     }
     if (eng_err) {   // a hand-off of the decode engine timed out (e.g. two engines sharing one GPU): never return tokens from such a frame
         (void)hipMemset(wide ? e->wide_err : e->eng_err, 0, sizeof(unsigned));
@@ -1590,9 +1675,22 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
     }
     e->overlap = cfg->max_cond_frames >= 2 && !e->eng_enabled && !e->wide_enabled;
     if (ov_env) { e->overlap_mode = ov_env[0] - '0'; e->overlap = cfg->max_cond_frames >= 2 && ov_env[0] != '0'; }
+    // One scene per GPU on the XCD-resident engine: the overlapped pass runs on the engine's idle XCDs (bg_worker.h; UMGEN_BG_ENGINE=0: the engine on all
+    // eight groups and every frame's whole window in the foreground, as in rounds 2-5).  Engines for more scenes keep every XCD busy with the decode.
+    const char* be_env = getenv("UMGEN_BG_ENGINE");
+    e->bg_engine = e->eng_enabled && cfg->max_batch == 1 && cfg->max_cond_frames >= 2 && cfg->max_cond_frames <= 32 && !ov_env && !(be_env && be_env[0] == '0');
+    if (e->bg_engine) { e->overlap = true; e->overlap_mode = 1; }
     int bg_cus = 64;   // mask bits are striped over the 8 XCDs: 64 = 8 CUs of each XCD for the background stream
     if (const char* bc = getenv("UMGEN_BG_CUS")) bg_cus = std::max(32, std::min(128, atoi(bc)));
-    if (e->overlap) {
+    if (e->bg_engine) {
+        void* qp = nullptr;
+        if (int rc = dev_alloc(e, &qp, sizeof(BgQueue))) return rc;
+        e->d_bgq = reinterpret_cast<BgQueue*>(qp);
+        HIPCHK(e, hipMemset(e->d_bgq, 0, sizeof(BgQueue)));
+        HIPCHK(e, hipEventCreate(&e->ev_drain0));
+        HIPCHK(e, hipEventCreate(&e->ev_drain1));
+    }
+    if (e->overlap && !e->bg_engine) {
         hipDeviceProp_t prop;
         HIPCHK(e, hipGetDeviceProperties(&prop, cfg->device));
         const int ncu = prop.multiProcessorCount;
@@ -2275,7 +2373,7 @@ int umgen_destroy(umgen_engine* e) {
         if (e->ev_side_done[i]) hipEventDestroy(e->ev_side_done[i]);
     }
     if (e->ev_side_in) hipEventDestroy(e->ev_side_in);
-    for (hipEvent_t ev : {e->ev_tar_done, e->ev_bg_done, e->ev_bg0, e->ev_pre_done}) if (ev) hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev_tar_done, e->ev_bg_done, e->ev_bg0, e->ev_pre_done, e->ev_drain0, e->ev_drain1}) if (ev) hipEventDestroy(ev);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return UMGEN_OK;

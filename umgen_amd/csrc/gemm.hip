@@ -5,6 +5,7 @@
 //   * gemm_valu: exact fp32 FMA chain (parity mode and the one-off GMLP(codebook) tables).
 #include <cstdlib>
 
+#include "bg_queue.h"
 #include "kernels.h"
 
 namespace umgen {
@@ -459,6 +460,15 @@ void launch_gemm_mfma(hipStream_t s, const GemmArgs& a) {
     //  (engine.hip, UMGEN_CONCURRENT_STACKS) the other stacks' workgroups fill a launch's last partial round, and the threshold that
     //  is best for a whole frame drops to <= 300 tiles (one scene: TAR 233.6 / 230.0 / 229.5 / 227.8 ms per frame at 1100 / 700 / 500 /
     //  300, no further change below; profiles/r03_engine_experiments.txt)
+    if (g_bg_rec) {      // the decode engine's background workers run every GEMM of the pass on the 256-tile body (same products, same k order)
+        GemmArgs v = a;
+        if (a.mode == GEMM_VT) {      // (operand roles as below)
+            v.P = a.Q; v.Mi = a.Nj; v.ldp = a.ldq; v.strideP = a.strideQ;
+            v.Q = a.P; v.Nj = a.Mi; v.ldq = a.ldp; v.strideQ = a.strideP;
+        }
+        record_gemm256(v);
+        return;
+    }
     static const int min_tiles256 = getenv("UMGEN_GEMM256_MIN_TILES") ? atoi(getenv("UMGEN_GEMM256_MIN_TILES")) : 300;
     const long tiles256 = (long)(a.Mi / 256) * ((a.Nj + 255) / 256);
     if (a.tile256 >= 0 && gemm256_supported(a) && (a.tile256 > 0 || tiles256 >= min_tiles256 || (a.K >= 2048 && tiles256 >= min_tiles256 / 3))) {

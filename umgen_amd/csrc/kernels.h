@@ -36,6 +36,7 @@ bool gemm256_supported(const GemmArgs& a);
 hipError_t gemm256_prepare();                   // per device, behind hipSetDevice (dynamic-LDS attribute, CU count of that device)
 int gemm256_read_stamps(unsigned long long* out16);   // measurement builds only (-2 otherwise)
 template <typename TT> void launch_gemm256(hipStream_t s, const GemmArgs& a);
+void record_gemm256(const GemmArgs& a);          // bg_queue.h: the same GEMM as an op of the decode engine's background workers
 template <typename TT> void launch_gemm_mfma(hipStream_t s, const GemmArgs& a);   // P, Q of the 16-bit type TT (bf16_t / f16_t), MFMA 16x16x32
 template <typename TP, typename TQ> void launch_gemm_valu(hipStream_t s, const GemmArgs& a);  // exact fp32 FMA chain
 
@@ -164,6 +165,7 @@ struct OarLayerDev {                           // one BlockOAR's parameters (mod
     const bf16_t *Wf2;                         // UMGEN_ENG_MFMA & 4: c_fc as matrix-core fragments [32 CUs][8 waves][6 tiles x 3 k-steps][64 lanes][8] (1 KB per request)
 };
 struct OarState;
+struct BgQueue;
 struct OarEngineArgs {
     const OarLayerDev* layers; int n_layers;
     bf16_t* kvcache; long kv_layer_stride, kv_scene_stride; int Lmax;   // [layer][scene][2][H][Lmax][48]
@@ -183,6 +185,10 @@ struct OarEngineArgs {
     // load for burn_ticks (100 MHz) -- what the decode step costs while the other XCDs work (profiles/r06_engine_contention.txt)
     int burn_ticks, burn_mfma, burn_sleep, burn_kb;
     const void* burn_buf;
+    // Background workers (bg_worker.h; one scene, D < NG): the workgroups of the XCD groups no scene uses execute the op list `bg` -- the next frame's TAR /
+    // ego pass -- while the engine part runs; bg_only: a launch without an engine part that drains what is left of the list
+    BgQueue* bg;
+    int bg_only;
 };
 // ------------------------------------------------------------------------------------------------
 // chip-wide decode engine for wide layers (oar_engine_wide.hip): n_embd 1536, one scene per launch, 256 workgroups (6 compute + 2 poll waves),
@@ -213,6 +219,7 @@ hipError_t launch_oar_engine_wide(hipStream_t s, const OarWideArgs& a);
 hipError_t launch_oar_engine_wide_census(hipStream_t s, unsigned int* d_counts16);
 
 size_t oar_engine_lds_bytes();
+size_t oar_engine_bg_lds_bytes();      // launches with background workers (bg_worker.h)
 hipError_t oar_engine_prepare();                // per device, before the first launch / census (dynamic-LDS attribute)
 hipError_t launch_oar_engine(hipStream_t s, const OarEngineArgs& a);
 hipError_t launch_oar_engine_census(hipStream_t s, int n_groups, unsigned int* d_counts16);

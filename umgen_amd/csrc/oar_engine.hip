@@ -29,6 +29,8 @@
 // (16 keys per pass) with an online softmax per lane group; the 16 lane groups of a wave, the 64 partials of a half, then the two
 // halves, are merged in a fixed order.
 #include "oar_common.h"
+#include "bg_queue.h"
+#include "bg_worker.h"
 
 namespace umgen {
 
@@ -332,7 +334,8 @@ constexpr int kStaggerTicks = UMGEN_ENG_STAGGER_US * 100;   // wall_clock64 tick
 // the other (item (layer l, scene s) on group l % 8 needs x of (l - 1, s) from group (l - 1) % 8).  A step costs
 // (n_layers + B - 1) item times instead of B x n_layers / 8 x (item + weight stream): with one scene per XCD (round 2) every
 // group streamed all 36 layers, 8x the algorithmic weight traffic through the fabric, and waited 11 of 29 us per item for it.
-template <bool STAMPS, typename TT, bool SYS>
+// BG (one scene, !SYS): the workgroups of the XCD groups no scene uses are the background workers of bg_worker.h (the next frame's TAR / ego pass)
+template <bool STAMPS, typename TT, bool SYS, bool BG = false>
 __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid0 = threadIdx.x;
@@ -372,6 +375,13 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
     const int R = SYS ? 1 : a.R, D = SYS ? a.NG : a.D;
     const int rounds = (a.B + R - 1) / R;
     const int pipe = g / D, q = g % D;      // pipeline (scene slot of the round) and position in it
+    if constexpr (BG) {
+        if (a.bg != nullptr && a.B == 1 && g >= D) {
+            bg_worker<TT>(a.bg, (g - D) * CU + w0, (a.NG - D) * CU, t_k0, a.bg_only != 0);
+            return;
+        }
+        if (a.bg_only) return;
+    }
 #ifdef UMGEN_ENG_BURN
     if (!SYS && a.burn_ticks > 0 && pipe >= a.B) {      // measurement: an idle pipeline's XCDs under a synthetic load
         typedef typename Mma16<TT>::vec vec8;
@@ -1286,7 +1296,11 @@ __global__ __launch_bounds__(kEngThreads) void oar_engine_kernel(OarEngineArgs a
                 const int n = 24 * w + row;
                 const float xn = xb[n] + sum;
                 if ((tid & 3) == 0) {
-                if (l + 1 == a.n_layers) (a.xdec + (long)s * E)[(u32)n] = xn;
+                if (l + 1 == a.n_layers) {
+                    (a.xdec + (long)s * E)[(u32)n] = xn;
+                    // the engine part of this launch ends here: the background workers of the next launch plan against this duration
+                    if (BG && a.bg != nullptr && w == 0 && tid == 0) a.bg->engine_ticks = (u32)(wall_clock64() - t_k0);
+                }
                 else if (D == 1) put_local(gxl, (u32)n, tg + 8, xn);
                 else put_far(a.gx + (long)s * E, (u32)n, tg + 8, xn);
                 }
@@ -1311,6 +1325,8 @@ size_t oar_engine_lds_bytes() {
     return need > (size_t)(96 << 10) ? need : (size_t)(96 << 10);   // > 80 KB: never two engine workgroups on one CU
 }
 
+size_t oar_engine_bg_lds_bytes() { return std::max(oar_engine_lds_bytes(), (size_t)kLds256); }
+
 hipError_t launch_oar_engine_census(hipStream_t s, int n_groups, unsigned int* d_counts16) {
     hipLaunchKernelGGL(oar_engine_census_kernel, dim3(n_groups * kEngGroup), dim3(kEngThreads), oar_engine_lds_bytes(), s, d_counts16);
     return hipGetLastError();
@@ -1326,6 +1342,10 @@ hipError_t oar_engine_prepare() {
         hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oar_engine_lds_bytes());
         if (rc != hipSuccess) return rc;
     }
+    for (const void* f : {reinterpret_cast<const void*>(oar_engine_kernel<false, bf16_t, false, true>), reinterpret_cast<const void*>(oar_engine_kernel<false, f16_t, false, true>)}) {
+        hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oar_engine_bg_lds_bytes());
+        if (rc != hipSuccess) return rc;
+    }
     return hipSuccess;
 }
 
@@ -1333,6 +1353,10 @@ template <typename TT, bool SYS>
 static void launch_engine_t(hipStream_t s, const OarEngineArgs& a) {
     const dim3 grid(a.NG * kEngGroup), block(kEngThreads);
     const size_t shm = oar_engine_lds_bytes();
+    if (!SYS && a.bg != nullptr && !a.stamps) {      // with background workers: the workers' GEMM tiles need the whole 160 KB
+        hipLaunchKernelGGL((oar_engine_kernel<false, TT, false, true>), grid, block, oar_engine_bg_lds_bytes(), s, a);
+        return;
+    }
     if (a.stamps) hipLaunchKernelGGL((oar_engine_kernel<true, TT, SYS>), grid, block, shm, s, a);
     else hipLaunchKernelGGL((oar_engine_kernel<false, TT, SYS>), grid, block, shm, s, a);
 }
