@@ -253,3 +253,51 @@ def test_default_path_selection_by_batch_size(setup):
     t = e.timings()
     assert t["decode_engine"] == 0 and t["decode_batched"] == 1 and t["decode_lanes"] == 2
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the overlapped pass on the decode engine's idle XCDs (csrc/bg_worker.h): engines for one scene per call
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("task", ["video", "control", "mapgiven"])
+def test_background_workers_reproduce_the_foreground_engine(task, precision):
+    """Production width, 10 BlockOAR layers / 2 blocks per stack (`deep`): a rollout whose later frames find slots 0 .. T - 2 of their window already pushed
+    through the four stacks by the background workers -- recorded op list, virtual launches of the stand-alone kernels' bodies on the XCDs the one-scene
+    engine leaves idle, resumed from decode step to decode step, the rest drained behind the frame -- equals, token for token, the rollout of an engine
+    that computes every window in the foreground (UMGEN_BG_ENGINE=0).  Sliding window (video), growing window with control tokens, and a given map
+    (whose prefix pass runs in the foreground in both engines, ahead of the workers' first op)."""
+    from tests.golden.make_full_width_golden import config as width_config
+    from umgen_amd.synth import synthetic_control, synthetic_given_map
+    from umgen_amd.weights import synthetic_state_dict as ssd
+    cfg = width_config("deep")
+    sd = ssd(cfg, seed=5)
+    T, frames = 4, 3
+    scene = synthetic_scene(17, n_frames=T)
+    kw = dict(cond_frames=T, input_cond_frames=T, seeds=[3])
+    if task == "control":
+        c = synthetic_control(17, n_frames=frames)
+        kw.update(input_cond_frames=2, init_tokens={k: c[k] for k in ("pose", "bbox3d")}, control_test=True)
+    elif task == "mapgiven":
+        kw.update(init_tokens={"map": synthetic_given_map(17, n_frames=frames)["map"]})
+    outs, tms = {}, {}
+    for bg in ("0", "1"):
+        old = os.environ.get("UMGEN_BG_ENGINE")
+        os.environ["UMGEN_BG_ENGINE"] = bg
+        try:
+            e = Engine(cfg, precision=precision, max_batch=1, max_cond_frames=T)
+        finally:
+            if old is None:
+                del os.environ["UMGEN_BG_ENGINE"]
+            else:
+                os.environ["UMGEN_BG_ENGINE"] = old
+        e.load_state_dict(sd)
+        e.finalize()
+        outs[bg] = e.rollout(scene, frames, **kw)
+        tms[bg] = e.timings()
+        e.close()
+    assert tms["1"]["decode_engine"] == 1 and tms["0"]["decode_engine"] == 1
+    assert tms["1"]["overlapped_frames"] == frames - 1, tms["1"]
+    if task == "mapgiven":
+        assert tms["1"]["prefix_passes"] == frames and tms["0"]["prefix_passes"] == frames
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(outs["1"][m], outs["0"][m], err_msg=m)

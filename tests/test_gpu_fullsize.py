@@ -63,6 +63,8 @@ def run_forced_frame(width, precision):
     e.load_state_dict(synthetic_state_dict(cfg, seed=WEIGHT_SEED))
     e.finalize()
     toks, tr = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, trace=True, forced=forced)
+    # which decode path faced the oracle: fp32 -> five launches per layer; 16-bit at E = 768 -> the XCD-resident engine; 16-bit at E = 1536 -> the chip-wide engine
+    assert e.timings()["decode_engine"] == (0 if precision == "fp32" else (3 if width == "wide2x" else 1)), e.timings()
     e.close()
     return g, tr
 
@@ -207,7 +209,7 @@ def test_given_map_prefix_pass_at_production_width_batch_and_engine(precision):
 
 
 def test_bf16_teacher_forced_logits_at_2x_width_vs_rounding_aware_oracle_golden():
-    """Config #5's doubled width (E=1536, H=32; five-launch decode layer) in bf16 against one run of the rounding-aware oracle
+    """Config #5's doubled width (E=1536, H=32; the chip-wide decode engine of csrc/oar_engine_wide.hip -- asserted) in bf16 against one run of the rounding-aware oracle
     (no ensemble at this width: one oracle frame takes ~10 CPU minutes): 1.5e-2 absolute / 4e-3 relative rms on logits, every
     arg-max flip a near-tie."""
     width = "wide2x"
@@ -266,6 +268,55 @@ def test_wide_engine_matches_the_five_launch_path_at_2x_width(precision):
     eager.load_state_dict(sd)
     eager.finalize()
     out = eager.rollout(scenes[0], 1, cond_frames=3, input_cond_frames=2, seeds=[21])
+    eager.close()
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(out[m], single[0][m], err_msg=m)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_wide_engine_at_depth_matches_the_five_launch_path(precision):
+    """The chip-wide engine with TEN BlockOAR layers (`wide2x` width, the `deep` layer counts): the request ring that fetches the next layer's q|k|v rows
+    behind the current layer's last barrier crosses nine layer boundaries per step instead of one (the 36-layer form ran only in
+    bench.py, and the same inline-assembly ring had returned NaNs at another register budget).  Teacher-forced logits within the north-star's 1e-3 of the
+    five-launch layer, graph replay == eager launches, a batch of two == the two one-scene rollouts."""
+    from tests.golden.make_full_width_golden import DEEP
+    cfg = width_config("wide2x", **DEEP)
+    sd = synthetic_state_dict(cfg, seed=WEIGHT_SEED)
+    scene = synthetic_scene(SCENE_ID, n_frames=2)
+    window = {m: scene[m][0] for m in MOD_ORDER}
+    with env(UMGEN_DECODE_WIDE=0):
+        ref = Engine(cfg, precision=precision, max_cond_frames=4)
+    ref.load_state_dict(sd)
+    ref.finalize()
+    toks_ref, tr_ref = ref.frame(window, frame_idx=0, seed=3, trace=True)
+    assert ref.timings()["decode_engine"] == 0
+    ref.close()
+    with env(UMGEN_DECODE_WIDE=2):
+        e = Engine(cfg, precision=precision, max_batch=2, max_cond_frames=4)
+    e.load_state_dict(sd)
+    e.finalize()
+    toks, tr = e.frame(window, frame_idx=0, seed=3, trace=True, forced=toks_ref)
+    assert e.timings()["decode_engine"] == 3
+    worst = 0.0
+    for m in ("map", "bbox3d", "image"):
+        assert np.isfinite(tr[f"logits_{m}"]).all(), m
+        worst = max(worst, float(np.abs(tr[f"logits_{m}"] - tr_ref[f"logits_{m}"]).max()))
+        np.testing.assert_allclose(tr[f"logits_{m}"], tr_ref[f"logits_{m}"], atol=1e-3, rtol=0, err_msg=m)
+    print(f"chip-wide engine vs launches at 2x width, 10 BlockOAR layers ({precision}): max |dlogit| = {worst:.2e}, sampled != forced: {tr['counters']['sampled_ne_forced']}")
+    assert tr["counters"]["sampled_ne_forced"] <= 4, tr["counters"]
+    scenes = [synthetic_scene(90 + i, n_frames=2) for i in range(2)]
+    single = [e.rollout(scenes[i], 1, cond_frames=3, input_cond_frames=2, seeds=[31 + i]) for i in range(2)]
+    both = e.rollout(cat(scenes), 1, cond_frames=3, input_cond_frames=2, seeds=[31, 32])
+    assert e.timings()["decode_engine"] == 3
+    e.close()
+    for i in range(2):
+        for m in MOD_ORDER:
+            np.testing.assert_array_equal(both[m][i:i + 1], single[i][m], err_msg=f"scene {i} {m}")
+    eager = Engine(cfg, precision=precision, max_batch=1, max_cond_frames=4, use_graphs=False)
+    eager.load_state_dict(sd)
+    eager.finalize()
+    out = eager.rollout(scenes[0], 1, cond_frames=3, input_cond_frames=2, seeds=[31])
+    assert eager.timings()["decode_engine"] == 3
     eager.close()
     for m in MOD_ORDER:
         np.testing.assert_array_equal(out[m], single[0][m], err_msg=m)
@@ -478,7 +529,7 @@ def test_large_overlapped_launch_path_equals_plain_eager_and_the_engine_up_to_ne
     # the engine owns every CU (no background pass), but the growing window's slot caches are reused in the FOREGROUND (f-3): the
     # second frame pushed only its new 14th slot through the stacks -- and that split is bit-identical to recomputing the window
     assert e.timings()["overlapped_frames"] == 1
-    with env(UMGEN_GROW_CACHE=0):
+    with env(UMGEN_GROW_CACHE=0, UMGEN_BG_ENGINE=0):      # (a one-scene engine would otherwise take the next window's known slots through the decode engine's background workers)
         x = Engine(cfg, precision="bf16", max_batch=1, max_cond_frames=20)
     x.load_state_dict(synthetic_items(cfg, seed=0))
     x.finalize()
@@ -501,3 +552,28 @@ def test_large_overlapped_launch_path_equals_plain_eager_and_the_engine_up_to_ne
         np.testing.assert_array_equal(outs[0]["pose"][:, 13:15], init["pose"][:, :2])
     agree = np.mean([np.mean(out_engine[m][:, 13] == outs[0][m][:, 13]) for m in ("map", "bbox3d", "image")])
     assert agree >= 0.99, agree
+
+
+def test_large_background_workers_equal_the_foreground_engine(large):
+    """Round 6 (csrc/bg_worker.h): an engine created for ONE scene per call runs the decode engine on 4 of the 8 XCD groups and lets the engine
+    workgroups of the other four XCDs execute the next frame's TAR / ego pass over the history slots that are already known, inside the decode steps'
+    launches (op list recorded from the stand-alone kernels' own launchers, same device functions).  UMGen_Large, sliding 20-frame window, four new
+    frames: tokens equal -- bit for bit -- those of the `large` fixture (an engine for 8 scenes: engine on 8 groups, every window in the foreground);
+    every frame but the first found its prefix in the slot caches, and the launch that drains the pass behind a frame's last step has nothing left to do
+    (the pass fits into the 2206 steps)."""
+    cfg, ref = large
+    scene = synthetic_scene(1007, n_frames=20)
+    want = ref.rollout(scene, 4, cond_frames=20, seeds=[13])
+    assert ref.timings()["overlapped_frames"] == 0
+    e = Engine(cfg, precision="bf16", max_batch=1, max_cond_frames=20)
+    e.load_state_dict(synthetic_items(cfg, seed=0))
+    e.finalize()
+    got = e.rollout(scene, 4, cond_frames=20, seeds=[13])
+    t = e.timings()
+    e.close()
+    assert t["decode_engine"] == 1 and t["overlapped_frames"] == 3, t
+    print(f"UMGen_Large, background workers: ego {t['ego_ms'] / 4:.1f} + TAR {t['tar_ms'] / 4:.1f} + decode {t['oar_ms'] / 4:.1f} ms per frame over 4 frames (the first one computes its whole window); "
+          f"drain launches {t['bg_ms']:.2f} ms in total")
+    assert t["bg_ms"] < 3 * 30.0, t      # (a drain launch with work left runs at half the chip: 637 ms for a whole pass)
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(got[m], want[m], err_msg=m)

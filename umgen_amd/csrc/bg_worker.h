@@ -144,9 +144,21 @@ __device__ __forceinline__ void bg_worker(BgQueue* q, int widx, int nwk, unsigne
     unsigned* const st = &q->state[widx][0];
     auto ld = [](const unsigned* p) { return (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
     auto stw = [](unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // Leaving the launch with units done in it: write this XCD's dirty L2 lines back NOW, under the engine part's last microseconds -- left to the
+    // end-of-kernel release they sat between every decode step and its head launch (step 458 -> 469 us with the workers' tiles still dirty).
+    bool worked = false;
+    auto leave = [&]() {
+        if (!worked) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
     for (;;) {
         const unsigned n_ops = ld(&q->n_ops), op = ld(st);
-        if (op >= n_ops) return;
+        if (op >= n_ops) { leave(); return; }
         const unsigned st1 = ld(st + 1);
         const int done = (int)(st1 & 0x7fffffffu);
         const bool arrived = (st1 >> 31) != 0u;
@@ -178,7 +190,8 @@ __device__ __forceinline__ void bg_worker(BgQueue* q, int widx, int nwk, unsigne
             __syncthreads();
             const int n = ctl[0];
             __syncthreads();
-            if (n <= 0) return;
+            if (n <= 0) { leave(); return; }
+            worked = true;
             bg_run<TT>(h, &q->ops[op], q, widx, nwk, done, n);
             if (tid == 0) {      // per-unit time of this op, as the next frame's pass will see it (ops keep their index from frame to frame)
                 const unsigned dt = ((unsigned)wall_clock64() - ld(st + 2)) / (unsigned)n;
@@ -219,7 +232,7 @@ __device__ __forceinline__ void bg_worker(BgQueue* q, int widx, int nwk, unsigne
         __syncthreads();
         const int ok = ctl[1];
         __syncthreads();
-        if (!ok) return;
+        if (!ok) { leave(); return; }
     }
 }
 
