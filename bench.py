@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak
 
 
-PMC_FILES = ["r05_pmc_fetch_size_engine.csv", "r04_pmc_fetch_size_engine.csv", "r03_pmc_fetch_size_engine.csv"]   # newest first
+PMC_FILES = ["r06_pmc_fetch_size_engine.csv", "r05_pmc_fetch_size_engine.csv", "r04_pmc_fetch_size_engine.csv", "r03_pmc_fetch_size_engine.csv"]   # newest first
+PMC_FILES_BATCH = {4: ["r06_pmc_fetch_size_engine_b4.csv"], 8: ["r06_pmc_fetch_size_engine_b8.csv"]}      # configs[2] / [3]: scenes per GPU
 
 
 def pmc_traffic_per_launch(engine_on: bool, files=None, kernel="oar_engine_kernel"):
@@ -261,7 +262,7 @@ def main():
         layers_us = tp["layers_ms"] * 1e3 / max(1, tp["layers_launches"])
         ach = layer_bytes / (layers_us * 1e-6) / 1e9 if layers_us > 0 else 0.0
         oar_gbs = (tm["oar_bytes"] / (tm["oar_ms"] * 1e-3) / 1e9) if tm["oar_ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_per_launch(engine_on and B == 1 and args.config == "large")
+        traffic, traffic_src = pmc_traffic_per_launch(engine_on and (B == 1 or B in PMC_FILES_BATCH) and args.config == "large", PMC_FILES_BATCH.get(B))
         lanes = int(tm.get("decode_lanes", 0))
         if int(tm["decode_engine"]) == 3:
             kname = ("umgen::oar_engine_wide_kernel (chip-wide decode engine of the 2x-width layers: the 36 BlockOAR layers of a decode step of one scene "

@@ -110,6 +110,11 @@ prof)   # rocprofv3 kernel statistics of bench.py ${PROF_ARGS} -> r04_prof_${PRO
 pmc)
   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc && UMGEN_DEBUG_OAR_STEPS=1101:1105 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/pmc.log 2>&1
    f=$(find /tmp/pmc -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python /root/repo/tools/pmc_summary.py "$f" > /root/repo/gpurun_out/${R}_pmc_fetch_size_engine.csv && head -4 /root/repo/gpurun_out/${R}_pmc_fetch_size_engine.csv) ;;
+pmcb)   # the same FETCH_SIZE pass at 4 and 8 scenes per GPU (configs[2] / [3]: is the systolic schedule's per-item weight re-streaming measurable?) -> r06_pmc_fetch_size_engine_b{4,8}.csv
+  for n in ${PMC_B:-4 8}; do
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmcb && UMGEN_DEBUG_OAR_STEPS=1101:1105 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmcb -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch $n > /tmp/pmcb.log 2>&1
+   f=$(find /tmp/pmcb -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python /root/repo/tools/pmc_summary.py "$f" > /root/repo/gpurun_out/${R}_pmc_fetch_size_engine_b$n.csv && grep oar_engine /root/repo/gpurun_out/${R}_pmc_fetch_size_engine_b$n.csv | cut -c1-200 || tail -5 /tmp/pmcb.log)
+  done ;;
 pmcgemm)
   bash tools/gemm_pmc.sh > gpurun_out/${R}_pmc_gemm_fc_353120x3072x768.txt 2>&1; tail -12 gpurun_out/${R}_pmc_gemm_fc_353120x3072x768.txt | cut -c1-300
   bash tools/attn_pmc.sh > gpurun_out/${R}_pmc_attn_spatial_F20_S2207_H16.txt 2>&1; tail -8 gpurun_out/${R}_pmc_attn_spatial_F20_S2207_H16.txt | cut -c1-300 ;;

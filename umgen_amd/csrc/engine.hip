@@ -980,8 +980,8 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     // the background pass runs on a quarter of the CUs (measured 3.1x the whole-window time of the same stacks on all CUs): only
     // worth launching when that is expected to hide behind the decode loop (numbers of the previous frames of this engine)
     if (e->last_B != B) { e->last_B = B; e->last_full_pre_ms = 0.f; }
-    // (on the decode engine's idle XCDs -- half the chip, the launches' tails idle -- ~2.3x)
-    const bool hides = e->overlap_mode == 2 || e->last_full_pre_ms <= 0.f || (e->bg_engine ? 2.3f : 3.3f) * e->last_full_pre_ms < 0.95f * e->last_oar_ms;
+    // (on the decode engine's idle XCDs the pass of a one-scene frame takes ~1800 of its 2206 decode steps, 3.3x its foreground time: profiles/r06_bg_worker_trace.txt)
+    const bool hides = e->overlap_mode == 2 || e->last_full_pre_ms <= 0.f || (e->bg_engine ? 3.4f : 3.3f) * e->last_full_pre_ms < 0.95f * e->last_oar_ms;
     const bool ov_active = e->overlap && !e->overlap_suspended && hides && !e->profiling && !tr && (B == 1 || e->overlap_mode == 2);
     // the ego / TAR phase runs on all CUs; the decode loop leaves the background stream's XCDs alone only when a pass can follow
     hipStream_t const pre = e->full_stream ? e->full_stream : fg;   // (the background stream is idle until this phase is over)
