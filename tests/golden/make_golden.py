@@ -27,9 +27,12 @@ LOGIT_POS = {"map": [0, 1, 511, 1023], "bbox3d": [0, 9, 10, 11, 330, 659], "imag
 COND_ROWS = [0, 1, 4, 5, 6, 500, 1030, 1031, 1032, 1042, 1692, 1693, 1694, 2000, 2206]
 
 
-def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, new_frames, control):
+def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, new_frames, control, autocast=None):
     sd = synthetic_state_dict(cfg, seed=weight_seed)
     model = refimport.build_reference_model(cfg, sd, greedy=True)
+    # autocast "fp16" / "bf16": the reference's own autocast region (UMGen.py:1604-1605) as torch CPU autocast in that type -- the fixtures that
+    # pin the engine's 16-bit modes on the reference's arithmetic instead of the build's rounding-aware restatement alone
+    refimport.set_autocast({None: None, "fp16": torch.float16, "bf16": torch.bfloat16}[autocast])
     scene = synthetic_scene(scene_id, n_frames=input_cond_frames)
     tokens = {k: torch.from_numpy(v) for k, v in scene.items()}
     init = None
@@ -47,19 +50,19 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
 
     def oar_spy(tar_emb, *a, **k):
         cat = torch.cat([tar_emb[m] for m in ("pose", "map", "bbox3d", "image")], dim=-2)
-        rec["cond"].append(cat[0, -1, COND_ROWS].detach().numpy().copy())
+        rec["cond"].append(cat[0, -1, COND_ROWS].detach().float().numpy().copy())
         for m in rec["count"]:
             rec["count"][m] = 0
         return orig_oar(tar_emb, *a, **k)
 
     model.infer_oar_net = oar_spy
     model.transformer.head_ego.register_forward_hook(
-        lambda mod, i, o: rec["ego_logits"].append(o[0, -1].detach().numpy().copy()))
+        lambda mod, i, o: rec["ego_logits"].append(o[0, -1].detach().float().numpy().copy()))
 
     def mk(modname):
         def hook(mod, i, o):
             if len(rec["cond"]) == 1 and rec["count"][modname] in LOGIT_POS[modname]:
-                rec["logits"][modname].append(o.reshape(-1, o.shape[-1])[-1].detach().numpy().copy())
+                rec["logits"][modname].append(o.reshape(-1, o.shape[-1])[-1].detach().float().numpy().copy())
             rec["count"][modname] += 1
         return hook
 
@@ -67,13 +70,16 @@ def run_case(name, cfg, weight_seed, scene_id, cond_frames, input_cond_frames, n
     model.transformer.head_ar_bbox3d.register_forward_hook(mk("bbox3d"))
     model.transformer.head_ar_img.register_forward_hook(mk("image"))
 
-    out = model.inference(new_frames=new_frames, cond_frames=cond_frames, pred_task="pose_map_bbox3d_image",
-                          input_cond_tokens=tokens, init_tokens=init, input_cond_frames=input_cond_frames,
-                          control_test=bool(control) and control not in ("map", "map+bbox3d"), cond_on_par=True, infer_from_gt=False)
+    try:
+        out = model.inference(new_frames=new_frames, cond_frames=cond_frames, pred_task="pose_map_bbox3d_image",
+                              input_cond_tokens=tokens, init_tokens=init, input_cond_frames=input_cond_frames,
+                              control_test=bool(control) and control not in ("map", "map+bbox3d"), cond_on_par=True, infer_from_gt=False)
+    finally:
+        refimport.set_autocast(None)
     blob = {f"out_{m}": out[m].astype(np.int16) for m in out}
     blob["cond_rows"] = np.stack(rec["cond"]).astype(np.float32)
     if rec["ego_logits"]:
-        blob["ego_logits"] = np.stack(rec["ego_logits"]).astype(np.float32)
+        blob["ego_logits"] = np.stack([np.asarray(x, dtype=np.float32) for x in rec["ego_logits"]])
     for m in LOGIT_POS:
         if rec["logits"][m]:
             blob[f"logits_{m}"] = np.stack(rec["logits"][m]).astype(np.float32)
@@ -99,10 +105,16 @@ def main():
              ("tiny_grow_boxctl_greedy", dict(weight_seed=5, scene_id=4, cond_frames=5, input_cond_frames=2, new_frames=5, control="bbox3d")),
              # the map of the new frames given as init_tokens: the decode loop starts behind a 1031-position prefix (UMGen.py:1184-1201)
              ("tiny_mapgiven_greedy", dict(weight_seed=6, scene_id=5, cond_frames=3, input_cond_frames=2, new_frames=2, control="map")),
-             ("tiny_mapboxgiven_greedy", dict(weight_seed=7, scene_id=6, cond_frames=3, input_cond_frames=2, new_frames=2, control="map+bbox3d"))]
+             ("tiny_mapboxgiven_greedy", dict(weight_seed=7, scene_id=6, cond_frames=3, input_cond_frames=2, new_frames=2, control="map+bbox3d")),
+             # the reference UNDER AUTOCAST (its production arithmetic, UMGen.py:1604-1605): one greedy frame in fp16 and in bf16; the 16-bit engines and
+             # the rounding-aware oracle modes are teacher-forced with these tokens and compared on the recorded rows
+             ("tiny_video_autocast_fp16", dict(weight_seed=1, scene_id=0, cond_frames=3, input_cond_frames=3, new_frames=1, control=False, autocast="fp16")),
+             ("tiny_video_autocast_bf16", dict(weight_seed=1, scene_id=0, cond_frames=3, input_cond_frames=3, new_frames=1, control=False, autocast="bf16"))]
     for name, kw in cases:
         if not only or name in only:
-            run_case(name, cfg, **kw)
+            # the autocast cases run WITHOUT the rule constraint: a blanked slot's pad tokens were never fed back in the run that produced them (stale K/V rows,
+            # UMGen.py:1116-1123), so its output tokens could not be used to teacher-force another implementation through the same computation
+            run_case(name, tiny_config(rule_constrain=False) if kw.get("autocast") else cfg, **kw)
 
 
 if __name__ == "__main__":

@@ -74,6 +74,14 @@ def _mod(name, **attrs):
 
 
 _installed = False
+AUTOCAST_DTYPE = None      # None: the reference's autocast region is a no-op (fp32); torch.float16 / torch.bfloat16: CPU autocast in that type
+
+
+def set_autocast(dtype):
+    """None | torch.float16 | torch.bfloat16: what the reference's `torch.cuda.amp.autocast()` region does from now on."""
+    global AUTOCAST_DTYPE
+    AUTOCAST_DTYPE = dtype
+
 
 
 def install_stubs():
@@ -114,9 +122,12 @@ def install_stubs():
     tv_t = _mod("torchvision.transforms", Compose=_T.Compose, ToTensor=_T.ToTensor)
     _mod("torchvision", transforms=tv_t)
 
-    # the reference hard-codes .cuda() and CUDA autocast; on this CPU box both become no-ops
+    # the reference hard-codes .cuda() and CUDA autocast (UMGen.py:1604-1605); on this CPU box .cuda() is a no-op and the autocast region is
+    # either off (AUTOCAST_DTYPE None: the fp32 goldens) or torch's CPU autocast in the selected 16-bit type (set_autocast: the goldens that pin
+    # the 16-bit modes on the reference's own arithmetic -- linear layers in the 16-bit type with 16-bit outputs, fp32 residual stream by type
+    # promotion, the reference's LayerNorm in fp32, attention through the flash-attn stand-in: 16-bit q / k / v in, fp32 math, 16-bit out)
     torch.Tensor.cuda = lambda self, *a, **k: self
-    torch.cuda.amp.autocast = lambda *a, **k: contextlib.nullcontext()
+    torch.cuda.amp.autocast = lambda *a, **k: (contextlib.nullcontext() if AUTOCAST_DTYPE is None else torch.autocast("cpu", dtype=AUTOCAST_DTYPE))
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
 

@@ -443,3 +443,31 @@ def test_fp16_mode_refuses_a_weight_outside_the_half_range_and_rounds_like_torch
     with pytest.raises(UMGenError, match="does not fit fp16"):
         e.load_tensor(key, w)
     e.close()
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_16bit_engine_vs_the_reference_under_autocast(precision):
+    """The 16-bit engines against the REFERENCE'S OWN autocast arithmetic (UMGen.py:1604-1605): tests/golden/tiny_video_autocast_{fp16,bf16}.npz
+    are one greedy frame of the imported reference with its autocast region live (torch CPU autocast in that type; make_golden.py), the engine is
+    teacher-forced with that run's tokens and compared on the recorded conditioning rows, ego logits and AR logit rows.  Tolerance: tests/test_oracle.py
+    AUTOCAST_BARS -- fp16 4e-3 on logits (measured 2.7e-3), bf16 3e-2 (measured 1.8e-2): the reference under autocast emits 16-bit LOGITS, so half an
+    ulp of the recorded numbers alone is 1e-3 .. 2e-3 (fp16) / 8e-3 .. 1.6e-2 (bf16) and the fp32 restatement sits at the same distance (2.8e-3 / 2.0e-2);
+    the north-star's 1e-3 is met against the fp32 reference goldens in fp32 mode (test_fp32_first_frame_activations_match_reference_golden)."""
+    from tests.test_oracle import AUTOCAST_BARS
+    g = np.load(os.path.join(GOLD, f"tiny_video_autocast_{precision}.npz"))
+    ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
+    cfg = tiny_config(rule_constrain=False).greedy()
+    e = make_engine(cfg, ws, precision)
+    scene = synthetic_scene(sid, n_frames=icf)
+    forced = {m: g[f"out_{m}"][0, icf].astype(np.int64) for m in MOD_ORDER}
+    toks, tr = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, trace=True, forced=forced)
+    e.close()
+    d = {"cond": float(np.abs(tr["cond"][COND_ROWS] - g["cond_rows"][0]).max()), "ego": float(np.abs(tr["ego_logits"] - g["ego_logits"][0]).max())}
+    for m, pos in LOGIT_POS.items():
+        d[m] = float(np.abs(tr[f"logits_{m}"][pos] - g[f"logits_{m}"]).max())
+    agree = float(np.mean([np.mean(toks[m] == forced[m]) for m in MOD_ORDER]))
+    print(f"tiny {precision} engine vs the reference under autocast: max abs deviation {d}; own arg-max == the reference's token at {agree:.4f} of the positions")
+    bar = AUTOCAST_BARS[precision]
+    assert d["cond"] <= bar["cond"] and d["ego"] <= bar["ego"], d
+    for m in LOGIT_POS:
+        assert d[m] <= bar["logits"], (m, d)
