@@ -301,3 +301,38 @@ def test_background_workers_reproduce_the_foreground_engine(task, precision):
         assert tms["1"]["prefix_passes"] == frames and tms["0"]["prefix_passes"] == frames
     for m in MOD_ORDER:
         np.testing.assert_array_equal(outs["1"][m], outs["0"][m], err_msg=m)
+
+
+def test_background_workers_with_a_long_window_and_eager_launches():
+    """A window of 22 history slots (the temporal kernel's 32-slot form: all 512 threads of a worker workgroup) and eager launches instead of graph replays:
+    same tokens as the foreground engine; and a frame through `umgen_frame` between two rollouts (no pass may be left pending, none is started)."""
+    from tests.golden.make_full_width_golden import config as width_config
+    from umgen_amd.weights import synthetic_state_dict as ssd
+    cfg = width_config("deep", max_frame_len=32)
+    sd = ssd(cfg, seed=6)
+    T, frames = 22, 2
+    scene = synthetic_scene(23, n_frames=T)
+    outs = {}
+    for bg, graphs in (("0", True), ("1", False)):
+        old = os.environ.get("UMGEN_BG_ENGINE")
+        os.environ["UMGEN_BG_ENGINE"] = bg
+        try:
+            e = Engine(cfg, precision="bf16", max_batch=1, max_cond_frames=T, use_graphs=graphs)
+        finally:
+            if old is None:
+                del os.environ["UMGEN_BG_ENGINE"]
+            else:
+                os.environ["UMGEN_BG_ENGINE"] = old
+        e.load_state_dict(sd)
+        e.finalize()
+        outs[bg] = e.rollout(scene, frames, cond_frames=T, input_cond_frames=T, seeds=[4])
+        if bg == "1":
+            assert e.timings()["overlapped_frames"] == frames - 1, e.timings()
+            toks, _ = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, seed=4)
+            again = e.rollout(scene, frames, cond_frames=T, input_cond_frames=T, seeds=[4])
+            for m in MOD_ORDER:
+                np.testing.assert_array_equal(toks[m], outs["1"][m][0, T], err_msg=f"umgen_frame {m}")
+                np.testing.assert_array_equal(again[m], outs["1"][m], err_msg=f"second rollout {m}")
+        e.close()
+    for m in MOD_ORDER:
+        np.testing.assert_array_equal(outs["1"][m], outs["0"][m], err_msg=m)

@@ -961,6 +961,12 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                      io.smp->rule_constrain, io.smp->merge_ar_tar, io.smp->only_ar};
     const umgen_trace* tr = io.trace;
     const bool forced = tr && tr->forced_map;
+    if (e->bg_pending && e->bg_engine) {
+        // a pass whose frame failed before its drain: whatever the workers have done of it is worthless -- empty the queue, the slot caches are not to be trusted
+        HIPCHK(e, hipMemsetAsync(&e->d_bgq->n_ops, 0, 4, fg));
+        e->bg_pending = false;
+        e->px.valid = false;
+    }
     if (e->bg_pending && !e->bg_engine) {   // the background pass reads the token arrays and owns the TAR scratch buffers until it is done
         const auto tw0 = std::chrono::steady_clock::now();
         HIPCHK(e, hipEventSynchronize(e->ev_bg_done));
@@ -1937,7 +1943,7 @@ int umgen_create(const umgen_config* cfg, umgen_engine** out) {
         if (int rc = dalloc(e, &e->eng_ticket, (size_t)16)) return rc;
         if (int rc = dalloc(e, &e->eng_err, (size_t)4)) return rc;
         HIPCHK(e, hipMemset(e->eng_ticket, 0, 64));
-        if (getenv("UMGEN_DEBUG_TIMING")) {
+        if (getenv("UMGEN_DEBUG_TIMING") && !e->bg_engine) {      // (per-phase stamps: the instantiation without background workers -- UMGEN_BG_ENGINE=0 for a one-scene engine)
             if (int rc = dalloc(e, &e->eng_stamps, (size_t)16)) return rc;
             HIPCHK(e, hipMemset(e->eng_stamps, 0, 128));
         }
