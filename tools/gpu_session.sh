@@ -26,6 +26,9 @@
 #   widestep   tools/wide_step_time.py: one 2x-width decode step at 64 / 1100 / 2200 keys, shipped library + measurement builds WIDE_VARIANTS="..." -> r05_wide_step_time.txt
 #   widevar    the 2x-width bench with per-phase stamps of the chip-wide engine, shipped + WIDE_VARIANTS        -> r05_bench_widevar_<v>.{json,err}
 #   wideprof / widepmc   rocprofv3 kernel statistics / FETCH_SIZE of the chip-wide engine  -> r05_prof_wide2x.csv, r05_pmc_fetch_size_wide_engine.csv
+#   contention one-scene engine on 4 XCD groups, and under a synthetic load on the other four (measurement build: tools/build_variant.sh burn -DUMGEN_ENG_BURN=1) -> r06_engine_contention.txt
+#   pmcb       the FETCH_SIZE pass at 4 / 8 scenes per GPU                               -> r06_pmc_fetch_size_engine_b{4,8}.csv
+#   (round 6) tools/dbg/bg_check.py: background workers vs the foreground engine, token for token; tools/dbg/trace_gaps.sh + trace_gaps.py: per-frame kernel durations out of a kernel trace
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 R=r06
