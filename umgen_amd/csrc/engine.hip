@@ -986,8 +986,10 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
     // the background pass runs on a quarter of the CUs (measured 3.1x the whole-window time of the same stacks on all CUs): only
     // worth launching when that is expected to hide behind the decode loop (numbers of the previous frames of this engine)
     if (e->last_B != B) { e->last_B = B; e->last_full_pre_ms = 0.f; }
-    // (on the decode engine's idle XCDs the pass of a one-scene frame takes ~1800 of its 2206 decode steps, 3.3x its foreground time: profiles/r06_bg_worker_trace.txt)
-    const bool hides = e->overlap_mode == 2 || e->last_full_pre_ms <= 0.f || (e->bg_engine ? 3.4f : 3.3f) * e->last_full_pre_ms < 0.95f * e->last_oar_ms;
+    // (On the decode engine's idle XCDs the pass of a one-scene frame takes ~1800 of its 2206 decode steps, 3.3 x its foreground time (profiles/r06_bg_worker_trace.txt), and what
+    //  the steps leave of it drains at 2.7 x: starting it pays as long as about two thirds of it hide -- 2.3 x the foreground time inside the decode loop.  A tighter rule (3.4 x, 5 %
+    //  slack) switched the pass OFF on a box whose stacks ran 12 % slower: fp16 1737 instead of 2041 scene-tokens/s.)
+    const bool hides = e->overlap_mode == 2 || e->last_full_pre_ms <= 0.f || (e->bg_engine ? 2.3f * e->last_full_pre_ms < e->last_oar_ms : 3.3f * e->last_full_pre_ms < 0.95f * e->last_oar_ms);
     const bool ov_active = e->overlap && !e->overlap_suspended && hides && !e->profiling && !tr && (B == 1 || e->overlap_mode == 2);
     // the ego / TAR phase runs on all CUs; the decode loop leaves the background stream's XCDs alone only when a pass can follow
     hipStream_t const pre = e->full_stream ? e->full_stream : fg;   // (the background stream is idle until this phase is over)
