@@ -62,7 +62,16 @@ template <typename TT>
 __device__ __noinline__ void bg_ln(const BgOp* op, int E, int widx, int nwk, int done, int n) {      // 8 rows per unit; l0 = row stride, l1 = rows
     const BgOpArgs o = load_uniform(&op->a);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int u = done; u < done + n; ++u) {
+    int u = done;
+    if (E <= 768) {      // four units at a time: a wave's four rows with all their loads in flight (the same arithmetic per row)
+        for (; u + 4 <= done + n; u += 4) {
+            long rows[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rows[r] = ((long)widx + (long)(u + r) * nwk) * 8 + wave;
+            layernorm_rows<TT, 4, 12>(reinterpret_cast<const float*>(o.p0), o.l0, E, reinterpret_cast<const float*>(o.p1), reinterpret_cast<TT*>(o.p2), rows, o.l1, lane);
+        }
+    }
+    for (; u < done + n; ++u) {
         const long row = ((long)widx + (long)u * nwk) * 8 + wave;
         if (row < o.l1) layernorm_row<TT>(reinterpret_cast<const float*>(o.p0), o.l0, E, reinterpret_cast<const float*>(o.p1), reinterpret_cast<TT*>(o.p2), row, lane);
     }
@@ -144,8 +153,8 @@ __device__ __forceinline__ void bg_worker(BgQueue* q, int widx, int nwk, unsigne
     unsigned* const st = &q->state[widx][0];
     auto ld = [](const unsigned* p) { return (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
     auto stw = [](unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // Leaving the launch with units done in it: write this XCD's dirty L2 lines back NOW, under the engine part's last microseconds -- left to the
-    // end-of-kernel release they sat between every decode step and its head launch (step 458 -> 469 us with the workers' tiles still dirty).
+    // Leaving the launch with units done in it: write this XCD's dirty L2 lines back now, under the engine part's last microseconds, instead of at the end of the kernel
+    // (measured: no difference in the step time -- the engine launch is longer while workers run because they share HBM and the fabric with it, not because of this write-back).
     bool worked = false;
     auto leave = [&]() {
         if (!worked) return;

@@ -1348,7 +1348,23 @@ int run_frame(umgen_engine* e, const FrameIO& io) {
                 return e->fail(UMGEN_E_HIP, "background pass incomplete: worker %d stopped at op %u of %zu", wk, e->bg_state_host[(size_t)wk * 4], e->bg_rec.ops.size());
             }
         e->px.valid = true;
-        if (getenv("UMGEN_DEBUG_TIMING")) fprintf(stderr, "[umgen] background pass: %zu ops, drain launch %.2f ms\n", e->bg_rec.ops.size(), dms);
+        if (getenv("UMGEN_DEBUG_TIMING")) {
+            fprintf(stderr, "[umgen] background pass: %zu ops, drain launch %.2f ms\n", e->bg_rec.ops.size(), dms);
+            // where a worker's time goes, by kind: sum over the ops of (units per worker) x (the slowest batch's time per unit) -- an upper bound
+            std::vector<unsigned> est(e->bg_rec.ops.size());
+            if (hipMemcpy(est.data(), &e->d_bgq->est[0], est.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+                double by_kind[8] = {}, gemm_by_mode[4] = {};
+                for (size_t i = 0; i < est.size(); ++i) {
+                    const BgOpHead& h = e->bg_rec.ops[i].h;
+                    const double us = std::ceil((double)h.n_units / 128.0) * ((double)est[i] - 20.0) / 1.125 / 100.0;
+                    by_kind[h.kind & 7] += us;
+                    if (h.kind == BG_GEMM) gemm_by_mode[h.mode & 3] += us;
+                }
+                fprintf(stderr, "[umgen] per-worker time by kind (ms, upper bound): gemm %.1f (store %.1f, resid %.1f, vt %.1f) ln %.1f attn_s %.1f attn_t %.1f embed %.1f warp %.1f\n", by_kind[BG_GEMM] / 1e3,
+                        gemm_by_mode[GEMM_STORE] / 1e3, gemm_by_mode[GEMM_RESID] / 1e3, gemm_by_mode[GEMM_VT] / 1e3, by_kind[BG_LN] / 1e3, by_kind[BG_ATTN_S] / 1e3, by_kind[BG_ATTN_T] / 1e3,
+                        by_kind[BG_EMBED] / 1e3, by_kind[BG_WARP] / 1e3);
+            }
+        }
     }
     if (eng_err) {   // a hand-off of the decode engine timed out (e.g. two engines sharing one GPU): never return tokens from such a frame
         (void)hipMemset(wide ? e->wide_err : e->eng_err, 0, sizeof(unsigned));
