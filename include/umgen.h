@@ -22,7 +22,8 @@
 extern "C" {
 #endif
 
-#define UMGEN_ABI_VERSION 3   /* 2: umgen_rollout takes given_map / given_bbox3d; umgen_timings::decode_batched.  3: umgen_timings::prefix_passes; decode_engine values 1 / 3 (2 retired) */
+#define UMGEN_ABI_VERSION 4   /* 2: umgen_rollout takes given_map / given_bbox3d; umgen_timings::decode_batched.  3: umgen_timings::prefix_passes; decode_engine values 1 / 3 (2 retired).
+                               * 4: umgen_trace::given_map / given_bbox3d (umgen_frame with a given-token prefix: traced logits behind a prefix pass) */
 
 enum {
     UMGEN_OK = 0,
@@ -86,6 +87,8 @@ typedef struct umgen_trace {
     const int64_t *forced_pose, *forced_map, *forced_bbox3d, *forced_image; /* teacher forcing, [S_mod] */
     int32_t *counters;      /* [8] events of the frame: 0 pad-avoid resamples, 1 control resamples, 2 rule checks,
                                3 rule collisions, 4 slots blanked, 5 sampled != forced token (teacher forcing only) */
+    const int64_t *given_map, *given_bbox3d; /* NULL, or the frame's GIVEN map [1024] (and boxes [660], only behind a given map): umgen_rollout's
+                               given_* for one frame (UMGen.py:1184-1201), so that the logits behind a given-token prefix can be traced */
 } umgen_trace;
 
 /* Event-timed phases of the last umgen_rollout call (milliseconds, HIP events on the engine stream). */

@@ -271,8 +271,14 @@ def _attention(q, k, v, n_head: int, causal: bool, round_p=None, perm: Optional[
 
 class OracleUMGen:
     def __init__(self, cfg: RolloutConfig, state_dict: Dict[str, np.ndarray], weight_dtype: str = "fp32", perm_seed: Optional[int] = None,
-                 mfma_noise: bool = False):
+                 mfma_noise: bool = False, prefix_contract: str = "decode"):
         self.cfg = cfg
+        # How the GIVEN-token prefix of a frame (UMGen.py:1184-1201: the first iteration of infer_oar_net pushes the whole prefix through the BlockOAR layers at once) is
+        # rounded in the *_engine modes.  "decode": like every decode step (fp32 activations, only the K/V rows in 16 bits) -- the engine's step-by-step replay.  "stack": the
+        # engine's ONE-PASS form (engine.hip run_prefix_prefill): positions 0 .. P - 2 go through the TAR stacks' kernels -- 16-bit LayerNorm outputs, q | k | v, attention
+        # probabilities and outputs, MLP hidden values; fp32 residual stream -- and position P - 1 is a decode step on their K/V rows.
+        assert prefix_contract in ("decode", "stack"), prefix_contract
+        self.prefix_contract = prefix_contract
         self._mfma_noise = mfma_noise and perm_seed is not None
         assert weight_dtype in ("fp32", "bf16", "bf16_engine", "fp16", "fp16_engine"), weight_dtype
         self._round = _fp16 if weight_dtype.startswith("fp16") else _bf16
@@ -378,6 +384,19 @@ class OracleUMGen:
         x = x + a
         x = x + self._mlp(self._ln(x, key + ".ln_2"), key + ".mlp")
         return x, kv
+
+    def _prefix_pass(self, x, kv):
+        """The engine's one-pass form of the given-token prefix (engine.hip run_prefix_prefill; prefix_contract == "stack"): rows 0 .. P - 2 with the TAR stacks'
+        rounding points and the causal S x S attention, row P - 1 as a decode step on their K/V rows.  Fills kv, returns x of all P rows."""
+        r = self._r
+        xa, xb = x[:, :-1], x[:, -1:]
+        for i in range(self.cfg.n_oar_layer):
+            key = f"transformer.OAR.{i}"
+            a, (ka, va) = self._self_attn(r(self._ln(xa, key + ".ln_1")), key + ".temporal_attn", True, site="tar_spatial")
+            xa = xa + a
+            xa = xa + self._mlp(r(self._ln(xa, key + ".ln_2")), key + ".mlp", tar=True)
+            xb, kv[i] = self._block_oar(xb, key, (ka, va))
+        return torch.cat([xa, xb], dim=1)
 
     def _decoder(self, x, p, key):
         """Decoder.forward_func (module.py:662-683) + FlashCrossAttention.forward (module.py:482-509)."""
@@ -597,9 +616,12 @@ class OracleUMGen:
             if pos == SEQ_LEN:
                 break  # img-eos: the reference still runs a forward whose output is unused (UMGen.py:1209)
             x = x_in
-            for i in range(cfg.n_oar_layer):
-                x, kv_i = self._block_oar(x, f"transformer.OAR.{i}", (kv[i] if kv[i] is not None else (None, None)))
-                kv[i] = kv_i
+            if self.engine_rounding and self.prefix_contract == "stack" and x.shape[1] > 1 and kv[0] is None:
+                x = self._prefix_pass(x, kv)
+            else:
+                for i in range(cfg.n_oar_layer):
+                    x, kv_i = self._block_oar(x, f"transformer.OAR.{i}", (kv[i] if kv[i] is not None else (None, None)))
+                    kv[i] = kv_i
             h = self._ln(x[:, -1:], "transformer.ln_oar")                                  # [1,1,C]
             if pos in d_pos:
                 nxt = axe[d_pos[pos]][None, None]

@@ -208,6 +208,40 @@ def test_given_map_prefix_pass_at_production_width_batch_and_engine(precision):
     assert agree > (0.90 if precision == "bf16" else 0.97), agree
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_16bit_prefix_pass_logits_vs_the_rounding_aware_oracle(precision):
+    """the one-pass form of the given-token prefix (engine.hip run_prefix_prefill) has its own arithmetic in the 16-bit modes -- the TAR stacks' rounding points
+    for positions 0 .. P - 2 instead of the decode step's fp32 activations -- and was only compared with the step-by-step replay.  Here it faces the rounding-aware
+    oracle's restatement of exactly that form (`prefix_contract="stack"`, tests/golden/make_prefix_golden.py) at production width: a frame with a GIVEN map, teacher-forced
+    with the oracle's tokens, traced through `umgen_frame` (ABI 4: `umgen_trace::given_map`); the bbox3d / image logit rows BEHIND the prefix -- every one of them a function of
+    the prefix pass's K/V rows -- within the accumulation-order noise of the production width (bars: 3e-3 bf16, 4e-4 fp16 = twice the ensemble spreads of the full_width
+    case; the two contracts themselves differ by 6e-5 / 8e-6 at this depth)."""
+    g = np.load(os.path.join(GOLD, f"full_width_mapgiven_{precision}_engine.npz"))
+    from tests.golden.make_prefix_golden import SCENE_ID as PS, WEIGHT_SEED as PW
+    from umgen_amd.synth import synthetic_given_map
+    assert [int(x) for x in g["meta"]] == [PW, PS]
+    cfg = width_config("full_width")
+    scene = synthetic_scene(PS, n_frames=2)
+    forced = {m: g[f"tok_{m}"].astype(np.int64) for m in MOD_ORDER}
+    given = {"map": synthetic_given_map(PS, n_frames=1)["map"][0, 0]}
+    np.testing.assert_array_equal(given["map"], forced["map"])
+    e = Engine(cfg, precision=precision, max_cond_frames=4)
+    e.load_state_dict(synthetic_state_dict(cfg, seed=PW))
+    e.finalize()
+    toks, tr = e.frame({m: scene[m][0] for m in MOD_ORDER}, frame_idx=0, trace=True, forced=forced, given=given)
+    t = e.timings()
+    e.close()
+    assert t["prefix_passes"] == 1 and t["decode_engine"] == 1, t
+    bar = {"bf16": 3e-3, "fp16": 4e-4}[precision]
+    worst = {}
+    for m in ("bbox3d", "image"):
+        worst[m] = float(np.abs(tr[f"logits_{m}"][LOGIT_POS[m]] - g[f"logits_{m}"]).max())
+    print(f"full_width {precision}: logits behind the one-pass prefix vs the rounding-aware oracle (stack contract): max abs deviation {worst} (bar {bar}); sampled != forced: {tr['counters']['sampled_ne_forced']}")
+    for m, d in worst.items():
+        assert d <= bar, (m, d)
+    np.testing.assert_array_equal(toks["map"], given["map"])
+
+
 def test_bf16_teacher_forced_logits_at_2x_width_vs_rounding_aware_oracle_golden():
     """Config #5's doubled width (E=1536, H=32; the chip-wide decode engine of csrc/oar_engine_wide.hip -- asserted) in bf16 against one run of the rounding-aware oracle
     (no ensemble at this width: one oracle frame takes ~10 CPU minutes): 1.5e-2 absolute / 4e-3 relative rms on logits, every

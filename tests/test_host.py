@@ -131,7 +131,7 @@ def test_engine_fails_loudly_without_gpu():
 def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_lib.Config) == 24 * 4
     assert ctypes.sizeof(_lib.Sampling) == 48
-    assert ctypes.sizeof(_lib.Trace) == 10 * 8
+    assert ctypes.sizeof(_lib.Trace) == 12 * 8
 
 
 def test_vq_decoder_key_inventory_and_checkpoint_unwrapping(tmp_path):

@@ -55,7 +55,8 @@ class Trace(C.Structure):
                 ("logits_image", C.POINTER(C.c_float)),
                 ("forced_pose", C.POINTER(C.c_int64)), ("forced_map", C.POINTER(C.c_int64)),
                 ("forced_bbox3d", C.POINTER(C.c_int64)), ("forced_image", C.POINTER(C.c_int64)),
-                ("counters", C.POINTER(C.c_int32))]
+                ("counters", C.POINTER(C.c_int32)),
+                ("given_map", C.POINTER(C.c_int64)), ("given_bbox3d", C.POINTER(C.c_int64))]
 
 
 class Timings(C.Structure):

@@ -2167,6 +2167,23 @@ int umgen_frame(umgen_engine* e, int32_t T, const int64_t* pose, const int64_t* 
     std::vector<int> out(kTokPerFrame);
     FrameIO io{1, T, p.data(), m.data(), bx.data(), im.data(), ctrl_pose ? cp.data() : nullptr, cs.empty() ? nullptr : cs.data(),
                frame_idx, sampling, trace, out.data()};
+    // the frame's GIVEN tokens (umgen_rollout's given_* for one frame: the predefined-token prefix of infer_oar_net, UMGen.py:1184-1201)
+    std::vector<int> gm, gb;
+    if (trace && trace->given_bbox3d && !trace->given_map)
+        return e->fail(UMGEN_E_UNSUPPORTED, "given bbox3d tokens without a given map: the reference would put them on the map's positions (UMGen.py:1190-1201)");
+    if (trace && trace->given_map) {
+        if (control_test) return e->fail(UMGEN_E_UNSUPPORTED, "given tokens and control_test exclude each other");
+        if (int rc = check_tokens(e, "given map", trace->given_map, kNMap, e->cfg.map_vocab, false)) return rc;
+        gm.resize(kNMap);
+        for (int i = 0; i < kNMap; ++i) gm[i] = (int)trace->given_map[i];
+        io.given_map = gm.data();
+        if (trace->given_bbox3d) {
+            if (int rc = check_tokens(e, "given bbox3d", trace->given_bbox3d, kNBox, e->cfg.bbox3d_vocab, false)) return rc;
+            gb.resize(kNBox);
+            for (int i = 0; i < kNBox; ++i) gb[i] = (int)trace->given_bbox3d[i];
+            io.given_box = gb.data();
+        }
+    }
     if (int rc = run_frame_any(e, io)) return rc;
     for (int i = 0; i < kNPose; ++i) out_pose[i] = out[i];
     for (int i = 0; i < kNMap; ++i) out_map[i] = out[kOffMap + i];

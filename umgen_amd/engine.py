@@ -34,7 +34,7 @@ class Engine:
         self.precision = precision
         self.max_batch = max_batch
         c = _lib.Config(
-            abi_version=3, n_embd=cfg.n_embd, n_head=cfg.n_head, n_ego_tar_layer=cfg.n_ego_tar_layer,
+            abi_version=4, n_embd=cfg.n_embd, n_head=cfg.n_head, n_ego_tar_layer=cfg.n_ego_tar_layer,
             n_ego_ca_layer=cfg.n_ego_ca_layer, n_map_tar_layer=cfg.n_map_tar_layer, n_box_tar_layer=cfg.n_box_tar_layer,
             n_tar_layer=cfg.n_tar_layer, n_oar_layer=cfg.n_oar_layer, pose_vocab=cfg.pose_vocab_size,
             map_vocab=cfg.map_vocab_size, bbox3d_vocab=cfg.bbox3d_vocab_size, img_vocab=cfg.img_vocab_size,
@@ -163,8 +163,9 @@ class Engine:
 
     def frame(self, window: Dict[str, np.ndarray], frame_idx: int = 0, ctrl: Optional[Dict[str, np.ndarray]] = None,
               control_test: bool = False, seed: int = 0, sampling: Optional[RolloutConfig] = None,
-              forced: Optional[Dict[str, np.ndarray]] = None, trace: bool = False):
-        """One frame of one scene.  window: mod -> [T, S_mod].  Returns (tokens dict, trace dict or None)."""
+              forced: Optional[Dict[str, np.ndarray]] = None, trace: bool = False, given: Optional[Dict[str, np.ndarray]] = None):
+        """One frame of one scene.  window: mod -> [T, S_mod].  Returns (tokens dict, trace dict or None).
+        given: {"map": [1024]} or {"map": ..., "bbox3d": [660]}: the frame's GIVEN tokens (init_tokens of `rollout` for one frame)."""
         cfg = self.cfg
         w = {m: _i64(window[m]) for m in MOD_ORDER}
         T = w["pose"].shape[0]
@@ -175,8 +176,13 @@ class Engine:
         tr = None
         tbuf = None
         fz = None
-        if trace or forced is not None:
+        gz = None
+        if trace or forced is not None or given is not None:
             tr = _lib.Trace()
+            if given is not None:
+                gz = {m: _i64(given[m]).reshape(-1) for m in given}
+                tr.given_map = _p64(gz["map"]) if "map" in gz else None
+                tr.given_bbox3d = _p64(gz["bbox3d"]) if "bbox3d" in gz else None
             counters = np.zeros(8, np.int32)
             tr.counters = counters.ctypes.data_as(C.POINTER(C.c_int32))
             fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
@@ -196,7 +202,7 @@ class Engine:
             self._h, T, _p64(w["pose"]), _p64(w["map"]), _p64(w["bbox3d"]), _p64(w["image"]), _p64(cp), _p64(cb),
             int(control_test), C.byref(smp), frame_idx, C.byref(tr) if tr is not None else None,
             _p64(outs["pose"]), _p64(outs["map"]), _p64(outs["bbox3d"]), _p64(outs["image"])), "frame")
-        del keep, fz
+        del keep, fz, gz
         if tr is not None:
             tbuf = tbuf if tbuf is not None else {}
             tbuf["counters"] = dict(zip(("pad_avoid", "control_resample", "rule_checked", "rule_collision", "rule_blanked",
