@@ -96,3 +96,28 @@ def test_rounding_aware_oracle_vs_the_reference_under_autocast(precision):
         assert mine[m] <= bar["logits"], (m, mine)
     for k in mine:
         assert mine[k] <= 1.25 * f32[k] + 1e-5, (k, mine[k], f32[k])
+
+
+def test_oracle_one_pass_prefix_contract_is_a_small_perturbation_of_the_replay_contract():
+    """`OracleUMGen(prefix_contract="stack")` -- the restatement of the engine's one-pass given-token prefix (TAR-stack rounding points for positions 0 .. P - 2;
+    tests/golden/make_prefix_golden.py records it at production width for the -m gpu test) -- against the default "decode" contract on the tiny map-given case: same
+    greedy tokens, logits behind the prefix within 5e-4 (bf16); and the fp32 mode, where no contract rounds anything, ignores the switch (the reference golden still holds)."""
+    cfg = tiny_config(rule_constrain=False).greedy()
+    sd = synthetic_state_dict(cfg, seed=6)
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    outs = {}
+    for pc in ("decode", "stack"):
+        o = OracleUMGen(cfg, sd, weight_dtype="bf16_engine", prefix_contract=pc)
+        out = o.inference(1, 3, synthetic_scene(5, n_frames=2), input_cond_frames=2, init_tokens=golden_init_tokens(5, 1, 3), trace=True)
+        outs[pc] = (out, o.trace["logits"][0])
+    for m in ("bbox3d", "image"):
+        np.testing.assert_array_equal(outs["decode"][0][m], outs["stack"][0][m], err_msg=m)
+        d = float(np.abs(outs["decode"][1][m] - outs["stack"][1][m]).max())
+        assert 0.0 < d < 5e-4, (m, d)
+    g = np.load(os.path.join(GOLD, "tiny_mapgiven_greedy.npz"))
+    ws, sid, cf, icf, nf, ctl = [int(x) for x in g["meta"]]
+    cfg32 = tiny_config().greedy()
+    o = OracleUMGen(cfg32, synthetic_state_dict(cfg32, seed=ws), prefix_contract="stack")
+    out = o.inference(1, cf, synthetic_scene(sid, n_frames=icf), input_cond_frames=icf, init_tokens=golden_init_tokens(sid, 1, ctl))
+    for m in ("pose", "map", "bbox3d", "image"):
+        np.testing.assert_array_equal(out[m][:, :icf + 1], g[f"out_{m}"].astype(np.int64)[:, :icf + 1], err_msg=m)
