@@ -40,7 +40,7 @@ struct BgQueue {
     EmbedTables tb;
     unsigned state[kBgMaxWorkers][4];        // per worker: op index; units of it done | arrived << 31; start (100 MHz, low word) of the batch of units in flight; -
     unsigned arrive[kBgMaxOps];              // workers that have published their share of op k
-    unsigned est[kBgMaxOps];                 // ticks per unit of op k: host guess, raised by the workers to 9/8 of the slowest batch they have seen
+    unsigned est[kBgMaxOps];                 // ticks per unit of op k: host guess, then tracked by the workers (9/8 of a batch's time per unit: half-way up at once, 1/64 of the way down per batch)
     BgOp ops[kBgMaxOps];
 };
 

@@ -187,7 +187,10 @@ __device__ __forceinline__ void bg_worker(BgQueue* q, int widx, int nwk, unsigne
             if (tid == 0) {
                 const unsigned long long t0 = wall_clock64();
                 const unsigned est = max(1u, __hip_atomic_load(&q->est[op], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const long fit = drain ? (long)h.chunk : (deadline > t0 ? (long)((deadline - t0) / est) : 0);
+                long fit = drain ? (long)h.chunk : (deadline > t0 ? (long)((deadline - t0) / est) : 0);
+                // progress whatever the estimate says: a workgroup that stands at the very start of a launch with the whole budget in front of it runs ONE unit even if
+                // its estimate does not fit (an estimate that one slow batch has pushed beyond the budget would otherwise park the whole pass in front of this op until the drain)
+                if (fit == 0 && !worked && deadline > t0 && t0 - t_k0 < 2000ull) fit = 1;
                 const int n0 = (int)min((long)min(mine - done, h.chunk), fit);
                 ctl[0] = n0;
                 if (n0 > 0) {      // (the units count as done from here on: nobody but this workgroup reads the word before its arrival)
@@ -202,9 +205,14 @@ __device__ __forceinline__ void bg_worker(BgQueue* q, int widx, int nwk, unsigne
             if (n <= 0) { leave(); return; }
             worked = true;
             bg_run<TT>(h, &q->ops[op], q, widx, nwk, done, n);
-            if (tid == 0) {      // per-unit time of this op, as the next frame's pass will see it (ops keep their index from frame to frame)
+            if (tid == 0) {      // per-unit time of this op, as the next frame's pass will see it (ops keep their index from frame to frame): up fast, down slowly --
+                // the estimate follows the slow tail of the ~128 batches an op is run in per pass and forgets an outlier within a pass or two (as a running MAXIMUM it crept up
+                // from pass to pass -- GEMM 460 -> 497 ms per worker over four passes -- and one slow batch could park an op for good); races between workers lose an update
                 const unsigned dt = ((unsigned)wall_clock64() - ld(st + 2)) / (unsigned)n;
-                atomicMax(&q->est[op], dt + (dt >> 3) + 20u);
+                const unsigned mine_est = dt + (dt >> 3) + 20u;
+                const unsigned old = __hip_atomic_load(&q->est[op], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned upd = mine_est > old ? old + ((mine_est - old + 1u) >> 1) : old - ((old - mine_est) >> 6);
+                __hip_atomic_store(&q->est[op], upd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             continue;
         }

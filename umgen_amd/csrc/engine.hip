@@ -925,7 +925,7 @@ int launch_prefix(umgen_engine* e, const FrameIO& io, const std::vector<int>& eg
         for (size_t i = 0; same && i < rec.ops.size(); ++i) same = memcmp(&rec.ops[i].h, &e->bg_rec.ops[i].h, sizeof(BgOpHead)) == 0;
         e->bg_rec = std::move(rec);
         // header: op count, engine_ticks = 0 (the first launch measures, the workers start with the second), margin 10 us, the embedding tables
-        e->bg_head.w[0] = (unsigned)e->bg_rec.ops.size(); e->bg_head.w[1] = 0u; e->bg_head.w[2] = (unsigned)(getenv("UMGEN_BG_MARGIN_US") ? atoi(getenv("UMGEN_BG_MARGIN_US")) * 100 : 1500); e->bg_head.w[3] = 0u;
+        e->bg_head.w[0] = (unsigned)e->bg_rec.ops.size(); e->bg_head.w[1] = 0u; e->bg_head.w[2] = (unsigned)(getenv("UMGEN_BG_MARGIN_US") ? atoi(getenv("UMGEN_BG_MARGIN_US")) * 100 : 1000); e->bg_head.w[3] = 0u;
         e->bg_head.tb = e->tb;
         static_assert(offsetof(BgQueue, tb) == 16 && offsetof(BgQueue, state) == 16 + sizeof(EmbedTables), "BgQueue header layout");
         HIPCHK(e, hipMemcpyAsync(&e->d_bgq->n_ops, &e->bg_head, sizeof(e->bg_head), hipMemcpyHostToDevice, fg));
